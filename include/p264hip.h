@@ -1,0 +1,143 @@
+/* p264hip.h - C ABI of the MI355X (gfx950) macroblock-reconstruction layer.
+ *
+ * This is the CPU->GPU seam of the decoder: the host keeps the serial CAVLC
+ * parse and hands one p264hip_picture_t per coded picture to this layer, which
+ * runs dequant + inverse transforms, intra prediction, motion compensation and
+ * the in-loop deblocking filter as hand-written HIP kernels.
+ *
+ * What each entry point stands in for in the reference (lspbeyond/p264decoder):
+ *   p264hip_picture_t / p264hip_mb_t  <- what p264_macroblock_decode and the deblocking
+ *        driver read from h->mb.* / h->dct.*  (core/core.h:330-341, 344-463)
+ *   p264hip_submit / p264hip_reconstruct <- the per-MB reconstruction driver
+ *        decoder/macroblock.c:755-934 plus the picture post-process sequence
+ *        decoder/decoder.c:635-661 (deblock; the border pads and half-pel planes are
+ *        replaced by clamped on-the-fly interpolation inside the MC kernel)
+ *   p264hip_read_frame  <- the plane aliasing at decoder/decoder.c:652-657
+ *   frame slots          <- h->frames.reference[] (decoder/lists.c:152-228)
+ *
+ * Plain C types only (no torch / C++ types).  All functions return 0 on success and a
+ * negative P264HIP_E* code on failure; p264hip_last_error() gives a message.
+ */
+#ifndef P264HIP_H
+#define P264HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P264HIP_MAX_REFS 16
+
+/* macroblock classes (our own numbering; cf. core/macroblock.h:42-65) */
+enum {
+    P264_MB_I4x4   = 0,
+    P264_MB_I16x16 = 1,
+    P264_MB_IPCM   = 2,   /* reserved: rejected by the reference (decoder/macroblock.c:510-514) */
+    P264_MB_P_L0   = 3,   /* 16x16, 16x8, 8x16 */
+    P264_MB_P_8x8  = 4,
+    P264_MB_P_SKIP = 5
+};
+#define P264_MB_IS_INTRA(t) ((t) <= P264_MB_IPCM)
+
+enum { P264_SLICE_P = 0, P264_SLICE_I = 2 };
+
+enum {
+    P264HIP_OK = 0,
+    P264HIP_EINVAL = -1,
+    P264HIP_ENODEV = -2,      /* no usable HIP device: the product never falls back to the CPU */
+    P264HIP_ENOMEM = -3,
+    P264HIP_EHIP = -4
+};
+
+/* coef_mask bits */
+#define P264_COEF_LUMA_DC   (1u << 24)   /* Intra16x16 DC block present (16 levels, zig-zag order) */
+#define P264_COEF_CHROMA_DC (1u << 25)   /* one packed block: Cb DC[0..3], Cr DC[4..7] (raster 2x2) */
+
+/* One per macroblock, 16 bytes.  Everything is as parsed (before dequantisation). */
+typedef struct p264hip_mb {
+    uint8_t  mb_type;      /* P264_MB_* */
+    uint8_t  qp;           /* luma QP as the reference stores it for the MB (core/macroblock.c:1247-1252) */
+    uint8_t  cbp;          /* bits 0-3: luma 8x8 coded, bits 4-5: chroma (0 none, 1 DC, 2 DC+AC) */
+    uint8_t  intra_modes;  /* bits 0-1 intra16x16_pred_mode, bits 4-5 intra_chroma_pred_mode (as coded) */
+    uint32_t coef_mask;    /* bit b<24: 4x4 block b has total_coeff>0 (0-15 luma in decode order
+                              core/macroblock.h:194-201, 16-19 Cb, 20-23 Cr); | P264_COEF_* */
+    uint32_t coef_index;   /* index, in 16-level blocks, of this MB's first packed block */
+    uint8_t  avail;        /* P264_AVAIL_*: neighbouring MBs usable for intra prediction
+                              (core/macroblock.c:926-1033; picture border / slice membership) */
+    uint8_t  edges;        /* P264_EDGE_*: which MB edges the loop filter touches (core/frame.c:524) */
+    uint16_t reserved;
+} p264hip_mb_t;
+
+#define P264_AVAIL_LEFT     1
+#define P264_AVAIL_TOP      2
+#define P264_AVAIL_TOPRIGHT 4
+#define P264_AVAIL_TOPLEFT  8
+#define P264_EDGE_LEFT      1   /* filter the left MB edge  */
+#define P264_EDGE_TOP       2   /* filter the top MB edge   */
+#define P264_EDGE_INNER     4   /* filter the inner edges   */
+
+/* Packed coefficient stream: for each MB, in this order and only when present:
+ *   [luma DC][chroma DC][block 0]...[block 23]; each entry is int16[16] in scan order
+ *   (AC-only blocks - I16x16 luma and all chroma - hold their 15 levels in [0..14], [15]=0). */
+
+typedef struct p264hip_picture {
+    int32_t  mb_w, mb_h;
+    int32_t  slice_type;            /* P264_SLICE_P / P264_SLICE_I */
+    int32_t  chroma_qp_offset;      /* pps chroma_qp_index_offset */
+    int32_t  deblock;               /* run the loop filter (decoder/decoder.c:639) */
+    int32_t  alpha_c0_offset;       /* used unshifted, as the reference does (core/frame.c:476-478) */
+    int32_t  beta_offset;
+    int32_t  dst_slot;              /* frame-store slot reconstructed into */
+    int32_t  n_ref;                 /* list-0 length */
+    int32_t  ref_slot[P264HIP_MAX_REFS];
+    uint32_t n_coef_blocks;         /* entries in coefs[] */
+    uint32_t frame_num;             /* informational */
+    const p264hip_mb_t *mb;         /* [mb_w*mb_h] raster order */
+    const int16_t      *mv;         /* [mb][16][2] quarter-pel, 4x4 blocks in raster order inside the MB */
+    const int8_t       *ref_idx;    /* [mb][4] per 8x8 (raster), -1 for intra */
+    const uint8_t      *i4modes;    /* [mb][16] Intra4x4PredMode per block in decode order (0..8) */
+    const int16_t      *coefs;      /* [n_coef_blocks][16] */
+} p264hip_picture_t;
+
+typedef struct p264hip_ctx p264hip_ctx;
+
+/* Device context: n_streams independent frame stores of `slots` frames each (planar 4:2:0,
+ * MB-aligned, no padding) and `max_pictures` device-resident picture inputs. */
+int  p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
+                    int n_streams, int slots, int max_pictures);
+void p264hip_destroy(p264hip_ctx *ctx);
+const char *p264hip_last_error(void);
+int  p264hip_device_count(void);
+
+/* Copy parsed pictures host->HBM into resident input slots [first, first+n). Asynchronous. */
+int  p264hip_upload(p264hip_ctx *ctx, int first, const p264hip_picture_t *pics, int n);
+/* Device-side copy of resident picture `src` into slot `dst` (private HBM copy; bench set-up). */
+int  p264hip_clone_picture(p264hip_ctx *ctx, int dst, int src);
+
+/* Reconstruct a batch: picture input slot pic_ids[i] is decoded into stream streams[i].
+ * All pictures of one call are mutually independent (different streams).  Asynchronous. */
+int  p264hip_reconstruct(p264hip_ctx *ctx, const int *pic_ids, const int *streams, int n);
+
+/* upload + reconstruct of one picture for one stream (the p264_decoder_decode path) */
+int  p264hip_submit(p264hip_ctx *ctx, int stream, const p264hip_picture_t *pic);
+
+int  p264hip_sync(p264hip_ctx *ctx);
+
+/* Frame-store access (synchronous).  Strides in bytes; planes are mb_w*16 x mb_h*16 (luma). */
+int  p264hip_read_frame(p264hip_ctx *ctx, int stream, int slot,
+                        uint8_t *y, int y_stride, uint8_t *u, uint8_t *v, int c_stride);
+int  p264hip_write_frame(p264hip_ctx *ctx, int stream, int slot,
+                         const uint8_t *y, int y_stride, const uint8_t *u, const uint8_t *v, int c_stride);
+
+/* Timing hooks used by bench.py: HIP events on the context's own stream.
+ * kernel index: 0 inter (MC + residual), 1 intra, 2 deblock, 3 whole reconstruct call. */
+#define P264HIP_NKERNELS 4
+int  p264hip_timing_enable(p264hip_ctx *ctx, int on);
+int  p264hip_timing_read(p264hip_ctx *ctx, double ms_sum[P264HIP_NKERNELS], int64_t count[P264HIP_NKERNELS]);
+int  p264hip_timing_reset(p264hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

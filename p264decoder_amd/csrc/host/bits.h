@@ -1,0 +1,86 @@
+/* bits.h - MSB-first bit reader over an RBSP buffer, with Exp-Golomb helpers.
+ *
+ * Replaces core/bs.h:54-170 of the reference.  Built around a 64-bit window that is
+ * refilled bytewise, so peeks of up to 32 bits are branch-light and reads past the end
+ * return zeros (the reference's bs_read stops at p_end; its bs_show over-reads 3 bytes,
+ * core/bs.h:119-126 - we pad instead).
+ */
+#ifndef P264_BITS_H
+#define P264_BITS_H
+#include <stdint.h>
+#include <stddef.h>
+
+typedef struct {
+    const uint8_t *buf;
+    size_t   size;      /* bytes */
+    size_t   pos;       /* next byte to load into the window */
+    uint64_t win;       /* bits are left-aligned: next bit is bit 63 */
+    int      avail;     /* valid bits in win */
+    size_t   consumed;  /* total bits consumed */
+} bitrd_t;
+
+static inline void br_refill(bitrd_t *b)
+{
+    while (b->avail <= 56) {
+        uint64_t byte = b->pos < b->size ? b->buf[b->pos] : 0;
+        b->pos++;
+        b->win |= byte << (56 - b->avail);
+        b->avail += 8;
+    }
+}
+
+static inline void br_init(bitrd_t *b, const uint8_t *buf, size_t size)
+{
+    b->buf = buf; b->size = size; b->pos = 0; b->win = 0; b->avail = 0; b->consumed = 0;
+    br_refill(b);
+}
+
+/* 1 <= n <= 32 */
+static inline uint32_t br_peek(bitrd_t *b, int n) { return (uint32_t)(b->win >> (64 - n)); }
+
+static inline void br_skip(bitrd_t *b, int n)
+{
+    b->win <<= n; b->avail -= n; b->consumed += (size_t)n;
+    br_refill(b);
+}
+
+static inline uint32_t br_u(bitrd_t *b, int n)
+{
+    if (n == 0) return 0;
+    uint32_t v = br_peek(b, n);
+    br_skip(b, n);
+    return v;
+}
+
+static inline uint32_t br_u1(bitrd_t *b) { return br_u(b, 1); }
+
+/* bits left in the buffer (may go negative after an over-read) */
+static inline long br_bits_left(const bitrd_t *b) { return (long)(b->size * 8) - (long)b->consumed; }
+static inline int  br_overrun(const bitrd_t *b)   { return b->consumed > b->size * 8; }
+/* mirrors bs_eof (core/bs.h:63-66): true once the byte cursor reached the end */
+static inline int  br_eof(const bitrd_t *b)       { return (b->consumed >> 3) >= b->size; }
+
+static inline uint32_t br_ue(bitrd_t *b)
+{
+    int zeros = 0;
+    while (zeros < 32 && br_peek(b, 1) == 0 && !br_overrun(b)) { br_skip(b, 1); zeros++; }
+    br_skip(b, 1);                       /* the terminating 1 */
+    if (zeros == 0) return 0;
+    if (zeros >= 32) return 0xffffffffu;
+    return ((1u << zeros) - 1u) + br_u(b, zeros);
+}
+
+static inline int32_t br_se(bitrd_t *b)
+{
+    uint32_t k = br_ue(b);
+    return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1);
+}
+
+/* truncated Exp-Golomb, range [0, max] */
+static inline uint32_t br_te(bitrd_t *b, int max)
+{
+    if (max == 1) return br_u1(b) ^ 1u;
+    if (max > 1)  return br_ue(b);
+    return 0;
+}
+#endif

@@ -1,0 +1,107 @@
+// device_common.h - shared device-side definitions for the gfx950 reconstruction kernels.
+//
+// All arithmetic here is 8/16/32-bit integer; the kernels are HBM/latency bound, there is
+// no dense contraction anywhere on this path (no MFMA on purpose).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "p264hip.h"
+
+#define WAVE 64
+
+// One entry per picture of a batch; built on the host for every reconstruct call.
+struct PicDev {
+    const p264hip_mb_t *mb;
+    const int          *mv;        // packed (mvy << 16) | (mvx & 0xffff) per 4x4 block, [mb][16]
+    const int8_t       *ref_idx;   // [mb][4]
+    const uint8_t      *i4modes;   // [mb][16]
+    const int16_t      *coefs;     // [blocks][16]
+    uint8_t            *dst;       // frame base (Y plane); U and V at fixed offsets
+    const uint8_t      *ref[P264HIP_MAX_REFS];
+    int32_t n_ref, slice_type, chroma_qp_offset, deblock, alpha_off, beta_off;
+    int32_t pad[2];
+};
+
+// Geometry shared by every picture of a context.
+struct Geom {
+    int mb_w, mb_h, n_mb;
+    int w, h, cw, ch;              // luma / chroma plane sizes (= strides)
+    size_t off_u, off_v;           // byte offsets of the chroma planes inside a frame
+};
+
+__device__ __forceinline__ int clip3i(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
+
+// LDS traffic between the lanes of ONE wave needs no barrier in hardware (a wave's DS
+// operations execute in order); this only stops the compiler from moving them.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- tables (H.264 standard data; the reference holds them at the cited places) --------
+// zig-zag scan -> raster position, decoder/macroblock.c:602-603
+__device__ __constant__ const uint8_t c_zigzag[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
+// dequant scale x 16 (flat scaling list), by qp%6 and position class; core/set.c:27-35,98
+__device__ __constant__ const uint16_t c_dqmf[6][3] = {
+    {160, 208, 256}, {176, 224, 288}, {208, 256, 320}, {224, 288, 368}, {256, 320, 400}, {288, 368, 464} };
+// core/macroblock.h:210-218
+__device__ __constant__ const uint8_t c_chroma_qp[52] = {
+     0, 1, 2, 3, 4, 5, 6, 7, 8, 9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,
+    29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39 };
+// core/frame.c:262-291
+__device__ __constant__ const uint8_t c_alpha[52] = {
+    0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,
+    25,28,32,36,40,45,50,56,63,71,80,90,101,113,127,144,162,182,203,226,255,255 };
+__device__ __constant__ const uint8_t c_beta[52] = {
+    0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,
+    8,8,9,9,10,10,11,11,12,12,13,13,14,14,15,15,16,16,17,17,18,18 };
+__device__ __constant__ const uint8_t c_tc0[52][3] = {
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},
+    {1,1,1},{1,1,1},{1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},{2,2,3},{2,2,4},{2,3,4},
+    {2,3,4},{3,3,5},{3,4,6},{3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},
+    {9,12,18},{10,13,20},{11,15,23},{13,17,25} };
+
+// luma 4x4 block index (decode order, core/macroblock.h:194-201) <-> position
+__device__ __forceinline__ int blk_x(int i) { return (i & 1) | ((i >> 1) & 2); }
+__device__ __forceinline__ int blk_y(int i) { return ((i >> 1) & 1) | ((i >> 2) & 2); }
+__device__ __forceinline__ int blk_at(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x & 2) << 1) | ((y & 2) << 2); }
+
+// index of packed block `bit` (0..23) of an MB inside the coefficient stream (see p264hip.h)
+__device__ __forceinline__ uint32_t coef_slot(uint32_t mask, int blk)
+{
+    return ((mask >> 24) & 1) + ((mask >> 25) & 1) + __popc(mask & ((1u << blk) - 1u) & 0xffffffu);
+}
+
+// ---- dequantisation, one coefficient (core/quant.c:66-99; int16 store wrap = A-Q8) -------
+__device__ __forceinline__ int dequant_coef(int c, int pos, int qp)
+{
+    int mf = c_dqmf[qp % 6][(pos & 1) + ((pos >> 2) & 1)];
+    int qbits = qp / 6 - 4;
+    int v = c * mf;
+    v = qbits >= 0 ? (int)((unsigned)v << qbits) : (v + (1 << (-qbits - 1))) >> (-qbits);
+    return (int)(int16_t)v;
+}
+
+// One output sample of the 4x4 inverse transform (core/dct.c:205-247): c = 16 dequantised
+// coefficients in raster order, (x,y) the sample.  Row pass then column pass with the
+// reference's int16 intermediates.
+__device__ __forceinline__ int idct4x4_sample(const int16_t *c, int x, int y)
+{
+    int t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int c0 = c[i*4], c1 = c[i*4+1], c2 = c[i*4+2], c3 = c[i*4+3];
+        int s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
+        int v = x == 0 ? s02 + s13 : x == 1 ? d02 + d13 : x == 2 ? d02 - d13 : s02 - s13;
+        t[i] = (int)(int16_t)v;
+    }
+    int s02 = t[0] + t[2], d02 = t[0] - t[2], s13 = t[1] + (t[3] >> 1), d13 = (t[1] >> 1) - t[3];
+    int v = y == 0 ? s02 + s13 : y == 1 ? d02 + d13 : y == 2 ? d02 - d13 : s02 - s13;
+    return (int)(int16_t)((v + 32) >> 6);
+}

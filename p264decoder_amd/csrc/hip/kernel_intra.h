@@ -1,0 +1,291 @@
+// kernel_intra.h - K3: intra macroblock reconstruction (I pictures, and the intra MBs of P pictures).
+//
+// Replaces the intra half of p264_macroblock_decode (decoder/macroblock.c:769-831,851-890), the
+// mode fix-ups valid_intra16x16_mode / valid_intra4x4_mode / valid_intra8x8c_mode
+// (decoder/macroblock.c:635-753), the predictors of core/predict.c:55-638, idct4x4dc +
+// p264_mb_dequant_4x4_dc (core/dct.c:104-136, core/quant.c:161-191) and add16x16_idct.
+//
+// Intra prediction reads the UNFILTERED reconstruction of the left / top / top-left / top-right
+// neighbours, so macroblocks form a 2-MB-lag wavefront over the picture (wavefront_sync.h): one
+// workgroup per picture, one wavefront per macroblock row.  In P pictures the inter MBs were
+// already written by k_inter, so only the sparse intra MBs are visited.  Missing neighbours are
+// substituted in registers (128 / replicated t3) instead of being written into the frame as the
+// reference does (decoder/macroblock.c:697-713, SURVEY A-Q7).
+#pragma once
+#include "device_common.h"
+#include "wavefront_sync.h"
+
+#define IT_STRIDE 24               // luma tile: row -1..15, byte 3 = left column, 4..19 = MB, 20..23 = top-right
+#define CT_STRIDE 12               // chroma tile: byte 3 = left column, 4..11 = MB
+
+struct IntraLds {                  // per wavefront
+    uint8_t  y[17 * IT_STRIDE];
+    uint8_t  c[2][9 * CT_STRIDE];
+    int16_t  coef[16 * 16];
+    int16_t  dc[16];
+};
+
+__device__ __forceinline__ int f3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
+__device__ __forceinline__ int f2(int a, int b) { return (a + b + 1) >> 1; }
+
+// One sample (x,y) of a 4x4 intra prediction (core/predict.c:366-638).  l[4] left, t[8] top and
+// top-right, lt corner - already substituted for missing neighbours.
+__device__ __forceinline__ int pred4x4_sample(int mode, int x, int y, const int *l, const int *t, int lt)
+{
+    switch (mode) {
+    case 0: return t[x];
+    case 1: return l[y];
+    case 2: return (l[0] + l[1] + l[2] + l[3] + t[0] + t[1] + t[2] + t[3] + 4) >> 3;
+    case 9: return (l[0] + l[1] + l[2] + l[3] + 2) >> 2;
+    case 10: return (t[0] + t[1] + t[2] + t[3] + 2) >> 2;
+    case 11: return 128;
+    case 3: { int k = x + y; return k == 6 ? (t[6] + 3 * t[7] + 2) >> 2 : f3(t[k], t[k+1], t[k+2]); }
+    case 4: {                                   // edge e = l3 l2 l1 l0 lt t0 t1 t2 t3, index 4 = lt
+        int k = 4 + x - y;
+        auto e = [&](int i) { return i < 4 ? l[3 - i] : i == 4 ? lt : t[i - 5]; };
+        return f3(e(k - 1), e(k), e(k + 1)); }
+    case 5: {                                   // vertical-right: zVR = 2x - y
+        int z = 2 * x - y;
+        auto e = [&](int i) { return i < 0 ? (i == -1 ? lt : l[-2 - i]) : t[i]; };   // e(-1)=lt, e(-2)=l0, e(-3)=l1 ...
+        if (z >= 0) { int i = x - (y >> 1); return (z & 1) ? f3(e(i - 2), e(i - 1), e(i)) : f2(e(i - 1), e(i)); }
+        if (z == -1) return f3(l[0], lt, t[0]);
+        return f3(l[y - 1], l[y - 2], y - 3 >= 0 ? l[y - 3] : lt); }
+    case 6: {                                   // horizontal-down: zHD = 2y - x
+        int z = 2 * y - x;
+        auto e = [&](int i) { return i < 0 ? (i == -1 ? lt : t[-2 - i]) : l[i]; };   // e(-1)=lt, e(-2)=t0 ...
+        if (z >= 0) { int i = y - (x >> 1); return (z & 1) ? f3(e(i - 2), e(i - 1), e(i)) : f2(e(i - 1), e(i)); }
+        if (z == -1) return f3(l[0], lt, t[0]);
+        return f3(t[x - 1], t[x - 2], x - 3 >= 0 ? t[x - 3] : lt); }
+    case 7: { int i = x + (y >> 1); return (y & 1) ? f3(t[i], t[i+1], t[i+2]) : f2(t[i], t[i+1]); }
+    case 8: {                                   // horizontal-up: zHU = x + 2y
+        int z = x + 2 * y;
+        if (z > 5) return l[3];
+        if (z == 5) return f3(l[2], l[3], l[3]);
+        int i = y + (x >> 1);
+        return (z & 1) ? f3(l[i], l[i+1], l[i+2]) : f2(l[i], l[i+1]); }
+    }
+    return 128;
+}
+
+// Reconstruct one intra macroblock with one wavefront.
+__device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, const p264hip_mb_t m, int lane)
+{
+    const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w, X0 = mbx * 16, Y0 = mby * 16;
+    const bool aL = m.avail & P264_AVAIL_LEFT, aT = m.avail & P264_AVAIL_TOP;
+    const bool aTR = m.avail & P264_AVAIL_TOPRIGHT, aTL = m.avail & P264_AVAIL_TOPLEFT;
+    uint8_t *Y = pd->dst, *U = pd->dst + g.off_u, *V = pd->dst + g.off_v;
+    const unsigned mask = m.coef_mask;
+    const int16_t *cf = pd->coefs + (size_t)m.coef_index * 16;
+
+    // ---- neighbour samples into the tiles; 128 where the neighbour does not exist ----
+    if (lane < 21) {                                        // top row: corner, 16 top, 4 top-right
+        int x = lane - 1;
+        bool ok = x < 0 ? aTL : x < 16 ? aT : aTR;
+        L.y[3 + lane] = ok ? Y[(size_t)(Y0 - 1) * g.w + X0 + x] : 128;
+    } else if (lane < 37) {                                 // left column
+        int r = lane - 21;
+        L.y[(r + 1) * IT_STRIDE + 3] = aL ? Y[(size_t)(Y0 + r) * g.w + X0 - 1] : 128;
+    } else if (lane < 55) {                                 // chroma top rows (corner + 8) of both planes
+        int p = (lane - 37) / 9, x = (lane - 37) % 9 - 1;
+        bool ok = x < 0 ? aTL : aT;
+        L.c[p][3 + x + 1] = ok ? (p ? V : U)[(size_t)(Y0 / 2 - 1) * g.cw + X0 / 2 + x] : 128;
+    }
+    if (lane < 16) {                                        // chroma left columns
+        int p = lane >> 3, r = lane & 7;
+        L.c[p][(r + 1) * CT_STRIDE + 3] = aL ? (p ? V : U)[(size_t)(Y0 / 2 + r) * g.cw + X0 / 2 - 1] : 128;
+    }
+    wave_lds_fence();
+    if (!aTR && lane < 4) L.y[20 + lane] = L.y[19];         // top-right of the MB missing: replicate t15 (:706-709)
+    wave_lds_fence();
+
+    if (m.mb_type == P264_MB_I16x16) {
+        // ---- prediction: each lane 4 samples of one row ----
+        int mode = m.intra_modes & 3;
+        if (mode == 2) mode = aTL ? 2 : aL ? 4 : aT ? 5 : 6;                    // :635-667
+        const int row = lane >> 2, c0 = (lane & 3) * 4;
+        const uint8_t *top = L.y + 4, *tile = L.y + IT_STRIDE;
+        int pv[4];
+        if (mode == 0)      { for (int i = 0; i < 4; i++) pv[i] = top[c0 + i]; }
+        else if (mode == 1) { int v = tile[row * IT_STRIDE + 3]; for (int i = 0; i < 4; i++) pv[i] = v; }
+        else if (mode == 3) {                                                     // plane, core/predict.c:159-193
+            int H = 0, Vv = 0;
+            for (int i = 0; i <= 7; i++) {
+                H  += (i + 1) * (top[8 + i] - top[6 - i]);                       // top[-1] is the corner
+                Vv += (i + 1) * (tile[(8 + i) * IT_STRIDE + 3] - L.y[(7 - i) * IT_STRIDE + 3]);
+            }
+            int a = 16 * (tile[15 * IT_STRIDE + 3] + top[15]), b = (5 * H + 32) >> 6, c = (5 * Vv + 32) >> 6;
+            int i00 = a - 7 * b - 7 * c + 16 + c * row;
+            for (int i = 0; i < 4; i++) pv[i] = clip255((i00 + b * (c0 + i)) >> 5);
+        } else {
+            int s = 0;
+            if (mode == 2)      { for (int i = 0; i < 16; i++) s += top[i] + tile[i * IT_STRIDE + 3]; s = (s + 16) >> 5; }
+            else if (mode == 4) { for (int i = 0; i < 16; i++) s += tile[i * IT_STRIDE + 3]; s = (s + 8) >> 4; }
+            else if (mode == 5) { for (int i = 0; i < 16; i++) s += top[i]; s = (s + 8) >> 4; }
+            else s = 128;
+            for (int i = 0; i < 4; i++) pv[i] = s;
+        }
+        // ---- luma DC: unscan, idct4x4dc (core/dct.c:104-136), rounded dequant (core/quant.c:161-191) ----
+        if (lane < 16) L.dc[c_zigzag[lane]] = (mask & P264_COEF_LUMA_DC) ? cf[lane] : (int16_t)0;
+        wave_lds_fence();
+        int dcv = 0;
+        if (lane < 16) {
+            int i = lane >> 2, j = lane & 3, tcol[4];
+            for (int c = 0; c < 4; c++) {                                       // column pass for tmp[i][c]
+                int d0 = L.dc[c], d1 = L.dc[4 + c], d2 = L.dc[8 + c], d3 = L.dc[12 + c];
+                int s01 = d0 + d1, d01 = d0 - d1, s23 = d2 + d3, d23 = d2 - d3;
+                int v = i == 0 ? s01 + s23 : i == 1 ? s01 - s23 : i == 2 ? d01 - d23 : d01 + d23;
+                tcol[c] = (int)(int16_t)v;
+            }
+            int s01 = tcol[0] + tcol[1], d01 = tcol[0] - tcol[1], s23 = tcol[2] + tcol[3], d23 = tcol[2] - tcol[3];
+            int v = j == 0 ? s01 + s23 : j == 1 ? s01 - s23 : j == 2 ? d01 - d23 : d01 + d23;
+            v = (int)(int16_t)v;
+            int qbits = m.qp / 6 - 6, mf = c_dqmf[m.qp % 6][0];
+            v = qbits >= 0 ? v * (int)((unsigned)mf << qbits) : (v * mf + (1 << (-qbits - 1))) >> (-qbits);
+            dcv = (int)(int16_t)v;
+        }
+        wave_lds_fence();
+        if (lane < 16) L.dc[lane] = (int16_t)dcv;                                // raster (y*4+x) of the 4x4 block grid
+        wave_lds_fence();
+        // ---- AC: 4 coefficients per lane, DC inserted at position 0 (:787-794) ----
+        {
+            int b = lane >> 2;                                                   // block in decode order
+            bool present = (mask >> b) & 1;
+            const int16_t *src = cf + coef_slot(mask, b) * 16;
+            for (int kk = 0; kk < 4; kk++) {
+                int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
+                int v = k == 0 ? L.dc[blk_y(b) * 4 + blk_x(b)] : dequant_coef(present ? src[k - 1] : 0, pos, m.qp);
+                L.coef[b * 16 + pos] = (int16_t)v;
+            }
+        }
+        wave_lds_fence();
+        {
+            int b = blk_at(lane & 3, row >> 2), yy = row & 3;
+            for (int i = 0; i < 4; i++)
+                L.y[(row + 1) * IT_STRIDE + 4 + c0 + i] = (uint8_t)clip255(pv[i] + idct4x4_sample(L.coef + b * 16, i, yy));
+        }
+        wave_lds_fence();
+    } else {
+        // ---- I4x4: sixteen dependent blocks, 16 lanes each (decoder/macroblock.c:799-831) ----
+        const int x = lane & 3, y = (lane >> 2) & 3;
+        for (int i = 0; i < 16; i++) {
+            const int bx = blk_x(i), by = blk_y(i);
+            const bool left = bx > 0 || aL, top = by > 0 || aT;
+            const bool topleft = (bx > 0 && by > 0) ? true : bx > 0 ? aT : by > 0 ? aL : aTL;
+            const bool topright = by == 0 ? (bx < 3 ? aT : aTR) : (0x5744 >> i) & 1;   // core/macroblock.c:1210-1231
+            int mode = pd->i4modes[mbi * 16 + i];
+            if (mode == 2) mode = (left && top) ? 2 : left ? 9 : top ? 10 : 11;       // :677-695
+            const uint8_t *o = L.y + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
+            int l[4], t[8], lt;
+            for (int k = 0; k < 4; k++) l[k] = left ? o[k * IT_STRIDE - 1] : 128;
+            for (int k = 0; k < 4; k++) t[k] = top ? o[-IT_STRIDE + k] : 128;
+            for (int k = 4; k < 8; k++) t[k] = topright ? o[-IT_STRIDE + k] : t[3];
+            lt = topleft ? o[-IT_STRIDE - 1] : 128;
+            int v = pred4x4_sample(mode, x, y, l, t, lt);
+            bool present = (mask >> i) & 1;
+            if (present) {
+                if (lane < 16) { int pos = c_zigzag[lane]; L.coef[pos] = (int16_t)dequant_coef(cf[coef_slot(mask, i) * 16 + lane], pos, m.qp); }
+                wave_lds_fence();
+                v = clip255(v + idct4x4_sample(L.coef, x, y));
+            }
+            wave_lds_fence();
+            if (lane < 16) L.y[(by * 4 + y + 1) * IT_STRIDE + 4 + bx * 4 + x] = (uint8_t)v;
+            wave_lds_fence();
+        }
+    }
+
+    // ---- chroma prediction (core/predict.c:199-361), one sample per lane and plane ----
+    {
+        int mode = (m.intra_modes >> 4) & 3;
+        if (mode == 0) mode = aTL ? 0 : aL ? 4 : aT ? 5 : 6;                     // :721-753
+        const int px = lane & 7, py = lane >> 3;
+        const unsigned cmask = m.cbp >> 4 ? 15u : 0u;
+        const int qpc = c_chroma_qp[clip3i(m.qp + pd->chroma_qp_offset, 0, 51)];
+        const int16_t *dcp = cf + ((mask >> 24) & 1) * 16;
+        const int j = lane >> 4, k = lane & 15, pos = c_zigzag[k];
+        for (int p = 0; p < 2; p++) {
+            const uint8_t *top = L.c[p] + 4, *tile = L.c[p] + CT_STRIDE;
+            int v;
+            if (mode == 1) v = tile[py * CT_STRIDE + 3];
+            else if (mode == 2) v = top[px];
+            else if (mode == 3) {
+                int H = 0, Vv = 0;
+                for (int i = 0; i < 4; i++) {
+                    H  += (i + 1) * (top[4 + i] - top[2 - i]);
+                    Vv += (i + 1) * (tile[(4 + i) * CT_STRIDE + 3] - L.c[p][(3 - i) * CT_STRIDE + 3]);
+                }
+                int a = 16 * (tile[7 * CT_STRIDE + 3] + top[7]), b = (17 * H + 16) >> 5, c = (17 * Vv + 16) >> 5;
+                v = clip255((a - 3 * b - 3 * c + 16 + c * py + b * px) >> 5);
+            } else {
+                int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                for (int i = 0; i < 4; i++) { s0 += top[i]; s1 += top[4 + i]; s2 += tile[i * CT_STRIDE + 3]; s3 += tile[(4 + i) * CT_STRIDE + 3]; }
+                int qd = ((py >> 2) << 1) | (px >> 2);
+                if (mode == 0)      v = qd == 0 ? (s0 + s2 + 4) >> 3 : qd == 1 ? (s1 + 2) >> 2 : qd == 2 ? (s3 + 2) >> 2 : (s1 + s3 + 4) >> 3;
+                else if (mode == 4) v = (qd < 2 ? s2 + 2 : s3 + 2) >> 2;
+                else if (mode == 5) v = ((qd & 1) ? s1 + 2 : s0 + 2) >> 2;
+                else v = 128;
+            }
+            if (cmask) {                                                          // residual, as in k_inter
+                int cv;
+                if (k == 0) {
+                    int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                    if (mask & P264_COEF_CHROMA_DC) { d0 = dcp[p*4]; d1 = dcp[p*4+1]; d2 = dcp[p*4+2]; d3 = dcp[p*4+3]; }
+                    int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
+                    int f = j == 0 ? t0 + t2 : j == 1 ? t1 + t3 : j == 2 ? t0 - t2 : t1 - t3;
+                    f = (int)(int16_t)f;
+                    int qbits = qpc / 6 - 5, mf = c_dqmf[qpc % 6][0];
+                    cv = qbits >= 0 ? f * (int)((unsigned)mf << qbits) : (f * mf) >> (-qbits);
+                    cv = (int)(int16_t)cv;
+                } else {
+                    int blk = 16 + 4 * p + j;
+                    int c = (mask >> blk) & 1 ? cf[coef_slot(mask, blk) * 16 + k - 1] : 0;
+                    cv = dequant_coef(c, pos, qpc);
+                }
+                L.coef[j * 16 + pos] = (int16_t)cv;
+                wave_lds_fence();
+                int jj = ((py >> 2) << 1) | (px >> 2);
+                v = clip255(v + idct4x4_sample(L.coef + jj * 16, px & 3, py & 3));
+            }
+            wave_lds_fence();
+            L.c[p][(py + 1) * CT_STRIDE + 4 + px] = (uint8_t)v;
+            wave_lds_fence();
+        }
+    }
+
+    // ---- write the macroblock out ----
+    {
+        int row = lane >> 2, d = lane & 3;
+        *(uint32_t *)(Y + (size_t)(Y0 + row) * g.w + X0 + d * 4) = *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4);
+        if (lane < 32) {
+            int p = lane >> 4, r = (lane >> 1) & 7, dd = lane & 1;
+            *(uint32_t *)((p ? V : U) + (size_t)(Y0 / 2 + r) * g.cw + X0 / 2 + dd * 4) = *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4);
+        }
+    }
+}
+
+__global__ __launch_bounds__(ROW_WAVES * 64)
+void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
+{
+    __shared__ RowSync sync;
+    __shared__ IntraLds lds[ROW_WAVES];
+    const PicDev *pd = pics + blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    rows_init(sync, g.mb_h);
+    bool ok = true;
+    for (int row = wave; row < g.mb_h; row += ROW_WAVES) {
+        for (int base = 0; base < g.mb_w; base += 64) {
+            // which of the next 64 macroblocks of this row are intra?
+            int x = base + lane;
+            bool intra = x < g.mb_w && P264_MB_IS_INTRA(pd->mb[row * g.mb_w + x].mb_type);
+            unsigned long long todo = __ballot(intra);
+            while (todo) {
+                int bit = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                int mbx = base + bit, mbi = row * g.mb_w + mbx;
+                row_publish(sync, row, mbx);                                      // everything left of mbx is final
+                if (row > 0 && ok) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
+                intra_mb(pd, g, lds[wave], mbi, pd->mb[mbi], lane);
+            }
+        }
+        row_publish(sync, row, g.mb_w);
+    }
+}

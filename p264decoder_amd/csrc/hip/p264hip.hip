@@ -1,0 +1,354 @@
+// p264hip.hip - host side of the C ABI in include/p264hip.h: device context, frame stores,
+// resident picture inputs, batch launch of the three reconstruction kernels, timing hooks.
+//
+// One context = one GPU = one HIP stream.  The product has no CPU reconstruction path: when no
+// device is usable every entry point fails with P264HIP_ENODEV.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <vector>
+#include "p264hip.h"
+#include "device_common.h"
+#include "kernel_inter.h"
+#include "kernel_intra.h"
+#include "kernel_deblock.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(P264HIP_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *p264hip_last_error(void) { return g_err; }
+
+extern "C" int p264hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PicSlot {                       // one device-resident parsed picture
+    uint8_t *dev = nullptr;
+    size_t   cap = 0;                  // bytes allocated
+    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_coef = 0;
+    p264hip_picture_t meta;            // scalar fields only; pointers unused
+    bool     valid = false;
+};
+
+#define BATCH_RING 4
+
+struct p264hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Geom g;
+    int n_streams = 0, slots = 0, max_pictures = 0;
+    uint8_t *frames = nullptr;
+    size_t frame_bytes = 0;
+    std::vector<PicSlot> pics;
+    PicDev *h_batch[BATCH_RING] = {}, *d_batch[BATCH_RING] = {};
+    hipEvent_t batch_free[BATCH_RING] = {};
+    int batch_cap = 0, ring = 0;
+    int *d_status = nullptr;
+    bool timing = false;
+    struct Stamp { hipEvent_t a, b; int k; };
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> event_pool;
+    double ms_sum[P264HIP_NKERNELS] = {};
+    int64_t ms_cnt[P264HIP_NKERNELS] = {};
+};
+
+static uint8_t *frame_ptr(p264hip_ctx *c, int stream, int slot)
+{
+    return c->frames + ((size_t)stream * c->slots + slot) * c->frame_bytes;
+}
+
+extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h, int n_streams, int slots, int max_pictures)
+{
+    if (!out || mb_w < 1 || mb_h < 1 || mb_h > MAX_MB_ROWS || n_streams < 1 || slots < 1 || slots > P264HIP_MAX_REFS + 1 || max_pictures < 1)
+        return fail(P264HIP_EINVAL, "p264hip_create: bad argument (mb %dx%d, streams %d, slots %d, pictures %d)", mb_w, mb_h, n_streams, slots, max_pictures);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(P264HIP_ENODEV, "no HIP device available: the MI355X reconstruction path cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(P264HIP_EINVAL, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    p264hip_ctx *c = new p264hip_ctx();
+    c->device = device;
+    c->n_streams = n_streams; c->slots = slots; c->max_pictures = max_pictures;
+    Geom &g = c->g;
+    g.mb_w = mb_w; g.mb_h = mb_h; g.n_mb = mb_w * mb_h;
+    g.w = mb_w * 16; g.h = mb_h * 16; g.cw = g.w / 2; g.ch = g.h / 2;
+    g.off_u = align_up((size_t)g.w * g.h, 256);
+    g.off_v = g.off_u + align_up((size_t)g.cw * g.ch, 256);
+    c->frame_bytes = g.off_v + align_up((size_t)g.cw * g.ch, 256) + 256;      // +256: dword loads may run past a row end
+    c->pics.resize((size_t)max_pictures);
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->frames, c->frame_bytes * (size_t)n_streams * slots);
+    if (e == hipSuccess) e = hipMemsetAsync(c->frames, 0, c->frame_bytes * (size_t)n_streams * slots, c->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        int rc = fail(e == hipErrorOutOfMemory ? P264HIP_ENOMEM : P264HIP_EHIP, "p264hip_create: %s", hipGetErrorString(e));
+        p264hip_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return P264HIP_OK;
+}
+
+extern "C" void p264hip_destroy(p264hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->pics) if (p.dev) (void)hipFree(p.dev);
+    for (int i = 0; i < BATCH_RING; i++) {
+        if (c->h_batch[i]) (void)hipHostFree(c->h_batch[i]);
+        if (c->d_batch[i]) (void)hipFree(c->d_batch[i]);
+        if (c->batch_free[i]) (void)hipEventDestroy(c->batch_free[i]);
+    }
+    for (auto &s : c->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->frames) (void)hipFree(c->frames);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
+{
+    if (p->mb_w != c->g.mb_w || p->mb_h != c->g.mb_h)
+        return fail(P264HIP_EINVAL, "picture is %dx%d MBs, context is %dx%d", p->mb_w, p->mb_h, c->g.mb_w, c->g.mb_h);
+    if (p->dst_slot < 0 || p->dst_slot >= c->slots) return fail(P264HIP_EINVAL, "dst_slot %d out of range", p->dst_slot);
+    if (p->n_ref < 0 || p->n_ref > P264HIP_MAX_REFS) return fail(P264HIP_EINVAL, "n_ref %d out of range", p->n_ref);
+    for (int i = 0; i < p->n_ref; i++)
+        if (p->ref_slot[i] < 0 || p->ref_slot[i] >= c->slots) return fail(P264HIP_EINVAL, "ref_slot[%d]=%d out of range", i, p->ref_slot[i]);
+    if (p->slice_type == P264_SLICE_P && p->n_ref < 1) return fail(P264HIP_EINVAL, "P picture without reference");
+    if (!p->mb || !p->mv || !p->ref_idx || !p->i4modes || (p->n_coef_blocks && !p->coefs)) return fail(P264HIP_EINVAL, "null picture array");
+    return 0;
+}
+
+static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
+{
+    int rc = check_pic(c, p);
+    if (rc) return rc;
+    PicSlot &s = c->pics[(size_t)id];
+    const size_t n = (size_t)c->g.n_mb;
+    size_t off_mv = align_up(n * sizeof(p264hip_mb_t), 256);
+    size_t off_ref = off_mv + align_up(n * 64, 256);
+    size_t off_i4 = off_ref + align_up(n * 4, 256);
+    size_t off_coef = off_i4 + align_up(n * 16, 256);
+    size_t need = off_coef + align_up((size_t)p->n_coef_blocks * 32, 256) + 256;
+    if (need > s.cap) {
+        if (s.dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(s.dev)); s.dev = nullptr; s.cap = 0; }
+        size_t cap = need + need / 4;
+        hipError_t e = hipMalloc((void **)&s.dev, cap);
+        if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for picture input: %s", cap, hipGetErrorString(e));
+        s.cap = cap;
+    }
+    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_coef = off_coef;
+    HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(s.dev + off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(s.dev + off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(s.dev + off_i4, p->i4modes, n * 16, hipMemcpyHostToDevice, c->stream));
+    if (p->n_coef_blocks)
+        HIPCHK(hipMemcpyAsync(s.dev + off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
+    s.meta = *p;
+    s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr;
+    s.valid = true;
+    return 0;
+}
+
+extern "C" int p264hip_upload(p264hip_ctx *c, int first, const p264hip_picture_t *pics, int n)
+{
+    if (!c || !pics || n < 0 || first < 0 || first + n > c->max_pictures) return fail(P264HIP_EINVAL, "p264hip_upload: bad range [%d,+%d)", first, n);
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++) { int rc = upload_one(c, first + i, &pics[i]); if (rc) return rc; }
+    // sources are pageable host memory owned by the caller: make sure they are consumed before returning
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
+{
+    if (!c || dst < 0 || src < 0 || dst >= c->max_pictures || src >= c->max_pictures || dst == src || !c->pics[(size_t)src].valid)
+        return fail(P264HIP_EINVAL, "p264hip_clone_picture: bad slots %d <- %d", dst, src);
+    HIPCHK(hipSetDevice(c->device));
+    PicSlot &d = c->pics[(size_t)dst], &s = c->pics[(size_t)src];
+    size_t need = s.off_coef + align_up((size_t)s.meta.n_coef_blocks * 32, 256) + 256;
+    if (need > d.cap) {
+        if (d.dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(d.dev)); d.dev = nullptr; d.cap = 0; }
+        hipError_t e = hipMalloc((void **)&d.dev, need);
+        if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for picture clone: %s", need, hipGetErrorString(e));
+        d.cap = need;
+    }
+    HIPCHK(hipMemcpyAsync(d.dev, s.dev, need, hipMemcpyDeviceToDevice, c->stream));
+    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef;
+    d.meta = s.meta; d.valid = true;
+    return P264HIP_OK;
+}
+
+static hipEvent_t get_event(p264hip_ctx *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+
+struct ScopedStamp {                   // HIP events on the context's own stream, around one launch
+    p264hip_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
+    ScopedStamp(p264hip_ctx *c_, int k_) : c(c_), k(k_) { if (c->timing) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); } }
+    ~ScopedStamp() { if (c->timing) { (void)hipEventRecord(b, c->stream); c->stamps.push_back({ a, b, k }); } }
+};
+
+extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int *streams, int n)
+{
+    if (!c || !pic_ids || !streams || n < 1) return fail(P264HIP_EINVAL, "p264hip_reconstruct: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (n > c->batch_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < BATCH_RING; i++) {
+            if (c->h_batch[i]) (void)hipHostFree(c->h_batch[i]);
+            if (c->d_batch[i]) (void)hipFree(c->d_batch[i]);
+            c->h_batch[i] = nullptr; c->d_batch[i] = nullptr;
+            HIPCHK(hipHostMalloc((void **)&c->h_batch[i], (size_t)n * sizeof(PicDev), hipHostMallocDefault));
+            HIPCHK(hipMalloc((void **)&c->d_batch[i], (size_t)n * sizeof(PicDev)));
+            if (!c->batch_free[i]) HIPCHK(hipEventCreateWithFlags(&c->batch_free[i], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(c->batch_free[i], c->stream));
+        }
+        c->batch_cap = n;
+    }
+    const int r = c->ring; c->ring = (c->ring + 1) % BATCH_RING;
+    HIPCHK(hipEventSynchronize(c->batch_free[r]));            // the copy that last used this staging buffer is done
+    PicDev *hb = c->h_batch[r];
+    bool any_p = false;
+    for (int i = 0; i < n; i++) {
+        int id = pic_ids[i], st = streams[i];
+        if (id < 0 || id >= c->max_pictures || !c->pics[(size_t)id].valid) return fail(P264HIP_EINVAL, "picture slot %d is empty", id);
+        if (st < 0 || st >= c->n_streams) return fail(P264HIP_EINVAL, "stream %d out of range", st);
+        const PicSlot &s = c->pics[(size_t)id];
+        PicDev &d = hb[i];
+        memset(&d, 0, sizeof d);
+        d.mb = (const p264hip_mb_t *)s.dev;
+        d.mv = (const int *)(s.dev + s.off_mv);
+        d.ref_idx = (const int8_t *)(s.dev + s.off_ref);
+        d.i4modes = s.dev + s.off_i4;
+        d.coefs = (const int16_t *)(s.dev + s.off_coef);
+        d.dst = frame_ptr(c, st, s.meta.dst_slot);
+        for (int k = 0; k < P264HIP_MAX_REFS; k++)
+            d.ref[k] = frame_ptr(c, st, k < s.meta.n_ref ? s.meta.ref_slot[k] : (s.meta.n_ref ? s.meta.ref_slot[0] : s.meta.dst_slot));
+        d.n_ref = s.meta.n_ref; d.slice_type = s.meta.slice_type;
+        d.chroma_qp_offset = s.meta.chroma_qp_offset; d.deblock = s.meta.deblock;
+        d.alpha_off = s.meta.alpha_c0_offset; d.beta_off = s.meta.beta_offset;
+        any_p |= s.meta.slice_type == P264_SLICE_P;
+    }
+    ScopedStamp whole(c, 3);
+    HIPCHK(hipMemcpyAsync(c->d_batch[r], hb, (size_t)n * sizeof(PicDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->batch_free[r], c->stream));
+    const Geom g = c->g;
+    if (any_p) {
+        ScopedStamp t(c, 0);
+        int per_pic = (g.n_mb + 3) / 4, n_blocks = per_pic * n, grid = (n_blocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_inter, dim3(grid), dim3(256), 0, c->stream, c->d_batch[r], g, per_pic, n_blocks);
+    }
+    {
+        ScopedStamp t(c, 1);
+        hipLaunchKernelGGL(k_intra, dim3(n), dim3(ROW_WAVES * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
+    }
+    {
+        ScopedStamp t(c, 2);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(ROW_WAVES * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
+    }
+    HIPCHK(hipGetLastError());
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_submit(p264hip_ctx *c, int stream, const p264hip_picture_t *pic)
+{
+    if (!c || !pic || stream < 0 || stream >= c->n_streams || stream >= c->max_pictures)
+        return fail(P264HIP_EINVAL, "p264hip_submit: bad argument (stream %d)", stream);
+    int rc = p264hip_upload(c, stream, pic, 1);               // input slot `stream` is this stream's staging slot
+    if (rc) return rc;
+    return p264hip_reconstruct(c, &stream, &stream, 1);
+}
+
+static int drain_stamps(p264hip_ctx *c)
+{
+    for (auto &s : c->stamps) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->ms_sum[s.k] += ms; c->ms_cnt[s.k]++; }
+        c->event_pool.push_back(s.a); c->event_pool.push_back(s.b);
+    }
+    c->stamps.clear();
+    return 0;
+}
+
+extern "C" int p264hip_sync(p264hip_ctx *c)
+{
+    if (!c) return fail(P264HIP_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    drain_stamps(c);
+    int st = 0;
+    HIPCHK(hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st) {
+        (void)hipMemset(c->d_status, 0, sizeof(int));
+        return fail(P264HIP_EHIP, "a macroblock-row dependency wait timed out on the device (status %d)", st);
+    }
+    return P264HIP_OK;
+}
+
+static int frame_io(p264hip_ctx *c, int stream, int slot, uint8_t *y, int ys, uint8_t *u, uint8_t *v, int cs, bool read)
+{
+    if (!c || stream < 0 || stream >= c->n_streams || slot < 0 || slot >= c->slots || !y || !u || !v || ys < c->g.w || cs < c->g.cw)
+        return fail(P264HIP_EINVAL, "frame access: bad argument (stream %d slot %d strides %d/%d)", stream, slot, ys, cs);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = p264hip_sync(c);
+    if (rc) return rc;
+    uint8_t *f = frame_ptr(c, stream, slot);
+    const Geom &g = c->g;
+    hipMemcpyKind k = read ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+    struct { uint8_t *host; int hs; uint8_t *dev; int w, h; } pl[3] = {
+        { y, ys, f, g.w, g.h }, { u, cs, f + g.off_u, g.cw, g.ch }, { v, cs, f + g.off_v, g.cw, g.ch } };
+    for (auto &p : pl) {
+        if (read) HIPCHK(hipMemcpy2D(p.host, (size_t)p.hs, p.dev, (size_t)p.w, (size_t)p.w, (size_t)p.h, k));
+        else      HIPCHK(hipMemcpy2D(p.dev, (size_t)p.w, p.host, (size_t)p.hs, (size_t)p.w, (size_t)p.h, k));
+    }
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_read_frame(p264hip_ctx *c, int stream, int slot, uint8_t *y, int ys, uint8_t *u, uint8_t *v, int cs)
+{ return frame_io(c, stream, slot, y, ys, u, v, cs, true); }
+
+extern "C" int p264hip_write_frame(p264hip_ctx *c, int stream, int slot, const uint8_t *y, int ys, const uint8_t *u, const uint8_t *v, int cs)
+{ return frame_io(c, stream, slot, (uint8_t *)y, ys, (uint8_t *)u, (uint8_t *)v, cs, false); }
+
+extern "C" int p264hip_timing_enable(p264hip_ctx *c, int on)
+{
+    if (!c) return fail(P264HIP_EINVAL, "null context");
+    int rc = p264hip_sync(c);
+    c->timing = on != 0;
+    return rc;
+}
+
+extern "C" int p264hip_timing_reset(p264hip_ctx *c)
+{
+    if (!c) return fail(P264HIP_EINVAL, "null context");
+    int rc = p264hip_sync(c);
+    for (int i = 0; i < P264HIP_NKERNELS; i++) { c->ms_sum[i] = 0; c->ms_cnt[i] = 0; }
+    return rc;
+}
+
+extern "C" int p264hip_timing_read(p264hip_ctx *c, double ms_sum[P264HIP_NKERNELS], int64_t count[P264HIP_NKERNELS])
+{
+    if (!c || !ms_sum || !count) return fail(P264HIP_EINVAL, "null argument");
+    int rc = p264hip_sync(c);
+    for (int i = 0; i < P264HIP_NKERNELS; i++) { ms_sum[i] = c->ms_sum[i]; count[i] = c->ms_cnt[i]; }
+    return rc;
+}

@@ -1,0 +1,99 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares;
+struct layouts seen by ctypes equal what a C compiler sees.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from p264decoder_amd import _native as N
+from p264decoder_amd import decoder as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+def declared_functions():
+    names = set()
+    for h in os.listdir(INC):
+        if not h.endswith(".h"):
+            continue
+        text = open(os.path.join(INC, h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        for m in re.finditer(r"\b(p264\w*)\s*\(", text):
+            pre = text[:m.start()].rstrip()
+            if pre.endswith(("*", "int", "void", "char", "int64_t", "p264parse", "p264_t")) or pre.endswith("const"):
+                names.add(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_functions()
+    assert {"p264_decoder_open", "p264_decoder_decode", "p264_decoder_close", "p264_nal_decode", "p264_param_default",
+            "p264hip_create", "p264hip_reconstruct", "p264hip_submit", "p264parse_nal", "p264_annexb_next"} <= names
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+
+
+def test_struct_layouts_match_the_headers(lib):
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "p264hip.h"
+#include "p264_dropin.h"
+int main(void) {
+  printf("mb %zu\n", sizeof(p264hip_mb_t));
+  printf("pic %zu %zu %zu %zu\n", sizeof(p264hip_picture_t), offsetof(p264hip_picture_t, ref_slot), offsetof(p264hip_picture_t, mb), offsetof(p264hip_picture_t, coefs));
+  printf("param %zu %zu %zu %zu\n", sizeof(p264_param_t), offsetof(p264_param_t, analyse), offsetof(p264_param_t, rc), offsetof(p264_param_t, b_repeat_headers));
+  printf("picture %zu %zu\n", sizeof(p264_picture_t), offsetof(p264_picture_t, img));
+  printf("nal %zu %zu\n", sizeof(p264_nal_t), offsetof(p264_nal_t, p_payload));
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.run(["gcc", "-I" + INC, c, "-o", exe], check=True)
+        out = dict((l.split()[0], [int(x) for x in l.split()[1:]]) for l in subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines())
+    assert out["mb"] == [C.sizeof(N.MbInfo)] == [16]
+    assert out["pic"] == [C.sizeof(N.Picture), N.Picture.ref_slot.offset, N.Picture.mb.offset, N.Picture.coefs.offset]
+    assert out["param"] == [C.sizeof(D.Param), D.Param.analyse.offset, D.Param.rc.offset, D.Param.b_repeat_headers.offset]
+    assert out["picture"] == [C.sizeof(D.PictureOut), D.PictureOut.img.offset]
+    assert out["nal"] == [C.sizeof(D.Nal), D.Nal.p_payload.offset]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/p264.h"), reason="reference tree not present (GPU box)")
+def test_dropin_structs_match_the_reference_header():
+    """Binary contract of the drop-in: same sizes/offsets as the reference's own p264.h."""
+    body = r'''
+int main(void) {
+  printf("%zu %zu %zu %zu %zu ", sizeof(p264_param_t), offsetof(p264_param_t, vui), offsetof(p264_param_t, cqm_4iy), offsetof(p264_param_t, analyse), offsetof(p264_param_t, rc));
+  printf("%zu %zu %zu ", offsetof(p264_param_t, pf_log), offsetof(p264_param_t, b_aud), offsetof(p264_param_t, b_repeat_headers));
+  printf("%zu %zu %zu %zu ", sizeof(p264_picture_t), offsetof(p264_picture_t, i_width), offsetof(p264_picture_t, img), sizeof(p264_image_t));
+  printf("%zu %zu %zu\n", sizeof(p264_nal_t), offsetof(p264_nal_t, i_payload), offsetof(p264_nal_t, p_payload));
+  return 0; }
+'''
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for inc, hdr in ((INC, "p264_dropin.h"), ("/root/reference", "p264.h")):
+            c = os.path.join(td, "t.c")
+            open(c, "w").write("#include <stdio.h>\n#include <stddef.h>\n#include <stdint.h>\n#include \"%s\"\n%s" % (hdr, body))
+            exe = os.path.join(td, "t")
+            subprocess.run(["gcc", "-w", "-I" + inc, c, "-o", exe], check=True)
+            outs.append(subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout)
+    assert outs[0] == outs[1]
+
+
+def test_open_fails_loudly_without_a_gpu(lib):
+    """No silent CPU fallback: on a box without a HIP device the product refuses to open."""
+    if lib.p264hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = D.param_default(lib)
+    D._bind(lib)
+    assert not lib.p264_decoder_open(C.byref(p))
+    h = C.c_void_p()
+    assert lib.p264hip_create(C.byref(h), 0, 22, 18, 1, 2, 1) == -2      # P264HIP_ENODEV
+    assert b"no HIP device" in lib.p264hip_last_error()

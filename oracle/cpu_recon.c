@@ -10,6 +10,15 @@
 #include <string.h>
 #include "cpu_recon.h"
 
+/* Coverage counters for the test-suite (not part of the arithmetic):
+ * [0] HV (centre) half-pel samples evaluated, [1] of those outside [-80,335] - the domain of the
+ * reference's clip LUT (core/clip1.h:36-70), beyond which the reference reads past its table
+ * (undefined; we clamp like the standard), [2] luma edge lines with bS>0, [3] of those modified,
+ * [4] chroma edge lines with bS>0, [5] of those modified. */
+static long long g_stats[8];
+void oracle_stats_reset(void) { memset(g_stats, 0, sizeof g_stats); }
+void oracle_stats_get(long long out[8]) { memcpy(out, g_stats, sizeof g_stats); }
+
 static inline int clip3(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 static inline int clip255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 static inline int iabs(int v) { return v < 0 ? -v : v; }
@@ -279,7 +288,9 @@ static int half_plane(const plane_t *f, int which, int x, int y)
     case 2: return clip255((tap_v(f, x, y) + 16) >> 5);                     /* core/mc.c:194 */
     default: {                                                                /* core/mc.c:213-223 */
         int t0 = tap_h(f,x,y-2), t1 = tap_h(f,x,y-1), t2 = tap_h(f,x,y), t3 = tap_h(f,x,y+1), t4 = tap_h(f,x,y+2), t5 = tap_h(f,x,y+3);
-        return clip255((t0 - 5*t1 + 20*t2 + 20*t3 - 5*t4 + t5 + 512) >> 10); }
+        int v = (t0 - 5*t1 + 20*t2 + 20*t3 - 5*t4 + t5 + 512) >> 10;
+        g_stats[0]++; if (v < -80 || v > 335) g_stats[1]++;
+        return clip255(v); }
     }
 }
 
@@ -549,6 +560,9 @@ static void edge(const p264hip_picture_t *pic, uint8_t *pix, int stride, int dir
     int ia = clip3(qp + pic->alpha_c0_offset, 0, 51);
     int alpha = alpha_tab[ia], beta = beta_tab[clip3(qp + pic->beta_offset, 0, 51)];
     int xs = dir == 0 ? 1 : stride, ys = dir == 0 ? stride : 1;
+    uint8_t before[16][8];
+    int nl = chroma ? 8 : 16, nside = chroma ? 2 : 4;
+    for (int l = 0; l < nl; l++) for (int k = 0; k < 2*nside; k++) before[l][k] = pix[l*ys + (k - nside)*xs];
     if (bS[0] < 4) {
         int8_t tc[4];
         for (int i = 0; i < 4; i++) tc[i] = (int8_t)((bS[i] ? tc0_tab[ia][bS[i] - 1] : -1) + chroma);
@@ -557,6 +571,12 @@ static void edge(const p264hip_picture_t *pic, uint8_t *pix, int stride, int dir
     } else {
         if (chroma) oracle_deblock_chroma_intra(pix, xs, ys, alpha, beta);
         else        oracle_deblock_luma_intra(pix, xs, ys, alpha, beta);
+    }
+    for (int l = 0; l < nl; l++) {
+        if (!bS[l * 4 / nl]) continue;
+        int changed = 0;
+        for (int k = 0; k < 2*nside; k++) changed |= before[l][k] != pix[l*ys + (k - nside)*xs];
+        g_stats[chroma ? 4 : 2]++; g_stats[chroma ? 5 : 3] += changed;
     }
 }
 

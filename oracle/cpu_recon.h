@@ -22,6 +22,10 @@ int oracle_reconstruct(const p264hip_picture_t *pic, uint8_t **planes);
 int oracle_reconstruct_nodeblock(const p264hip_picture_t *pic, uint8_t **planes);
 int oracle_deblock_picture(const p264hip_picture_t *pic, uint8_t **planes);
 
+/* coverage counters, see cpu_recon.c */
+void oracle_stats_reset(void);
+void oracle_stats_get(long long out[8]);
+
 /* kernel-level entry points, one per reference function table entry (for known-answer tests) */
 void oracle_dequant4x4(int16_t d[16], int qp);                               /* core/quant.c:72-99  */
 void oracle_idct4x4dc(int16_t d[16]);                                        /* core/dct.c:104-136  */

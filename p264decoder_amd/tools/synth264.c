@@ -1,0 +1,482 @@
+/* synth264.c - synthetic H.264 Annex-B stream writer (random syntax, no rate control).
+ *
+ * There is no encoder in the build image and the reference ships a single 352x288 clip, so the
+ * 720p / 1080p workloads of BASELINE.json (configs 2-3) are written by this tool.  It emits
+ * only syntax from the subset the reference decodes correctly ("safe
+ * subset"): Baseline CAVLC, one slice per picture, I and P slices, I4x4 / I16x16 / P_L0
+ * 16x16,16x8,8x16 / P_8x8 with 8x8 sub-blocks / P_SKIP, one reference frame, constant QP,
+ * mb_qp_delta = 0, deblocking on with zero offsets, motion vectors that keep every referenced
+ * sample within 24 samples of the picture.  Like an encoder it mirrors the decoder's
+ * neighbour state (MV / intra-mode / nC predictors) so that what it writes is decodable.
+ * Output is a pure function of the arguments (splitmix64), so tests regenerate streams and
+ * only their hashes are committed.
+ *
+ *   synth264 out.264 --mbw 120 --mbh 68 --frames 60 --gop 30 --seed 3 [--intra-only]
+ *            [--qp 26] [--coded 12] [--maxlevel 32] [--mvmax 64] [--cqo 0] [--nodeblock]
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "cavlc_tables.h"
+
+/* ---------------------------------------------------------------- PRNG ------------------ */
+static uint64_t g_rng;
+static uint64_t rnd64(void)
+{
+    uint64_t z = (g_rng += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+static int rnd(int n) { return (int)(rnd64() % (uint64_t)n); }            /* [0,n) */
+static int pct(int p) { return rnd(100) < p; }
+
+/* ---------------------------------------------------------------- bit writer ------------ */
+typedef struct { uint8_t *buf; size_t cap, len; uint32_t acc; int nacc; } bw_t;
+static void bw_byte(bw_t *b, uint8_t v)
+{
+    if (b->len + 1 > b->cap) { b->cap = b->cap * 2 + 1024; b->buf = realloc(b->buf, b->cap); }
+    b->buf[b->len++] = v;
+}
+static void bw_put(bw_t *b, int n, uint32_t v)
+{
+    for (int i = n - 1; i >= 0; i--) {
+        b->acc = (b->acc << 1) | ((v >> i) & 1);
+        if (++b->nacc == 8) { bw_byte(b, (uint8_t)b->acc); b->acc = 0; b->nacc = 0; }
+    }
+}
+static void bw_ue(bw_t *b, uint32_t v)
+{
+    uint32_t x = v + 1; int n = 0;
+    while ((x >> n) > 1) n++;
+    bw_put(b, n, 0); bw_put(b, n + 1, x);
+}
+static void bw_se(bw_t *b, int v) { bw_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+static void bw_trailing(bw_t *b) { bw_put(b, 1, 1); while (b->nacc) bw_put(b, 1, 0); }
+
+/* write one NAL: start code, header, payload with emulation prevention */
+static void write_nal(FILE *f, int ref_idc, int type, const bw_t *b)
+{
+    static const uint8_t sc[4] = { 0, 0, 0, 1 };
+    fwrite(sc, 1, 4, f);
+    fputc((ref_idc << 5) | type, f);
+    int zeros = 0;
+    for (size_t i = 0; i < b->len; i++) {
+        uint8_t v = b->buf[i];
+        if (zeros >= 2 && v <= 3) { fputc(3, f); zeros = 0; }
+        fputc(v, f);
+        zeros = v == 0 ? zeros + 1 : 0;
+    }
+}
+
+/* ---------------------------------------------------------------- stream state ---------- */
+enum { T_I4 = 0, T_I16 = 1, T_P = 3, T_P8 = 4, T_SKIP = 5 };
+static int W, H, NMB;                       /* in macroblocks */
+static int opt_qp = 26, opt_coded = 12, opt_maxlevel = 32, opt_mvmax = 64, opt_cqo = 0, opt_deblock = 1;
+static uint8_t *mb_type;                    /* per MB of the current picture */
+static int16_t *mvs;                        /* [mb][16][2] */
+static uint8_t *nnz;                        /* [mb][24] */
+static int8_t  *i4m;                        /* [mb][16], 2 for non-I4x4 */
+static int cur;                             /* current MB index */
+
+static int avail(int mbx, int mby) { return mbx >= 0 && mby >= 0 && mbx < W && mby < H && mby * W + mbx < cur; }
+
+typedef struct { int ref, x, y; } nb_t;     /* ref -2 unavailable, -1 intra, 0 inter */
+static unsigned mv_done;
+static nb_t nb_motion(int x4, int y4)
+{
+    nb_t r = { -2, 0, 0 };
+    if (x4 < 0 || y4 < 0 || (x4 >> 2) >= W || (y4 >> 2) >= H) return r;
+    int i = (y4 >> 2) * W + (x4 >> 2), sub = (y4 & 3) * 4 + (x4 & 3);
+    if (i == cur) { if (!((mv_done >> sub) & 1)) return r; }
+    else if (i > cur) return r;
+    if (i != cur && mb_type[i] <= T_I16) { r.ref = -1; return r; }
+    r.ref = 0; r.x = mvs[(i * 16 + sub) * 2]; r.y = mvs[(i * 16 + sub) * 2 + 1];
+    return r;
+}
+static int med3(int a, int b, int c) { int lo = a < b ? a : b, hi = a < b ? b : a; return c < lo ? lo : c > hi ? hi : c; }
+/* H.264 8.4.1.3, single reference: dir 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right */
+static void predict_mv(int mbx, int mby, int bx, int by, int bw, int dir, int *px, int *py)
+{
+    int x0 = mbx * 4 + bx, y0 = mby * 4 + by;
+    nb_t a = nb_motion(x0 - 1, y0), b = nb_motion(x0, y0 - 1), c = nb_motion(x0 + bw, y0 - 1);
+    if (c.ref == -2) c = nb_motion(x0 - 1, y0 - 1);
+    if (dir == 1 && b.ref == 0) { *px = b.x; *py = b.y; return; }
+    if (dir == 2 && a.ref == 0) { *px = a.x; *py = a.y; return; }
+    if (dir == 3 && a.ref == 0) { *px = a.x; *py = a.y; return; }
+    if (dir == 4 && c.ref == 0) { *px = c.x; *py = c.y; return; }
+    int hits = (a.ref == 0) + (b.ref == 0) + (c.ref == 0);
+    if (hits == 1) { nb_t *s = a.ref == 0 ? &a : b.ref == 0 ? &b : &c; *px = s->x; *py = s->y; return; }
+    if (hits == 0 && b.ref == -2 && c.ref == -2 && a.ref != -2) { *px = a.x; *py = a.y; return; }
+    *px = med3(a.x, b.x, c.x); *py = med3(a.y, b.y, c.y);
+}
+static void set_mv(int bx, int by, int bw, int bh, int mx, int my)
+{
+    for (int y = by; y < by + bh; y++)
+        for (int x = bx; x < bx + bw; x++) {
+            mvs[(cur * 16 + y * 4 + x) * 2] = (int16_t)mx; mvs[(cur * 16 + y * 4 + x) * 2 + 1] = (int16_t)my;
+            mv_done |= 1u << (y * 4 + x);
+        }
+}
+/* keep every referenced sample within ~19 samples of the picture (A-Q9 allows 24) */
+static int mv_ok(int mbx, int mby, int bx, int by, int bw, int bh, int mx, int my)
+{
+    int x = mbx * 16 + bx * 4 + (mx >> 2), y = mby * 16 + by * 4 + (my >> 2);
+    return x >= -16 && y >= -16 && x + bw * 4 <= W * 16 + 16 && y + bh * 4 <= H * 16 + 16;
+}
+static void random_mv(int mbx, int mby, int bx, int by, int bw, int bh, int *mx, int *my)
+{
+    for (int tries = 0; tries < 64; tries++) {
+        int x = rnd(2 * opt_mvmax + 1) - opt_mvmax, y = rnd(2 * opt_mvmax + 1) - opt_mvmax;
+        if (mv_ok(mbx, mby, bx, by, bw, bh, x, y)) { *mx = x; *my = y; return; }
+    }
+    *mx = 0; *my = 0;
+}
+
+static int predict_nc(int mbx, int mby, int blk)
+{
+    const uint8_t *c = nnz + (size_t)cur * 24;
+    int na = -1, nb = -1, L = avail(mbx - 1, mby), T = avail(mbx, mby - 1);
+    if (blk < 16) {
+        int x = blk_x[blk], y = blk_y[blk];
+        if (x > 0) na = c[blk_of_xy[y][x-1]]; else if (L) na = (c - 24)[blk_of_xy[y][3]];
+        if (y > 0) nb = c[blk_of_xy[y-1][x]]; else if (T) nb = (c - 24 * W)[blk_of_xy[3][x]];
+    } else {
+        int base = blk < 20 ? 16 : 20, k = blk - base, x = k & 1, y = k >> 1;
+        if (x > 0) na = c[blk - 1]; else if (L) na = (c - 24)[base + y * 2 + 1];
+        if (y > 0) nb = c[blk - 2]; else if (T) nb = (c - 24 * W)[base + 2 + x];
+    }
+    if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
+    return na >= 0 ? na : nb >= 0 ? nb : 0;
+}
+
+/* ---------------------------------------------------------------- CAVLC residual writer - */
+static int rand_level(void)
+{
+    int m = 1;
+    while (m < opt_maxlevel && pct(45)) m += 1 + (pct(20) ? rnd(6) : 0);
+    if (m > opt_maxlevel) m = opt_maxlevel;
+    return rnd(2) ? m : -m;
+}
+/* fill `n` scan positions with tc random non-zero levels */
+static int rand_block(int16_t *lv, int n)
+{
+    memset(lv, 0, sizeof(int16_t) * 16);
+    int tc = 1;
+    while (tc < n && pct(55)) tc++;
+    if (pct(4)) tc = n;                                   /* exercise total_coeff == max */
+    for (int k = 0; k < tc; k++) {
+        int p;
+        do p = pct(60) ? rnd((n + 1) / 2) : rnd(n); while (lv[p]);
+        lv[p] = (int16_t)(pct(35) ? (rnd(2) ? 1 : -1) : rand_level());
+    }
+    return tc;
+}
+
+static void put_block(bw_t *b, const int16_t *lv, int n, int nC)
+{
+    int idx[16], tc = 0;
+    for (int i = n - 1; i >= 0; i--) if (lv[i]) idx[tc++] = i;          /* high frequency first */
+    int t1 = 0;
+    while (t1 < tc && t1 < 3 && (lv[idx[t1]] == 1 || lv[idx[t1]] == -1)) t1++;
+    if (nC < 0) bw_put(b, ctdc_len[t1][tc], ctdc_code[t1][tc]);
+    else if (nC >= 8) bw_put(b, 6, tc == 0 ? 3u : (uint32_t)(((tc - 1) << 2) | t1));
+    else { int c = nC < 2 ? 0 : nC < 4 ? 1 : 2; bw_put(b, ct_len[c][t1][tc], ct_code[c][t1][tc]); }
+    if (!tc) return;
+    for (int i = 0; i < t1; i++) bw_put(b, 1, lv[idx[i]] < 0);
+    int sl = (tc > 10 && t1 < 3) ? 1 : 0;
+    for (int i = t1; i < tc; i++) {
+        int v = lv[idx[i]], code = v > 0 ? 2 * v - 2 : -2 * v - 1;
+        if (i == t1 && t1 < 3) code -= 2;
+        if (sl == 0) {
+            if (code < 14) { bw_put(b, code, 0); bw_put(b, 1, 1); }
+            else if (code < 30) { bw_put(b, 14, 0); bw_put(b, 1, 1); bw_put(b, 4, (uint32_t)(code - 14)); }
+            else { bw_put(b, 15, 0); bw_put(b, 1, 1); bw_put(b, 12, (uint32_t)(code - 30)); }
+        } else {
+            if (code < (15 << sl)) { bw_put(b, code >> sl, 0); bw_put(b, 1, 1); bw_put(b, sl, (uint32_t)(code & ((1 << sl) - 1))); }
+            else { bw_put(b, 15, 0); bw_put(b, 1, 1); bw_put(b, 12, (uint32_t)(code - (15 << sl))); }
+        }
+        if (sl == 0) sl = 1;
+        int a = v < 0 ? -v : v;
+        if (a > (3 << (sl - 1)) && sl < 6) sl++;
+    }
+    int total_zeros = idx[0] + 1 - tc;
+    if (tc < n) {
+        if (n == 4) bw_put(b, tzdc_len[tc-1][total_zeros], tzdc_code[tc-1][total_zeros]);
+        else bw_put(b, tz_len[tc-1][total_zeros], tz_code[tc-1][total_zeros]);
+    }
+    int zl = total_zeros;
+    for (int i = 0; i < tc - 1 && zl > 0; i++) {
+        int run = idx[i] - idx[i+1] - 1, t = (zl > 7 ? 7 : zl) - 1;
+        bw_put(b, rb_len[t][run], rb_code[t][run]);
+        zl -= run;
+    }
+}
+
+/* ---------------------------------------------------------------- macroblock writers ---- */
+typedef struct { int16_t dc_luma[16], dc_c[2][16], blk[24][16]; int has[24]; } resid_t;
+
+/* draw residual content for the MB; returns cbp (luma bits 0-3, chroma bits 4-5) */
+static int rand_residual(resid_t *r, int is_i16, int *i16_ac)
+{
+    memset(r, 0, sizeof *r);
+    int cbp = 0, n = is_i16 ? 15 : 16;
+    int dense = pct(opt_coded * 2);                    /* some MBs carry most of the coefficients */
+    if (is_i16) {
+        if (pct(60)) rand_block(r->dc_luma, 16);
+        *i16_ac = pct(35);
+        if (*i16_ac) { cbp = 15; for (int i = 0; i < 16; i++) if (pct(dense ? 60 : 25)) { rand_block(r->blk[i], n); r->has[i] = 1; } }
+    } else {
+        for (int q = 0; q < 4; q++) {
+            if (!pct(dense ? 70 : opt_coded)) continue;
+            int any = 0;
+            for (int j = 0; j < 4; j++) if (pct(dense ? 60 : 40)) { rand_block(r->blk[q*4+j], n); r->has[q*4+j] = 1; any = 1; }
+            if (pct(90) || any) cbp |= 1 << q;        /* occasionally a coded 8x8 with four empty blocks */
+            if (!(cbp & (1 << q))) for (int j = 0; j < 4; j++) { memset(r->blk[q*4+j], 0, 32); r->has[q*4+j] = 0; }
+        }
+    }
+    int cc = pct(dense ? 60 : opt_coded) ? 1 + pct(50) : 0;
+    if (cc) {
+        for (int p = 0; p < 2; p++) if (pct(70)) rand_block(r->dc_c[p], 4);
+        if (cc == 2) for (int i = 16; i < 24; i++) if (pct(50)) { rand_block(r->blk[i], 15); r->has[i] = 1; }
+    }
+    return cbp | (cc << 4);
+}
+
+static void put_residual(bw_t *b, int mbx, int mby, const resid_t *r, int is_i16, int cbp)
+{
+    uint8_t *nz = nnz + (size_t)cur * 24;
+    if (is_i16) put_block(b, r->dc_luma, 16, predict_nc(mbx, mby, 0));
+    for (int i = 0; i < 16; i++) {
+        nz[i] = 0;
+        if (!(cbp & (1 << (i >> 2)))) continue;
+        put_block(b, r->blk[i], is_i16 ? 15 : 16, predict_nc(mbx, mby, i));
+        int tc = 0; for (int k = 0; k < 16; k++) tc += r->blk[i][k] != 0;
+        nz[i] = (uint8_t)tc;
+    }
+    if (cbp >> 4) { put_block(b, r->dc_c[0], 4, -1); put_block(b, r->dc_c[1], 4, -1); }
+    for (int i = 16; i < 24; i++) {
+        nz[i] = 0;
+        if (!((cbp >> 4) & 2)) continue;
+        put_block(b, r->blk[i], 15, predict_nc(mbx, mby, i));
+        int tc = 0; for (int k = 0; k < 16; k++) tc += r->blk[i][k] != 0;
+        nz[i] = (uint8_t)tc;
+    }
+}
+
+static int pred_i4mode(int mbx, int mby, int blk)
+{
+    int x = blk_x[blk], y = blk_y[blk], ma, mb;
+    if (x > 0) ma = i4m[cur * 16 + blk_of_xy[y][x-1]];
+    else if (avail(mbx - 1, mby)) ma = mb_type[cur - 1] == T_I4 ? i4m[(cur - 1) * 16 + blk_of_xy[y][3]] : 2;
+    else ma = -1;
+    if (y > 0) mb = i4m[cur * 16 + blk_of_xy[y-1][x]];
+    else if (avail(mbx, mby - 1)) mb = mb_type[cur - W] == T_I4 ? i4m[(cur - W) * 16 + blk_of_xy[3][x]] : 2;
+    else mb = -1;
+    int m = ma < mb ? ma : mb;
+    return m < 0 ? 2 : m;
+}
+
+/* intra MB (I slice: offset 0; P slice: mb_type + 5) */
+static void put_intra(bw_t *b, int mbx, int mby, int type_offset)
+{
+    int L = avail(mbx - 1, mby), T = avail(mbx, mby - 1), TL = avail(mbx - 1, mby - 1);
+    int is16 = pct(50);
+    resid_t r; int i16_ac = 0;
+    int cbp = rand_residual(&r, is16, &i16_ac);
+    memset(mvs + cur * 32, 0, 64);
+    if (is16) {
+        int legal[4], nl = 0;
+        if (T) legal[nl++] = 0;
+        if (L) legal[nl++] = 1;
+        legal[nl++] = 2;
+        if (L && T && TL) legal[nl++] = 3;
+        int mode = legal[rnd(nl)];
+        mb_type[cur] = T_I16;
+        memset(i4m + cur * 16, 2, 16);
+        bw_ue(b, (uint32_t)(type_offset + 1 + mode + 4 * (cbp >> 4) + (i16_ac ? 12 : 0)));
+    } else {
+        mb_type[cur] = T_I4;
+        bw_ue(b, (uint32_t)type_offset);
+        for (int i = 0; i < 16; i++) {
+            int bx = blk_x[i], by = blk_y[i];
+            int l = bx > 0 || L, t = by > 0 || T;
+            int tl = (bx > 0 && by > 0) ? 1 : bx > 0 ? T : by > 0 ? L : TL;
+            int legal[9], nl = 0;
+            if (t) legal[nl++] = 0;
+            if (l) legal[nl++] = 1;
+            legal[nl++] = 2;
+            if (t) { legal[nl++] = 3; legal[nl++] = 7; }           /* missing top-right is replicated, as in the standard */
+            if (l && t && tl) { legal[nl++] = 4; legal[nl++] = 5; legal[nl++] = 6; }
+            if (l) legal[nl++] = 8;
+            int mode = legal[rnd(nl)], pred = pred_i4mode(mbx, mby, i);
+            i4m[cur * 16 + i] = (int8_t)mode;
+            if (mode == pred) bw_put(b, 1, 1);
+            else { bw_put(b, 1, 0); bw_put(b, 3, (uint32_t)(mode < pred ? mode : mode - 1)); }
+        }
+    }
+    {   /* intra_chroma_pred_mode */
+        int legal[4], nl = 0;
+        legal[nl++] = 0;
+        if (L) legal[nl++] = 1;
+        if (T) legal[nl++] = 2;
+        if (L && T && TL) legal[nl++] = 3;
+        bw_ue(b, (uint32_t)legal[rnd(nl)]);
+    }
+    if (!is16) {
+        int code = -1;
+        for (int k = 0; k < 48; k++) if (cbp_intra_of_code[k] == cbp) code = k;
+        bw_ue(b, (uint32_t)code);
+    }
+    if (cbp || is16) { bw_se(b, 0); put_residual(b, mbx, mby, &r, is16, cbp); }
+    else memset(nnz + (size_t)cur * 24, 0, 24);
+}
+
+/* try to write a non-skipped inter MB; returns 0 if no legal vectors were found */
+static void put_inter(bw_t *b, int mbx, int mby)
+{
+    int pick = rnd(76);           /* 16x16 : 16x8 : 8x16 : 8x8 = 50 : 9 : 9 : 8 */
+    int t = pick < 50 ? 0 : pick < 59 ? 1 : pick < 68 ? 2 : 3;
+    static const int8_t geo[3][2][4] = { { {0,0,4,4}, {0,0,0,0} }, { {0,0,4,2}, {0,2,4,2} }, { {0,0,2,4}, {2,0,2,4} } };
+    mb_type[cur] = t == 3 ? T_P8 : T_P;
+    memset(i4m + cur * 16, 2, 16);
+    bw_ue(b, (uint32_t)t);
+    if (t < 3) {
+        int np = t == 0 ? 1 : 2;
+        for (int k = 0; k < np; k++) {
+            int mx, my, px, py, dir = t == 0 ? 0 : t == 1 ? 1 + k : 3 + k;
+            predict_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], dir, &px, &py);
+            if (pct(25) && mv_ok(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], px, py)) { mx = px; my = py; }
+            else random_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], &mx, &my);
+            bw_se(b, mx - px); bw_se(b, my - py);
+            set_mv(geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], mx, my);
+        }
+    } else {
+        for (int k = 0; k < 4; k++) bw_ue(b, 0);                       /* sub_mb_type 8x8 (A-Q4) */
+        for (int k = 0; k < 4; k++) {
+            int ox = (k & 1) * 2, oy = (k >> 1) * 2, mx, my, px, py;
+            predict_mv(mbx, mby, ox, oy, 2, 0, &px, &py);
+            random_mv(mbx, mby, ox, oy, 2, 2, &mx, &my);
+            bw_se(b, mx - px); bw_se(b, my - py);
+            set_mv(ox, oy, 2, 2, mx, my);
+        }
+    }
+    resid_t r; int dummy;
+    int cbp = rand_residual(&r, 0, &dummy), code = -1;
+    for (int k = 0; k < 48; k++) if (cbp_inter_of_code[k] == cbp) code = k;
+    bw_ue(b, (uint32_t)code);
+    if (cbp) { bw_se(b, 0); put_residual(b, mbx, mby, &r, 0, cbp); }
+    else memset(nnz + (size_t)cur * 24, 0, 24);
+}
+
+/* P_SKIP motion (8.4.1.1); returns 0 when the inferred vector would leave the safe zone */
+static int try_skip(int mbx, int mby)
+{
+    int mx = 0, my = 0;
+    nb_t a = nb_motion(mbx * 4 - 1, mby * 4), b = nb_motion(mbx * 4, mby * 4 - 1);
+    if (!(a.ref == -2 || b.ref == -2 || (a.ref == 0 && !a.x && !a.y) || (b.ref == 0 && !b.x && !b.y)))
+        predict_mv(mbx, mby, 0, 0, 4, 0, &mx, &my);
+    if (!mv_ok(mbx, mby, 0, 0, 4, 4, mx, my)) return 0;
+    mb_type[cur] = T_SKIP;
+    memset(i4m + cur * 16, 2, 16);
+    memset(nnz + (size_t)cur * 24, 0, 24);
+    set_mv(0, 0, 4, 4, mx, my);
+    return 1;
+}
+
+/* ---------------------------------------------------------------- pictures -------------- */
+static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn)
+{
+    bw_t b = { 0 };
+    bw_ue(&b, 0);                               /* first_mb_in_slice */
+    bw_ue(&b, is_p ? 5 : 7);                    /* slice_type: all slices of the picture alike */
+    bw_ue(&b, 0);                               /* pps id */
+    bw_put(&b, log2_fn, (uint32_t)frame_num);
+    if (idr) bw_ue(&b, (uint32_t)idr_id);
+    if (is_p) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }   /* no num_ref_idx override, no reordering */
+    if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }    /* no_output_of_prior_pics, long_term_reference */
+    else bw_put(&b, 1, 0);                              /* sliding-window marking */
+    bw_se(&b, 0);                               /* slice_qp_delta */
+    bw_ue(&b, opt_deblock ? 0 : 1);             /* disable_deblocking_filter_idc */
+    if (opt_deblock) { bw_se(&b, 0); bw_se(&b, 0); }
+    int skip_run = 0;
+    for (cur = 0; cur < NMB; cur++) {
+        int mbx = cur % W, mby = cur / W;
+        mv_done = 0;
+        if (!is_p) { put_intra(&b, mbx, mby, 0); continue; }
+        int k = rnd(100);
+        if (k < 20 && try_skip(mbx, mby)) { skip_run++; continue; }
+        bw_ue(&b, (uint32_t)skip_run); skip_run = 0;
+        if (k >= 96) put_intra(&b, mbx, mby, 5); else put_inter(&b, mbx, mby);
+    }
+    if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+    bw_trailing(&b);
+    write_nal(f, 3, idr ? 5 : 1, &b);
+    free(b.buf);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: synth264 out.264 [--mbw N --mbh N --frames N --gop N --seed N --intra-only ...]\n"); return 2; }
+    int frames = 30, gop = 30, intra_only = 0, crop_bottom = 0;
+    uint64_t seed = 1;
+    W = 22; H = 18;
+    for (int i = 2; i < argc; i++) {
+        const char *a = argv[i];
+        int v = i + 1 < argc ? atoi(argv[i + 1]) : 0;
+        if (!strcmp(a, "--mbw")) { W = v; i++; }
+        else if (!strcmp(a, "--mbh")) { H = v; i++; }
+        else if (!strcmp(a, "--frames")) { frames = v; i++; }
+        else if (!strcmp(a, "--gop")) { gop = v; i++; }
+        else if (!strcmp(a, "--seed")) { seed = (uint64_t)v; i++; }
+        else if (!strcmp(a, "--qp")) { opt_qp = v; i++; }
+        else if (!strcmp(a, "--coded")) { opt_coded = v; i++; }
+        else if (!strcmp(a, "--maxlevel")) { opt_maxlevel = v; i++; }
+        else if (!strcmp(a, "--mvmax")) { opt_mvmax = v; i++; }
+        else if (!strcmp(a, "--cqo")) { opt_cqo = v; i++; }
+        else if (!strcmp(a, "--crop-bottom")) { crop_bottom = v; i++; }
+        else if (!strcmp(a, "--intra-only")) intra_only = 1;
+        else if (!strcmp(a, "--nodeblock")) opt_deblock = 0;
+        else { fprintf(stderr, "unknown option %s\n", a); return 2; }
+    }
+    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51) { fprintf(stderr, "bad geometry\n"); return 2; }
+    NMB = W * H;
+    g_rng = seed * 0x9e3779b97f4a7c15ull + 264;
+    mb_type = calloc((size_t)NMB, 1); mvs = calloc((size_t)NMB * 32, 2); nnz = calloc((size_t)NMB, 24); i4m = calloc((size_t)NMB, 16);
+    FILE *f = fopen(argv[1], "wb");
+    if (!f) { perror(argv[1]); return 2; }
+    const int log2_fn = 8;
+    {   /* SPS: Baseline, POC type 2, one reference frame */
+        bw_t b = { 0 };
+        bw_put(&b, 8, 66); bw_put(&b, 8, 0xc0); bw_put(&b, 8, 40);
+        bw_ue(&b, 0); bw_ue(&b, log2_fn - 4); bw_ue(&b, 2);
+        bw_ue(&b, 1); bw_put(&b, 1, 0);
+        bw_ue(&b, (uint32_t)(W - 1)); bw_ue(&b, (uint32_t)(H - 1));
+        bw_put(&b, 1, 1); bw_put(&b, 1, 1);
+        if (crop_bottom) { bw_put(&b, 1, 1); bw_ue(&b, 0); bw_ue(&b, 0); bw_ue(&b, 0); bw_ue(&b, (uint32_t)crop_bottom); }
+        else bw_put(&b, 1, 0);
+        bw_put(&b, 1, 0);
+        bw_trailing(&b);
+        write_nal(f, 3, 7, &b); free(b.buf);
+    }
+    {   /* PPS: CAVLC, deblocking control present */
+        bw_t b = { 0 };
+        bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 1, 0); bw_ue(&b, 0);
+        bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 2, 0);
+        bw_se(&b, opt_qp - 26); bw_se(&b, 0); bw_se(&b, opt_cqo);
+        bw_put(&b, 1, 1); bw_put(&b, 1, 0); bw_put(&b, 1, 0);
+        bw_trailing(&b);
+        write_nal(f, 3, 8, &b); free(b.buf);
+    }
+    int frame_num = 0, idr_id = 0;
+    for (int n = 0; n < frames; n++) {
+        int idr = intra_only || n == 0 || (gop > 0 && n % gop == 0);
+        if (idr) frame_num = 0;
+        put_slice(f, idr, !idr, frame_num, idr_id, log2_fn);
+        if (idr) idr_id = (idr_id + 1) & 0xffff;
+        frame_num = (frame_num + 1) & ((1 << log2_fn) - 1);
+    }
+    fclose(f);
+    return 0;
+}

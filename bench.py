@@ -98,16 +98,12 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from p264decoder_amd import shard
+    rank, local_rank, world = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the reconstruction path")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    shard.init("nccl", torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm; barrier + clock only
 
     from p264decoder_amd import HipReconstructor, Parser, _native
     from tests import synth_cases
@@ -141,22 +137,16 @@ def main():
     hip.timing_enable(True)
     hip.timing_reset()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(1 + Wm, T):
         step(t)
     hip.sync()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    shard.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device="cuda")
     timing = hip.timing_read()
     hip.timing_enable(False)
 
@@ -205,8 +195,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(paths[0], T)
         print(json.dumps(out), flush=True)
     hip.close()
-    if dist:
-        dist.barrier()
+    shard.barrier()
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

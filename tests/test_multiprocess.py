@@ -1,0 +1,63 @@
+"""N>1 path on CPU: two processes (gloo) shard independent streams round-robin, each decodes its
+own (parser -> CPU oracle here, HIP on the GPU box), nothing but the barrier / clock / result
+gather crosses ranks, and the union equals the single-process result."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, time, json
+sys.path.insert(0, %(root)r)
+from p264decoder_amd import Parser, shard
+from tests import oracle_bind, synth_cases
+from tests.conftest import frame_sha256
+rank, local_rank, world = shard.init("gloo")
+ora = oracle_bind.load()
+cases = ["tiny_1x1", "row_1xN", "col_Nx1", "qp38", "nodeblock"]          # five independent "streams"
+mine = shard.streams_of_rank(len(cases), rank, world)
+shard.barrier()
+t0 = time.perf_counter()
+res = {}
+for s in mine:
+    parser = Parser(quiet=True)
+    pics = parser.parse_stream(synth_cases.stream_bytes(cases[s]))
+    store = oracle_bind.FrameStore(pics[0].mb_w, pics[0].mb_h, parser.slots)
+    res[s] = [frame_sha256(*oracle_bind.reconstruct(ora, store, p)) for p in pics]
+shard.barrier()
+el = shard.max_over_ranks(time.perf_counter() - t0)
+allres = shard.gather_objects(res)
+if rank == 0:
+    merged = {}
+    for r in allres: merged.update(r)
+    ok = all(merged[s] == synth_cases.golden(cases[s])[1] for s in range(len(cases)))
+    print(json.dumps({"ok": ok, "streams": sorted(merged), "owners": [sorted(r) for r in allres], "elapsed": el}))
+'''
+
+
+def test_two_ranks_shard_streams_with_gloo(lib, oracle, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["ok"] and r["streams"] == [0, 1, 2, 3, 4]
+    assert r["owners"] == [[0, 2, 4], [1, 3]]          # round-robin, disjoint, no stream decoded twice
+    assert r["elapsed"] > 0
+
+
+def test_sharding_is_a_partition():
+    from p264decoder_amd import shard
+    for world in (1, 2, 4, 8):
+        owned = [shard.streams_of_rank(37, r, world) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(37))

@@ -67,6 +67,27 @@ __device__ __constant__ const uint8_t c_tc0[52][3] = {
     {2,3,4},{3,3,5},{3,4,6},{3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},
     {9,12,18},{10,13,20},{11,15,23},{13,17,25} };
 
+// table-free forms for the hot kernels (no dependent constant-memory loads):
+// zig-zag scan position k -> raster position (same data as c_zigzag, one nibble per entry)
+__device__ __forceinline__ int zigzag_pos(int k) { return (int)(((k & 8) ? 0xFEB7ADC9u : 0x63258410u) >> (4 * (k & 7))) & 15; }
+
+// dequantisation parameters of one macroblock / plane: wave-uniform, so they live in SGPRs
+struct DqParams { int mf0, mf1, mf2, qbits; };
+__device__ __forceinline__ DqParams dq_params(int qp)
+{
+    int rem = qp % 6;
+    DqParams d = { c_dqmf[rem][0], c_dqmf[rem][1], c_dqmf[rem][2], qp / 6 - 4 };
+    return d;
+}
+__device__ __forceinline__ int dequant_coef(int c, int pos, const DqParams &d)
+{   // core/quant.c:66-99; position class (pos&1) + ((pos>>2)&1); int16 store wrap = A-Q8
+    int cls = (pos & 1) + ((pos >> 2) & 1);
+    int mf = cls == 0 ? d.mf0 : cls == 1 ? d.mf1 : d.mf2;
+    int v = c * mf;
+    v = d.qbits >= 0 ? (int)((unsigned)v << d.qbits) : (v + (1 << (-d.qbits - 1))) >> (-d.qbits);
+    return (int)(int16_t)v;
+}
+
 // luma 4x4 block index (decode order, core/macroblock.h:194-201) <-> position
 __device__ __forceinline__ int blk_x(int i) { return (i & 1) | ((i >> 1) & 2); }
 __device__ __forceinline__ int blk_y(int i) { return ((i >> 1) & 1) | ((i >> 2) & 2); }

@@ -30,8 +30,8 @@
 #define CWIN_DW 10                // 5 rows x 2 dwords per chroma quadrant window
 
 struct InterLds {                 // per wavefront
-    uint32_t ywin[4][YWIN_DW];
-    uint32_t cwin[2][4][CWIN_DW];
+    uint32_t ywin[4][YWIN_DW];    // whole-MB path: 21 rows x 6 dwords (+2 pad); quadrant path: 13 x 4 luma + 20 chroma dwords
+    uint32_t cwin[2][4][16];      // whole-MB path: 2 planes x 9 rows x 3 dwords (+pad)
     int16_t  coef[24 * 16];       // dequantised coefficients, raster order per block
 };
 
@@ -49,17 +49,17 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b
 __device__ __forceinline__ int no_fuse(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
 
-// ---- four samples from a 16-byte-per-row LDS window ---------------------------------------
-// 4 bytes at row r, byte b (b + 3 <= 15)
-__device__ __forceinline__ uint32_t row4(const uint32_t *w, int r, int b)
+// ---- four samples from an LDS window with a row pitch of P dwords ---------------------------
+// 4 bytes at row r, byte b
+template <int P> __device__ __forceinline__ uint32_t row4(const uint32_t *w, int r, int b)
 {
-    const uint32_t *p = w + r * 4 + (b >> 2);
+    const uint32_t *p = w + r * P + (b >> 2);
     return alignbyte(p[1], p[0], b & 3);
 }
 // 12 bytes at row r starting at byte `start` (only the first 9 are meaningful)
-__device__ __forceinline__ void row12(const uint32_t *w, int r, int start, uint32_t &n0, uint32_t &n1, uint32_t &n2)
+template <int P> __device__ __forceinline__ void row12(const uint32_t *w, int r, int start, uint32_t &n0, uint32_t &n1, uint32_t &n2)
 {
-    const uint32_t *p = w + r * 4 + (start >> 2);
+    const uint32_t *p = w + r * P + (start >> 2);
     uint32_t e0 = p[0], e1 = p[1], e2 = p[2];
     int s = start & 3;
     n0 = alignbyte(e1, e0, s); n1 = alignbyte(e2, e1, s); n2 = e2 >> (8 * s);
@@ -74,19 +74,19 @@ __device__ __forceinline__ void tap_h4(uint32_t n0, uint32_t n1, uint32_t n2, in
     t[2] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 2), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 2), C1, 4096, false), false);
     t[3] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 3), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 3), C1, 4096, false), false);
 }
-__device__ __forceinline__ uint32_t h4(const uint32_t *w, int r, int b)       // mc_hh, core/mc.c:172-185
+template <int P> __device__ __forceinline__ uint32_t h4(const uint32_t *w, int r, int b)       // mc_hh, core/mc.c:172-185
 {
     uint32_t n0, n1, n2; int t[4];
-    row12(w, r, b - 2, n0, n1, n2);
+    row12<P>(w, r, b - 2, n0, n1, n2);
     tap_h4(n0, n1, n2, t);
     return pack4(clip255(no_fuse((t[0] + 16) >> 5)), clip255(no_fuse((t[1] + 16) >> 5)), clip255(no_fuse((t[2] + 16) >> 5)), clip255(no_fuse((t[3] + 16) >> 5)));
 }
-__device__ __forceinline__ uint32_t v4(const uint32_t *w, int r, int b)       // mc_hv, core/mc.c:186-199
+template <int P> __device__ __forceinline__ uint32_t v4(const uint32_t *w, int r, int b)       // mc_hv, core/mc.c:186-199
 {
     s16x2 lo[6], hi[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        uint32_t d = row4(w, r - 2 + k, b);
+        uint32_t d = row4<P>(w, r - 2 + k, b);
         lo[k] = as_s16x2(d & 0x00ff00ffu); hi[k] = as_s16x2((d >> 8) & 0x00ff00ffu);
     }
     const s16x2 c20 = { 20, 20 }, c5 = { 5, 5 }, c16 = { 16, 16 }, z = { 0, 0 }, m = { 255, 255 };
@@ -97,14 +97,14 @@ __device__ __forceinline__ uint32_t v4(const uint32_t *w, int r, int b)       //
     b2 = __builtin_elementwise_min(__builtin_elementwise_max(b2, z), m);
     return as_u32(a) | (as_u32(b2) << 8);
 }
-__device__ __forceinline__ uint32_t hv4(const uint32_t *w, int r, int b)      // mc_hc, core/mc.c:200-235
+template <int P> __device__ __forceinline__ uint32_t hv4(const uint32_t *w, int r, int b)      // mc_hc, core/mc.c:200-235
 {
     int acc[4] = { 512, 512, 512, 512 };
     const int cv[6] = { 1, -5, 20, 20, -5, 1 };
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 6; k++) {
         uint32_t n0, n1, n2; int t[4];
-        row12(w, r - 2 + k, b - 2, n0, n1, n2);
+        row12<P>(w, r - 2 + k, b - 2, n0, n1, n2);
         tap_h4(n0, n1, n2, t);
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] += cv[k] * t[i];
@@ -112,20 +112,20 @@ __device__ __forceinline__ uint32_t hv4(const uint32_t *w, int r, int b)      //
     return pack4(clip255(no_fuse(acc[0] >> 10)), clip255(no_fuse(acc[1] >> 10)), clip255(no_fuse(acc[2] >> 10)), clip255(no_fuse(acc[3] >> 10)));
 }
 // four samples at half-pel coordinate (2x + hx, 2y + hy); plane choice as in core/mc.c:244-257
-__device__ __forceinline__ uint32_t half4(const uint32_t *w, int r, int b, int hx, int hy)
+template <int P> __device__ __forceinline__ uint32_t half4(const uint32_t *w, int r, int b, int hx, int hy)
 {
     r += hy >> 1; b += hx >> 1;
     int which = (hx & 1) | ((hy & 1) << 1);
-    if (which == 0) return row4(w, r, b);
-    if (which == 1) return h4(w, r, b);
-    if (which == 2) return v4(w, r, b);
-    return hv4(w, r, b);
+    if (which == 0) return row4<P>(w, r, b);
+    if (which == 1) return h4<P>(w, r, b);
+    if (which == 2) return v4<P>(w, r, b);
+    return hv4<P>(w, r, b);
 }
-__device__ __forceinline__ uint32_t qpel4(const uint32_t *w, int r, int b, int fx, int fy)
+template <int P> __device__ __forceinline__ uint32_t qpel4(const uint32_t *w, int r, int b, int fx, int fy)
 {
     int corr = (fx & 1) && (fy & 1) && ((fx & 2) ^ (fy & 2));
-    uint32_t a = half4(w, r, b, fx >> 1, (fy + 1 - corr) >> 1);
-    if ((fx | fy) & 1) a = avg4(a, half4(w, r, b, (fx + 1) >> 1, (fy + corr) >> 1));
+    uint32_t a = half4<P>(w, r, b, fx >> 1, (fy + 1 - corr) >> 1);
+    if ((fx | fy) & 1) a = avg4(a, half4<P>(w, r, b, (fx + 1) >> 1, (fy + corr) >> 1));
     return a;
 }
 
@@ -135,25 +135,40 @@ struct ClampedPlane {
     __device__ __forceinline__ int operator()(int x, int y) const
     { return p[clip3i(y, 0, h - 1) * w + clip3i(x, 0, w - 1)]; }
 };
-template <class F> __device__ __forceinline__ int tap_h(const F &f, int x, int y)
-{ return f(x-2, y) - 5*f(x-1, y) + 20*(f(x, y) + f(x+1, y)) - 5*f(x+2, y) + f(x+3, y); }
-template <class F> __device__ __forceinline__ int tap_v(const F &f, int x, int y)
-{ return f(x, y-2) - 5*f(x, y-1) + 20*(f(x, y) + f(x, y+1)) - 5*f(x, y+2) + f(x, y+3); }
-template <class F> __device__ int half_sample(const F &f, int x, int y, int hx, int hy)
+// Deliberately rolled loops: this path is rare (sub-8x8 partitions, windows crossing the left/right
+// picture edge) and must not set the register budget of the kernel.
+__device__ __forceinline__ int tap_coef(int k) { return (k == 0 || k == 5) ? 1 : (k == 1 || k == 4) ? -5 : 20; }
+__device__ __noinline__ int half_sample(const uint8_t *p, int w, int h, int x, int y, int hx, int hy)
 {
+    ClampedPlane f = { p, w, h };
     x += hx >> 1; y += hy >> 1;
     int which = (hx & 1) | ((hy & 1) << 1);
     if (which == 0) return f(x, y);
-    if (which == 1) return clip255((tap_h(f, x, y) + 16) >> 5);
-    if (which == 2) return clip255((tap_v(f, x, y) + 16) >> 5);
-    int t = tap_h(f, x, y-2) - 5*tap_h(f, x, y-1) + 20*(tap_h(f, x, y) + tap_h(f, x, y+1)) - 5*tap_h(f, x, y+2) + tap_h(f, x, y+3);
-    return clip255((t + 512) >> 10);
+    int s = 0;
+    if (which == 1) {
+#pragma unroll 1
+        for (int k = 0; k < 6; k++) s += tap_coef(k) * f(x - 2 + k, y);
+        return clip255((s + 16) >> 5);
+    }
+    if (which == 2) {
+#pragma unroll 1
+        for (int k = 0; k < 6; k++) s += tap_coef(k) * f(x, y - 2 + k);
+        return clip255((s + 16) >> 5);
+    }
+#pragma unroll 1
+    for (int j = 0; j < 6; j++) {
+        int t = 0;
+#pragma unroll 1
+        for (int k = 0; k < 6; k++) t += tap_coef(k) * f(x - 2 + k, y - 2 + j);
+        s += tap_coef(j) * t;
+    }
+    return clip255((s + 512) >> 10);
 }
-template <class F> __device__ int qpel_sample(const F &f, int x, int y, int fx, int fy)
+__device__ __forceinline__ int qpel_sample(const uint8_t *p, int w, int h, int x, int y, int fx, int fy)
 {
     int corr = (fx & 1) && (fy & 1) && ((fx & 2) ^ (fy & 2));
-    int a = half_sample(f, x, y, fx >> 1, (fy + 1 - corr) >> 1);
-    if ((fx | fy) & 1) a = (a + half_sample(f, x, y, (fx + 1) >> 1, (fy + corr) >> 1) + 1) >> 1;
+    int a = half_sample(p, w, h, x, y, fx >> 1, (fy + 1 - corr) >> 1);
+    if ((fx | fy) & 1) a = (a + half_sample(p, w, h, x, y, (fx + 1) >> 1, (fy + corr) >> 1) + 1) >> 1;
     return a;
 }
 __device__ __forceinline__ int chroma_sample(const ClampedPlane &c, int sx, int sy, int mvx, int mvy)
@@ -191,6 +206,40 @@ __device__ __forceinline__ uint32_t add_residual4(uint32_t pred, const int16_t *
                  clip255((int)((pred >> 16) & 255) + r[2]), clip255((int)(pred >> 24) + r[3]));
 }
 
+// chroma 1/8-pel bilinear, 4 samples (core/mc.c:303-334): w = the sample row inside a window of row pitch P dwords,
+// b = byte offset of the first sample (b + 4 <= 4P - 1 is guaranteed by the staging); (dx,dy) wave-uniform
+template <int P> __device__ __forceinline__ uint32_t chroma4(const uint32_t *w, int b, int dx, int dy)
+{
+    const uint32_t *p = w + (b >> 2);
+    const int s = b & 3;
+    const unsigned long long r0 = ((unsigned long long)p[1] << 32) | p[0], r1 = ((unsigned long long)p[P + 1] << 32) | p[P];
+    const uint32_t a = (uint32_t)(r0 >> (8 * s)), bb = (uint32_t)(r0 >> (8 * s + 8));
+    const uint32_t c = (uint32_t)(r1 >> (8 * s)), d = (uint32_t)(r1 >> (8 * s + 8));
+    const short cA = (short)((8 - dx) * (8 - dy)), cB = (short)(dx * (8 - dy)), cC = (short)((8 - dx) * dy), cD = (short)(dx * dy);
+    const s16x2 kA = { cA, cA }, kB = { cB, cB }, kC = { cC, cC }, kD = { cD, cD }, k32 = { 32, 32 };
+    s16x2 lo = kA * as_s16x2(a & 0x00ff00ffu) + kB * as_s16x2(bb & 0x00ff00ffu) + kC * as_s16x2(c & 0x00ff00ffu) + kD * as_s16x2(d & 0x00ff00ffu) + k32;
+    s16x2 hi = kA * as_s16x2((a >> 8) & 0x00ff00ffu) + kB * as_s16x2((bb >> 8) & 0x00ff00ffu) + kC * as_s16x2((c >> 8) & 0x00ff00ffu) + kD * as_s16x2((d >> 8) & 0x00ff00ffu) + k32;
+    // sums reach 64*255+32 = 16352 < 32768: the 16-bit lanes never overflow
+    return ((as_u32(lo) >> 6) & 0x00ff00ffu) | (((as_u32(hi) >> 6) & 0x00ff00ffu) << 8);
+}
+
+// rare paths kept out of line so that they do not set the register budget of the kernel
+__device__ __noinline__ uint32_t slow_luma4(const uint8_t *ref, int w, int h, int x, int y, int mv)
+{
+    uint32_t out = 0;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) out |= (uint32_t)qpel_sample(ref, w, h, x + i + (mv_x(mv) >> 2), y + (mv_y(mv) >> 2), mv_x(mv) & 3, mv_y(mv) & 3) << (8 * i);
+    return out;
+}
+__device__ __noinline__ uint32_t slow_chroma4(const uint8_t *ref, int w, int h, int x, int y, int mvA, int mvB)
+{
+    ClampedPlane f = { ref, w, h };
+    uint32_t out = 0;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) { int m2 = i < 2 ? mvA : mvB; out |= (uint32_t)chroma_sample(f, x + i, y, mv_x(m2), mv_y(m2)) << (8 * i); }
+    return out;
+}
+
 __global__ __launch_bounds__(256)
 void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_blocks)
 {
@@ -205,66 +254,23 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     const int mbi = rfl((logical - pic * blocks_per_pic) * 4 + wave);
     if (mbi >= g.n_mb) return;
     const PicDev *pd = pics + pic;
-    const p264hip_mb_t m = pd->mb[mbi];
-    if (P264_MB_IS_INTRA(m.mb_type)) return;
+
+    // ---------------- header: everything wave-uniform goes to SGPRs ----------------
+    const uint4 rec = *(const uint4 *)(pd->mb + mbi);
+    const unsigned w0 = (unsigned)rfl((int)rec.x), mask = (unsigned)rfl((int)rec.y);
+    const int mb_type = w0 & 255, qp = (w0 >> 8) & 255, cbp = (w0 >> 16) & 255;
+    if (P264_MB_IS_INTRA(mb_type)) return;
+    const int16_t *cf = pd->coefs + (size_t)(unsigned)rfl((int)rec.z) * 16;
+    const int mvreg = lane < 16 ? pd->mv[mbi * 16 + lane] : 0;
+    const int refs4 = rfl(*(const int *)(pd->ref_idx + mbi * 4));
+    const int n_ref = pd->n_ref;
 
     InterLds &L = lds[wave];
     const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w;
     const int X0 = mbx * 16, Y0 = mby * 16;
-    const int mvreg = lane < 16 ? pd->mv[mbi * 16 + lane] : 0;
-    const int refs4 = *(const int *)(pd->ref_idx + mbi * 4);
-    const unsigned mask = m.coef_mask;
-    const int16_t *cf = pd->coefs + (size_t)m.coef_index * 16;
 
-    // ---------------- per-quadrant set-up (wave-uniform) ----------------
-    int qmv[4]; const uint8_t *qref[4]; unsigned fast = 0;      // fully unrolled below: stay in SGPRs
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b0 = (q >> 1) * 8 + (q & 1) * 2;          // raster 4x4 index of the quadrant's first block
-        const int mv0 = __builtin_amdgcn_readlane(mvreg, b0), mv1 = __builtin_amdgcn_readlane(mvreg, b0 + 1);
-        const int mv2 = __builtin_amdgcn_readlane(mvreg, b0 + 4), mv3 = __builtin_amdgcn_readlane(mvreg, b0 + 5);
-        int ri = (int)(int8_t)(refs4 >> (8 * q));
-        if (ri < 0 || ri >= pd->n_ref) ri = 0;
-        qref[q] = pd->ref[ri];
-        qmv[q] = mv0;
-        const int wx0 = X0 + (q & 1) * 8 + (mv_x(mv0) >> 2) - 2;             // luma window column 0
-        const int cx0 = X0 / 2 + (q & 1) * 4 + (mv_x(mv0) >> 3);             // chroma window column 0
-        if (mv0 == mv1 && mv0 == mv2 && mv0 == mv3 && wx0 >= 0 && wx0 + 12 < g.w && cx0 >= 0 && cx0 + 4 < g.cw) fast |= 1u << q;
-    }
-
-    // ---------------- issue every global load of this macroblock ----------------
-    uint32_t yv[4], cv[2];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {                            // 4 windows x 13 rows x 4 dwords = 208 dwords
-        int i = lane + 64 * k;
-        yv[k] = 0;
-        if (i < 208) {
-            int q = i / 52, rem = i - q * 52, r = rem >> 2, d = rem & 3;
-            if ((fast >> q) & 1) {
-                int mv = q == 0 ? qmv[0] : q == 1 ? qmv[1] : q == 2 ? qmv[2] : qmv[3];
-                const uint8_t *rf = q == 0 ? qref[0] : q == 1 ? qref[1] : q == 2 ? qref[2] : qref[3];
-                int wx0 = X0 + (q & 1) * 8 + (mv_x(mv) >> 2) - 2;
-                int yy = clip3i(Y0 + (q >> 1) * 8 + (mv_y(mv) >> 2) - 2 + r, 0, g.h - 1);
-                yv[k] = *(const uint32_t *)(rf + (size_t)yy * g.w + (wx0 & ~3) + d * 4);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {                            // 2 planes x 4 quadrants x 5 rows x 2 dwords = 80 dwords
-        int i = lane + 64 * k;
-        cv[k] = 0;
-        if (i < 80) {
-            int p = i / 40, rem = i - p * 40, q = rem / 10, rr = rem - q * 10, r = rr >> 1, d = rr & 1;
-            if ((fast >> q) & 1) {
-                int mv = q == 0 ? qmv[0] : q == 1 ? qmv[1] : q == 2 ? qmv[2] : qmv[3];
-                const uint8_t *rf = q == 0 ? qref[0] : q == 1 ? qref[1] : q == 2 ? qref[2] : qref[3];
-                int cx0 = X0 / 2 + (q & 1) * 4 + (mv_x(mv) >> 3);
-                int yy = clip3i(Y0 / 2 + (q >> 1) * 4 + (mv_y(mv) >> 3) + r, 0, g.ch - 1);
-                cv[k] = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (cx0 & ~3) + d * 4);
-            }
-        }
-    }
-    // coded coefficients: luma block lane>>2, levels 4*(lane&3)..+3 ; chroma block 16+(lane>>3), levels 2*(lane&7)..+1
+    // coded coefficients are fetched now, whatever path the prediction takes:
+    // luma block lane>>2, levels 4*(lane&3)..+3 ; chroma block 16+(lane>>3), levels 2*(lane&7)..+1
     uint2 lc = make_uint2(0, 0); uint32_t cc = 0; int cdc = 0;
     if (mask) {
         int lb = lane >> 2;
@@ -274,29 +280,113 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdc = cf[((mask >> 24) & 1) * 16 + lane];
     }
 
-    // ---------------- land them in LDS ----------------
+    const int row = lane >> 2, dw = lane & 3;                 // luma: lane = (row, dword) of the 16x16 block
+    const int crow = (lane >> 1) & 7, cdw = lane & 1, cp = (lane >> 4) & 1;   // chroma (lanes 0..31): (plane, row, dword)
+    uint32_t outY = 0, outC = 0;
+
+    const int mv0 = __builtin_amdgcn_readfirstlane(mvreg);
+    int r0i = (int)(int8_t)refs4;
+    if (r0i < 0 || r0i >= n_ref) r0i = 0;
+    const bool same_mv = __ballot(lane < 16 && mvreg != mv0) == 0 && (unsigned)refs4 == ((unsigned)(refs4 & 255) * 0x01010101u);
+    const int ux0 = X0 + (mv_x(mv0) >> 2) - 2, ucx0 = X0 / 2 + (mv_x(mv0) >> 3);
+
+    if (same_mv && ux0 >= 0 && ux0 + 20 < g.w && ucx0 >= 0 && ucx0 + 8 < g.cw) {
+        // ======== one vector for the whole macroblock (16x16 partitions and P_SKIP) ========
+        // luma window 21 rows x 6 dwords, chroma windows 2 x 9 rows x 3 dwords: three load instructions
+        const uint8_t *rf = pd->ref[r0i];
+        const int lx = mv_x(mv0), ly = mv_y(mv0);
+        uint32_t yv[2], cvv = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int i = lane + 64 * k; if (i < 208) { int q = i / 52; L.ywin[q][i - q * 52] = yv[k]; } }
-#pragma unroll
-    for (int k = 0; k < 2; k++) { int i = lane + 64 * k; if (i < 80) { int p = i / 40, rem = i - p * 40, q = rem / 10; L.cwin[p][q][rem - q * 10] = cv[k]; } }
+        for (int k = 0; k < 2; k++) {
+            int i = lane + 64 * k, r = (i * 43) >> 8, d = i - r * 6;       // i / 6 for i < 128
+            yv[k] = 0;
+            if (i < 126) {
+                int yy = clip3i(Y0 + (ly >> 2) - 2 + r, 0, g.h - 1);
+                yv[k] = *(const uint32_t *)(rf + (size_t)yy * g.w + (ux0 & ~3) + d * 4);
+            }
+        }
+        if (lane < 54) {
+            int p = lane >= 27, l2 = lane - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
+            int yy = clip3i(Y0 / 2 + (ly >> 3) + r, 0, g.ch - 1);
+            cvv = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (ucx0 & ~3) + d * 4);
+        }
+        uint32_t *yw = &L.ywin[0][0], *cw = &L.cwin[0][0][0];
+        yw[lane] = yv[0];
+        if (lane < 62) yw[64 + lane] = yv[1];
+        if (lane < 54) cw[lane] = cvv;
+        wave_lds_fence();
+        outY = qpel4<6>(yw, row + 2, (ux0 & 3) + 2 + dw * 4, lx & 3, ly & 3);
+        if (lane < 32) outC = chroma4<3>(cw + cp * 27 + crow * 3, (ucx0 & 3) + cdw * 4, lx & 7, ly & 7);
+    } else {
+        // ======== general case: one 8x8 quadrant after the other ========
+        const int mvl = __shfl(mvreg, (row >> 2) * 4 + dw);
+        const int mvA = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2), mvB = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2 + 1);
+        const int lq = (row >> 3) * 2 + (dw >> 1), cq = (crow >> 2) * 2 + cdw;
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+            const int b0 = (q >> 1) * 8 + (q & 1) * 2;      // raster 4x4 index of the quadrant's first block
+            const int qmv = __builtin_amdgcn_readlane(mvreg, b0);
+            const bool uni = qmv == __builtin_amdgcn_readlane(mvreg, b0 + 1) && qmv == __builtin_amdgcn_readlane(mvreg, b0 + 4) &&
+                             qmv == __builtin_amdgcn_readlane(mvreg, b0 + 5);
+            int ri = (int)(int8_t)(refs4 >> (8 * q));
+            if (ri < 0 || ri >= n_ref) ri = 0;
+            const uint8_t *rf = pd->ref[ri];
+            const int lx = mv_x(qmv), ly = mv_y(qmv);
+            const int wx0 = X0 + (q & 1) * 8 + (lx >> 2) - 2, cx0 = X0 / 2 + (q & 1) * 4 + (lx >> 3);
+            if (uni && wx0 >= 0 && wx0 + 12 < g.w && cx0 >= 0 && cx0 + 4 < g.cw) {
+                uint32_t v = 0;                              // lanes 0..51: 13 x 4 luma dwords; 52..63: first 12 chroma dwords
+                uint32_t v2 = 0;                             // lanes 0..7: remaining 8 chroma dwords
+                {
+                    int ci = lane - 52;                      // chroma dword index 0..19: plane = ci/10, row = (ci%10)>>1, d = ci&1
+                    if (lane < 52) {
+                        int yy = clip3i(Y0 + (q >> 1) * 8 + (ly >> 2) - 2 + (lane >> 2), 0, g.h - 1);
+                        v = *(const uint32_t *)(rf + (size_t)yy * g.w + (wx0 & ~3) + (lane & 3) * 4);
+                    } else {
+                        int p = ci >= 10, c2 = ci - 10 * p;
+                        int yy = clip3i(Y0 / 2 + (q >> 1) * 4 + (ly >> 3) + (c2 >> 1), 0, g.ch - 1);
+                        v = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (cx0 & ~3) + (c2 & 1) * 4);
+                    }
+                    if (lane < 8) {
+                        int c3 = 12 + lane, p = c3 >= 10, c2 = c3 - 10 * p;
+                        int yy = clip3i(Y0 / 2 + (q >> 1) * 4 + (ly >> 3) + (c2 >> 1), 0, g.ch - 1);
+                        v2 = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (cx0 & ~3) + (c2 & 1) * 4);
+                    }
+                }
+                wave_lds_fence();                            // the previous quadrant has finished reading
+                L.ywin[0][lane] = v;                         // dwords 52..63 = chroma 0..11
+                if (lane < 8) L.ywin[0][64 + lane] = v2;     // chroma 12..19
+                wave_lds_fence();
+                if (lq == q) outY = qpel4<4>(L.ywin[0], (row & 7) + 2, (wx0 & 3) + 2 + (dw & 1) * 4, lx & 3, ly & 3);
+                if (lane < 32 && cq == q) outC = chroma4<2>(L.ywin[0] + 52 + cp * 10 + (crow & 3) * 2, cx0 & 3, lx & 7, ly & 7);
+            } else {
+                // sub-8x8 partitions with differing vectors, or a window crossing the left/right
+                // picture edge: every lane samples the clamped plane with its own vectors
+                if (lq == q) outY = slow_luma4(rf, g.w, g.h, X0 + dw * 4, Y0 + row, mvl);
+                if (lane < 32 && cq == q) outC = slow_chroma4(rf + (cp ? g.off_v : g.off_u), g.cw, g.ch, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
+            }
+        }
+    }
+
+    // ---------------- residual (decoder/macroblock.c:832-890) ----------------
     if (mask) {
-        const int qp = m.qp;
-        if (mask & 0xffff) {                                  // luma: unscan + dequant (decoder/macroblock.c:839-843)
+        if (mask & 0xffff) {                                  // luma: unscan + dequant
+            const DqParams dq = dq_params(qp);
             int lb = lane >> 2;
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
+                int pos = zigzag_pos((lane & 3) * 4 + kk);
                 int c = (int)(int16_t)((kk & 2 ? lc.y : lc.x) >> (16 * (kk & 1)));
-                L.coef[lb * 16 + pos] = (int16_t)dequant_coef(c, pos, qp);
+                L.coef[lb * 16 + pos] = (int16_t)dequant_coef(c, pos, dq);
             }
         }
-        if (m.cbp >> 4) {                                     // chroma: DC (core/dct.c:55-68, core/quant.c:138-159) + AC
+        if (cbp >> 4) {                                       // chroma: DC (core/dct.c:55-68, core/quant.c:138-159) + AC
             const int qpc = c_chroma_qp[clip3i(qp + pd->chroma_qp_offset, 0, 51)];
+            const DqParams dq = dq_params(qpc);
             int cb = 16 + (lane >> 3), i2 = lane & 7;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {                  // level index 2*i2+kk sits at scan position 2*i2+kk+1
                 int k = 2 * i2 + kk + 1;
-                if (k < 16) { int pos = c_zigzag[k]; L.coef[cb * 16 + pos] = (int16_t)dequant_coef((int)(int16_t)(cc >> (16 * kk)), pos, qpc); }
+                if (k < 16) { int pos = zigzag_pos(k); L.coef[cb * 16 + pos] = (int16_t)dequant_coef((int)(int16_t)(cc >> (16 * kk)), pos, dq); }
             }
             // DC of chroma block j of plane p: lanes 0..7 hold the parsed DC levels of (p = lane>>2, index lane&3)
             int d0 = __shfl(cdc, (lane >> 5) * 4 + 0), d1 = __shfl(cdc, (lane >> 5) * 4 + 1);
@@ -306,72 +396,19 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
                 int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
                 int f = j == 0 ? t0 + t2 : j == 1 ? t1 + t3 : j == 2 ? t0 - t2 : t1 - t3;
                 f = (int)(int16_t)f;
-                int qbits = qpc / 6 - 5, mf = c_dqmf[qpc % 6][0];
-                int v = qbits >= 0 ? f * (int)((unsigned)mf << qbits) : (f * mf) >> (-qbits);
+                int qbits = dq.qbits - 1;                     // qpc/6 - 5
+                int v = qbits >= 0 ? f * (int)((unsigned)dq.mf0 << qbits) : (f * dq.mf0) >> (-qbits);
                 L.coef[cb * 16] = (int16_t)v;
             }
         }
-    }
-    wave_lds_fence();
-
-    // ---------------- luma: lane = (row, dword) of the 16x16 block ----------------
-    const int row = lane >> 2, dw = lane & 3;
-    uint32_t outY;
-    {
-        const int q = (row >> 3) * 2 + (dw >> 1);
-        const int mvl = __shfl(mvreg, (row >> 2) * 4 + dw);
-        const int lx = mv_x(mvl), ly = mv_y(mvl);
-        if ((fast >> q) & 1) {
-            const int wx0 = X0 + (q & 1) * 8 + (lx >> 2) - 2;
-            outY = qpel4(L.ywin[q], (row & 7) + 2, (wx0 & 3) + 2 + (dw & 1) * 4, lx & 3, ly & 3);
-        } else {
-            int ri = (int)(int8_t)(refs4 >> (8 * q));
-            if (ri < 0 || ri >= pd->n_ref) ri = 0;
-            ClampedPlane f = { pd->ref[ri], g.w, g.h };
-            int v[4];
-            for (int i = 0; i < 4; i++) v[i] = qpel_sample(f, X0 + dw * 4 + i + (lx >> 2), Y0 + row + (ly >> 2), lx & 3, ly & 3);
-            outY = pack4(v[0], v[1], v[2], v[3]);
-        }
+        wave_lds_fence();
         const int blk = blk_at(dw, row >> 2);
         if ((mask >> blk) & 1) outY = add_residual4(outY, L.coef + blk * 16, row & 3);
+        if (lane < 32 && (cbp >> 4)) outC = add_residual4(outC, L.coef + (16 + cp * 4 + (crow >> 2) * 2 + cdw) * 16, crow & 3);
     }
-    *(uint32_t *)(pd->dst + (size_t)(Y0 + row) * g.w + X0 + dw * 4) = outY;
 
-    // ---------------- chroma: lanes 0..31 = (plane, row, dword) of the two 8x8 blocks ----------------
-    if (lane < 32) {
-        const int p = lane >> 4, crow = (lane >> 1) & 7, cdw = lane & 1;
-        const int q = (crow >> 2) * 2 + cdw;
-        uint32_t outC;
-        // vectors of the two 4x4 luma blocks this dword spans (equal on the fast path); shuffled here,
-        // outside the divergent branch, so that the source lanes 0..15 are active
-        const int mvA = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2), mvB = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2 + 1);
-        if ((fast >> q) & 1) {
-            const int lx = mv_x(mvA), ly = mv_y(mvA);
-            const int cx0 = X0 / 2 + (q & 1) * 4 + (lx >> 3);
-            const uint32_t *w = L.cwin[p][q] + (crow & 3) * 2;
-            const int off = cx0 & 3;
-            const unsigned long long r0 = ((unsigned long long)w[1] << 32) | w[0], r1 = ((unsigned long long)w[3] << 32) | w[2];
-            const uint32_t a = (uint32_t)(r0 >> (8 * off)), b = (uint32_t)(r0 >> (8 * off + 8));
-            const uint32_t c = (uint32_t)(r1 >> (8 * off)), d = (uint32_t)(r1 >> (8 * off + 8));
-            const int dx = lx & 7, dy = ly & 7;
-            const short cA = (short)((8 - dx) * (8 - dy)), cB = (short)(dx * (8 - dy)), cC = (short)((8 - dx) * dy), cD = (short)(dx * dy);
-            const s16x2 kA = { cA, cA }, kB = { cB, cB }, kC = { cC, cC }, kD = { cD, cD }, k32 = { 32, 32 };
-            s16x2 lo = kA * as_s16x2(a & 0x00ff00ffu) + kB * as_s16x2(b & 0x00ff00ffu) + kC * as_s16x2(c & 0x00ff00ffu) + kD * as_s16x2(d & 0x00ff00ffu) + k32;
-            s16x2 hi = kA * as_s16x2((a >> 8) & 0x00ff00ffu) + kB * as_s16x2((b >> 8) & 0x00ff00ffu) + kC * as_s16x2((c >> 8) & 0x00ff00ffu) + kD * as_s16x2((d >> 8) & 0x00ff00ffu) + k32;
-            // sums reach 64*255+32 = 16352 < 32768: the 16-bit lanes never overflow; logical shift of non-negative values
-            outC = ((as_u32(lo) >> 6) & 0x00ff00ffu) | (((as_u32(hi) >> 6) & 0x00ff00ffu) << 8);
-        } else {
-            int ri = (int)(int8_t)(refs4 >> (8 * q));
-            if (ri < 0 || ri >= pd->n_ref) ri = 0;
-            ClampedPlane f = { pd->ref[ri] + (p ? g.off_v : g.off_u), g.cw, g.ch };
-            int v[4];
-            for (int i = 0; i < 4; i++) {
-                int mv = i < 2 ? mvA : mvB;
-                v[i] = chroma_sample(f, X0 / 2 + cdw * 4 + i, Y0 / 2 + crow, mv_x(mv), mv_y(mv));
-            }
-            outC = pack4(v[0], v[1], v[2], v[3]);
-        }
-        if (mask && (m.cbp >> 4)) outC = add_residual4(outC, L.coef + (16 + p * 4 + (crow >> 2) * 2 + cdw) * 16, crow & 3);
-        *(uint32_t *)(pd->dst + (p ? g.off_v : g.off_u) + (size_t)(Y0 / 2 + crow) * g.cw + X0 / 2 + cdw * 4) = outC;
-    }
+    // ---------------- the lane stores its own dword ----------------
+    *(uint32_t *)(pd->dst + (size_t)(Y0 + row) * g.w + X0 + dw * 4) = outY;
+    if (lane < 32)
+        *(uint32_t *)(pd->dst + (cp ? g.off_v : g.off_u) + (size_t)(Y0 / 2 + crow) * g.cw + X0 / 2 + cdw * 4) = outC;
 }

@@ -54,7 +54,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    lib = C.CDLL(path or LIB_PATH)
+    lib = C.CDLL(path or os.environ.get("P264AMD_LIB") or LIB_PATH)
     u8p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
     # ---- p264parse.h
     lib.p264parse_open.restype = C.c_void_p

@@ -25,6 +25,21 @@
 // reference's pads (SURVEY A-Q9).
 #pragma once
 #include "device_common.h"
+#ifndef EXP_NOCOMPUTE
+#define EXP_NOCOMPUTE 0
+#endif
+#ifndef EXP_NORESID
+#define EXP_NORESID 0
+#endif
+#ifndef EXP_NOSTORE
+#define EXP_NOSTORE 0
+#endif
+#ifndef EXP_NOLOAD
+#define EXP_NOLOAD 0
+#endif
+#ifndef EXP_HDRONLY
+#define EXP_HDRONLY 0
+#endif
 
 #define YWIN_DW 56                // 13 rows x 4 dwords (+4 pad) per luma quadrant window
 #define CWIN_DW 10                // 5 rows x 2 dwords per chroma quadrant window
@@ -280,6 +295,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdc = cf[((mask >> 24) & 1) * 16 + lane];
     }
 
+    if (EXP_HDRONLY) { if (mvreg == 0x7fffffff) pd->dst[0] = 1; return; }
     const int row = lane >> 2, dw = lane & 3;                 // luma: lane = (row, dword) of the 16x16 block
     const int crow = (lane >> 1) & 7, cdw = lane & 1, cp = (lane >> 4) & 1;   // chroma (lanes 0..31): (plane, row, dword)
     uint32_t outY = 0, outC = 0;
@@ -300,12 +316,12 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         for (int k = 0; k < 2; k++) {
             int i = lane + 64 * k, r = (i * 43) >> 8, d = i - r * 6;       // i / 6 for i < 128
             yv[k] = 0;
-            if (i < 126) {
+            if (i < 126 && !EXP_NOLOAD) {
                 int yy = clip3i(Y0 + (ly >> 2) - 2 + r, 0, g.h - 1);
                 yv[k] = *(const uint32_t *)(rf + (size_t)yy * g.w + (ux0 & ~3) + d * 4);
             }
         }
-        if (lane < 54) {
+        if (lane < 54 && !EXP_NOLOAD) {
             int p = lane >= 27, l2 = lane - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
             int yy = clip3i(Y0 / 2 + (ly >> 3) + r, 0, g.ch - 1);
             cvv = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (ucx0 & ~3) + d * 4);
@@ -315,60 +331,90 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         if (lane < 62) yw[64 + lane] = yv[1];
         if (lane < 54) cw[lane] = cvv;
         wave_lds_fence();
+#if EXP_NOCOMPUTE
+        outY = yw[lane]; outC = cw[lane & 31];
+#else
         outY = qpel4<6>(yw, row + 2, (ux0 & 3) + 2 + dw * 4, lx & 3, ly & 3);
         if (lane < 32) outC = chroma4<3>(cw + cp * 27 + crow * 3, (ucx0 & 3) + cdw * 4, lx & 7, ly & 7);
+#endif
     } else {
-        // ======== general case: one 8x8 quadrant after the other ========
+        // ======== general case: four 8x8 quadrants; all their windows are fetched at once ========
         const int mvl = __shfl(mvreg, (row >> 2) * 4 + dw);
         const int mvA = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2), mvB = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2 + 1);
         const int lq = (row >> 3) * 2 + (dw >> 1), cq = (crow >> 2) * 2 + cdw;
-#pragma unroll 1
+        int qmv[4]; const uint8_t *qref[4]; unsigned fast = 0;      // fully unrolled: SGPRs
+#pragma unroll
         for (int q = 0; q < 4; q++) {
             const int b0 = (q >> 1) * 8 + (q & 1) * 2;      // raster 4x4 index of the quadrant's first block
-            const int qmv = __builtin_amdgcn_readlane(mvreg, b0);
-            const bool uni = qmv == __builtin_amdgcn_readlane(mvreg, b0 + 1) && qmv == __builtin_amdgcn_readlane(mvreg, b0 + 4) &&
-                             qmv == __builtin_amdgcn_readlane(mvreg, b0 + 5);
+            qmv[q] = __builtin_amdgcn_readlane(mvreg, b0);
+            const bool uni = qmv[q] == __builtin_amdgcn_readlane(mvreg, b0 + 1) && qmv[q] == __builtin_amdgcn_readlane(mvreg, b0 + 4) &&
+                             qmv[q] == __builtin_amdgcn_readlane(mvreg, b0 + 5);
             int ri = (int)(int8_t)(refs4 >> (8 * q));
             if (ri < 0 || ri >= n_ref) ri = 0;
-            const uint8_t *rf = pd->ref[ri];
-            const int lx = mv_x(qmv), ly = mv_y(qmv);
-            const int wx0 = X0 + (q & 1) * 8 + (lx >> 2) - 2, cx0 = X0 / 2 + (q & 1) * 4 + (lx >> 3);
-            if (uni && wx0 >= 0 && wx0 + 12 < g.w && cx0 >= 0 && cx0 + 4 < g.cw) {
-                uint32_t v = 0;                              // lanes 0..51: 13 x 4 luma dwords; 52..63: first 12 chroma dwords
-                uint32_t v2 = 0;                             // lanes 0..7: remaining 8 chroma dwords
-                {
-                    int ci = lane - 52;                      // chroma dword index 0..19: plane = ci/10, row = (ci%10)>>1, d = ci&1
-                    if (lane < 52) {
-                        int yy = clip3i(Y0 + (q >> 1) * 8 + (ly >> 2) - 2 + (lane >> 2), 0, g.h - 1);
-                        v = *(const uint32_t *)(rf + (size_t)yy * g.w + (wx0 & ~3) + (lane & 3) * 4);
-                    } else {
-                        int p = ci >= 10, c2 = ci - 10 * p;
-                        int yy = clip3i(Y0 / 2 + (q >> 1) * 4 + (ly >> 3) + (c2 >> 1), 0, g.ch - 1);
-                        v = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (cx0 & ~3) + (c2 & 1) * 4);
-                    }
-                    if (lane < 8) {
-                        int c3 = 12 + lane, p = c3 >= 10, c2 = c3 - 10 * p;
-                        int yy = clip3i(Y0 / 2 + (q >> 1) * 4 + (ly >> 3) + (c2 >> 1), 0, g.ch - 1);
-                        v2 = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (cx0 & ~3) + (c2 & 1) * 4);
-                    }
+            qref[q] = pd->ref[ri];
+            const int wx0 = X0 + (q & 1) * 8 + (mv_x(qmv[q]) >> 2) - 2, cx0 = X0 / 2 + (q & 1) * 4 + (mv_x(qmv[q]) >> 3);
+            if (uni && wx0 >= 0 && wx0 + 12 < g.w && cx0 >= 0 && cx0 + 4 < g.cw) fast |= 1u << q;
+        }
+        uint32_t yv[4], cv[2];
+        {
+            const int r = lane >> 2, d = lane & 3;           // luma: one instruction per quadrant, lanes 0..51
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                yv[q] = 0;
+                if (((fast >> q) & 1) && lane < 52) {
+                    int wx0 = X0 + (q & 1) * 8 + (mv_x(qmv[q]) >> 2) - 2;
+                    int yy = clip3i(Y0 + (q >> 1) * 8 + (mv_y(qmv[q]) >> 2) - 2 + r, 0, g.h - 1);
+                    yv[q] = *(const uint32_t *)(qref[q] + (size_t)yy * g.w + (wx0 & ~3) + d * 4);
                 }
-                wave_lds_fence();                            // the previous quadrant has finished reading
-                L.ywin[0][lane] = v;                         // dwords 52..63 = chroma 0..11
-                if (lane < 8) L.ywin[0][64 + lane] = v2;     // chroma 12..19
-                wave_lds_fence();
-                if (lq == q) outY = qpel4<4>(L.ywin[0], (row & 7) + 2, (wx0 & 3) + 2 + (dw & 1) * 4, lx & 3, ly & 3);
-                if (lane < 32 && cq == q) outC = chroma4<2>(L.ywin[0] + 52 + cp * 10 + (crow & 3) * 2, cx0 & 3, lx & 7, ly & 7);
+            }
+            const int q4 = lane >> 4, rr = lane & 15, cr = rr >> 1, cd = rr & 1;   // chroma: one instruction per plane, 16 lanes per quadrant
+            const int cmv = q4 == 0 ? qmv[0] : q4 == 1 ? qmv[1] : q4 == 2 ? qmv[2] : qmv[3];
+            const uint8_t *crf = q4 == 0 ? qref[0] : q4 == 1 ? qref[1] : q4 == 2 ? qref[2] : qref[3];
+            const int cx0 = X0 / 2 + (q4 & 1) * 4 + (mv_x(cmv) >> 3);
+            const int cyy = clip3i(Y0 / 2 + (q4 >> 1) * 4 + (mv_y(cmv) >> 3) + cr, 0, g.ch - 1);
+            const bool cok = ((fast >> q4) & 1) && rr < 10;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                cv[p] = 0;
+                if (cok) cv[p] = *(const uint32_t *)(crf + (p ? g.off_v : g.off_u) + (size_t)cyy * g.cw + (cx0 & ~3) + cd * 4);
+            }
+        }
+        if (lane < 52) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) L.ywin[q][lane] = yv[q];
+        }
+        if ((lane & 15) < 10) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) L.cwin[p][lane >> 4][lane & 15] = cv[p];
+        }
+        wave_lds_fence();
+        // one pass per distinct (vector, reference): the phase is wave-uniform inside a pass
+        unsigned todo = 15;
+#pragma unroll
+        for (int q0 = 0; q0 < 4; q0++) {
+            if (!((todo >> q0) & 1)) continue;
+            unsigned group = 0;
+#pragma unroll
+            for (int q = q0; q < 4; q++)
+                if (qmv[q] == qmv[q0] && qref[q] == qref[q0] && ((fast >> q) & 1) == ((fast >> q0) & 1)) group |= 1u << q;
+            todo &= ~group;
+            if ((fast >> q0) & 1) {
+                const int lx = mv_x(qmv[q0]), ly = mv_y(qmv[q0]);
+                if ((group >> lq) & 1)
+                    outY = qpel4<4>(L.ywin[lq], (row & 7) + 2, ((X0 + (lx >> 2) - 2) & 3) + 2 + (dw & 1) * 4, lx & 3, ly & 3);
+                if (lane < 32 && ((group >> cq) & 1))
+                    outC = chroma4<2>(L.cwin[cp][cq] + (crow & 3) * 2, (X0 / 2 + (lx >> 3)) & 3, lx & 7, ly & 7);
             } else {
                 // sub-8x8 partitions with differing vectors, or a window crossing the left/right
                 // picture edge: every lane samples the clamped plane with its own vectors
-                if (lq == q) outY = slow_luma4(rf, g.w, g.h, X0 + dw * 4, Y0 + row, mvl);
-                if (lane < 32 && cq == q) outC = slow_chroma4(rf + (cp ? g.off_v : g.off_u), g.cw, g.ch, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
+                if ((group >> lq) & 1) outY = slow_luma4(qref[q0], g.w, g.h, X0 + dw * 4, Y0 + row, mvl);
+                if (lane < 32 && ((group >> cq) & 1)) outC = slow_chroma4(qref[q0] + (cp ? g.off_v : g.off_u), g.cw, g.ch, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
             }
         }
     }
 
     // ---------------- residual (decoder/macroblock.c:832-890) ----------------
-    if (mask) {
+    if (mask && !EXP_NORESID) {
         if (mask & 0xffff) {                                  // luma: unscan + dequant
             const DqParams dq = dq_params(qp);
             int lb = lane >> 2;
@@ -408,6 +454,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     }
 
     // ---------------- the lane stores its own dword ----------------
+    if (EXP_NOSTORE && outY != 0x12345678u) return;
     *(uint32_t *)(pd->dst + (size_t)(Y0 + row) * g.w + X0 + dw * 4) = outY;
     if (lane < 32)
         *(uint32_t *)(pd->dst + (cp ? g.off_v : g.off_u) + (size_t)(Y0 / 2 + crow) * g.cw + X0 / 2 + cdw * 4) = outC;

@@ -56,6 +56,7 @@ struct p264hip_ctx {
     hipEvent_t batch_free[BATCH_RING] = {};
     int batch_cap = 0, ring = 0;
     int *d_status = nullptr;
+    EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
     bool timing = false;
     struct Stamp { hipEvent_t a, b; int k; };
     std::vector<Stamp> stamps;
@@ -117,6 +118,7 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     for (auto &s : c->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->frames) (void)hipFree(c->frames);
+    if (c->d_edge) (void)hipFree(c->d_edge);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -222,6 +224,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
             if (!c->batch_free[i]) HIPCHK(hipEventCreateWithFlags(&c->batch_free[i], hipEventDisableTiming));
             HIPCHK(hipEventRecord(c->batch_free[i], c->stream));
         }
+        if (c->d_edge) (void)hipFree(c->d_edge);
+        c->d_edge = nullptr;
+        HIPCHK(hipMalloc((void **)&c->d_edge, (size_t)n * c->g.n_mb * sizeof(EdgeInfo)));
         c->batch_cap = n;
     }
     const int r = c->ring; c->ring = (c->ring + 1) % BATCH_RING;
@@ -263,7 +268,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     }
     {
         ScopedStamp t(c, 2);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(ROW_WAVES * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
+        int total = n * g.n_mb;
+        hipLaunchKernelGGL(k_deblock_bs, dim3((total + 7) / 8), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, n);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(ROW_WAVES * 64), 0, c->stream, c->d_batch[r], g, (const EdgeInfo *)c->d_edge, c->d_status);
     }
     HIPCHK(hipGetLastError());
     return P264HIP_OK;

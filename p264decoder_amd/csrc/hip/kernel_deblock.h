@@ -27,6 +27,18 @@
 //     its prefetch anyway, so the stores of MB x-1 have long completed.
 #pragma once
 #include "device_common.h"
+#ifndef EXPD_NOFILTER
+#define EXPD_NOFILTER 0
+#endif
+#ifndef EXPD_NOSTORE
+#define EXPD_NOSTORE 0
+#endif
+#ifndef EXPD_NOLOAD
+#define EXPD_NOLOAD 0
+#endif
+#ifndef EXPD_NOWAIT
+#define EXPD_NOWAIT 0
+#endif
 #include "wavefront_sync.h"
 
 #define DY_DW 5                    // luma tile row: 5 dwords = cols -4..15
@@ -112,196 +124,242 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// sample filters on an LDS tile
+// sample filters on register values
 // ------------------------------------------------------------------------------------------
-// One line across one edge.  q points at q0 inside an LDS tile, xs = distance between samples
-// across the edge.  bS < 4: core/frame.c:302-341 (luma) / 351-377 (chroma); bS == 4: :387-462.
-__device__ __forceinline__ void filter_line_luma(uint8_t *q, int xs, int bS, int alpha, int beta, int tc0)
+// One line across one edge: p[0..3] = p0..p3, q[0..3] = q0..q3 (ints), updated in place.
+// bS < 4: core/frame.c:302-341 (luma) / 351-377 (chroma); bS == 4: :387-462.
+__device__ __forceinline__ void filter_luma(int (&p)[4], int (&q)[4], int bS, int alpha, int beta, int tc0)
 {
-    int p2 = q[-3*xs], p1 = q[-2*xs], p0 = q[-xs], q0 = q[0], q1 = q[xs], q2 = q[2*xs];
+    const int p0 = p[0], p1 = p[1], p2 = p[2], q0 = q[0], q1 = q[1], q2 = q[2];
     if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
     if (bS < 4) {
         int tc = tc0;
-        if (abs(p2 - p0) < beta) { q[-2*xs] = (uint8_t)(p1 + clip3i(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0)); tc++; }
-        if (abs(q2 - q0) < beta) { q[xs]    = (uint8_t)(q1 + clip3i(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0)); tc++; }
+        if (abs(p2 - p0) < beta) { p[1] = p1 + clip3i(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0); tc++; }
+        if (abs(q2 - q0) < beta) { q[1] = q1 + clip3i(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0); tc++; }
         int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-        q[-xs] = (uint8_t)clip255(p0 + delta);
-        q[0]   = (uint8_t)clip255(q0 - delta);
+        p[0] = clip255(p0 + delta);
+        q[0] = clip255(q0 - delta);
     } else {
         if (abs(p0 - q0) < ((alpha >> 2) + 2)) {
             if (abs(p2 - p0) < beta) {
-                int p3 = q[-4*xs];
-                q[-xs]   = (uint8_t)((p2 + 2*p1 + 2*p0 + 2*q0 + q1 + 4) >> 3);
-                q[-2*xs] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
-                q[-3*xs] = (uint8_t)((2*p3 + 3*p2 + p1 + p0 + q0 + 4) >> 3);
-            } else q[-xs] = (uint8_t)((2*p1 + p0 + q1 + 2) >> 2);
+                p[0] = (p2 + 2*p1 + 2*p0 + 2*q0 + q1 + 4) >> 3;
+                p[1] = (p2 + p1 + p0 + q0 + 2) >> 2;
+                p[2] = (2*p[3] + 3*p2 + p1 + p0 + q0 + 4) >> 3;
+            } else p[0] = (2*p1 + p0 + q1 + 2) >> 2;
             if (abs(q2 - q0) < beta) {
-                int q3 = q[3*xs];
-                q[0]    = (uint8_t)((p1 + 2*p0 + 2*q0 + 2*q1 + q2 + 4) >> 3);
-                q[xs]   = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
-                q[2*xs] = (uint8_t)((2*q3 + 3*q2 + q1 + q0 + p0 + 4) >> 3);
-            } else q[0] = (uint8_t)((2*q1 + q0 + p1 + 2) >> 2);
+                q[0] = (p1 + 2*p0 + 2*q0 + 2*q1 + q2 + 4) >> 3;
+                q[1] = (p0 + q0 + q1 + q2 + 2) >> 2;
+                q[2] = (2*q[3] + 3*q2 + q1 + q0 + p0 + 4) >> 3;
+            } else q[0] = (2*q1 + q0 + p1 + 2) >> 2;
         } else {
-            q[-xs] = (uint8_t)((2*p1 + p0 + q1 + 2) >> 2);
-            q[0]   = (uint8_t)((2*q1 + q0 + p1 + 2) >> 2);
+            p[0] = (2*p1 + p0 + q1 + 2) >> 2;
+            q[0] = (2*q1 + q0 + p1 + 2) >> 2;
         }
     }
 }
-
-__device__ __forceinline__ void filter_line_chroma(uint8_t *q, int xs, int bS, int alpha, int beta, int tc)
+__device__ __forceinline__ void filter_chroma(int &p0, int p1, int &q0, int q1, int bS, int alpha, int beta, int tc)
 {
-    int p1 = q[-2*xs], p0 = q[-xs], q0 = q[0], q1 = q[xs];
     if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
     if (bS < 4) {
         int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-        q[-xs] = (uint8_t)clip255(p0 + delta);
-        q[0]   = (uint8_t)clip255(q0 - delta);
+        int np = clip255(p0 + delta), nq = clip255(q0 - delta);
+        p0 = np; q0 = nq;
     } else {
-        q[-xs] = (uint8_t)((2*p1 + p0 + q1 + 2) >> 2);
-        q[0]   = (uint8_t)((2*q1 + q0 + p1 + 2) >> 2);
+        int np = (2*p1 + p0 + q1 + 2) >> 2, nq = (2*q1 + q0 + p1 + 2) >> 2;
+        p0 = np; q0 = nq;
     }
 }
 
-// the eight edges of one macroblock in reference order; lanes 0-15 luma lines, 16-23 Cb, 24-31 Cr.
-// e0..e11 = the macroblock's EdgeInfo as 12 wave-uniform dwords.
-__device__ __forceinline__ void filter_mb(uint32_t *ty, uint32_t *tcb, uint32_t *tcr, const uint32_t (&e)[12], int lane)
-{
-    const uint8_t *eb = nullptr; (void)eb;
-    auto ab = [&](int k, int j) { int idx = 16 + k * 2 + j; return (int)((e[idx >> 2] >> (8 * (idx & 3))) & 255); };
-    auto tcv = [&](int k, int b) { int idx = 28 + k * 3 + b; return (int)((e[idx >> 2] >> (8 * (idx & 3))) & 255); };
-    const bool chroma = lane >= 16;
-    const int line = chroma ? lane & 7 : lane;
-    const int seg = chroma ? line >> 1 : line >> 2;
-    uint8_t *yb = (uint8_t *)ty, *cb = (uint8_t *)((lane >> 3) & 1 ? tcr : tcb);
-#pragma unroll
-    for (int dir = 0; dir < 2; dir++) {
-#pragma unroll
-        for (int ed = 0; ed < 4; ed++) {
-            const uint32_t nib = (e[dir * 2 + (ed >> 1)] >> ((ed & 1) * 16)) & 0xffffu;   // 4 segments of this edge (wave-uniform)
-            if (nib != 0 && lane < 32 && !(chroma && (ed & 1))) {
-                const int b = (nib >> (4 * seg)) & 15;
-                const int first = nib & 15;                                            // deblock_edge keys the filter type on bS[0] (:480)
-                const int k = (ed == 0 ? (dir == 0 ? EC_LEFT : EC_TOP) : EC_INNER) + (chroma ? 3 : 0);
-                const int alpha = ab(k, 0), beta = ab(k, 1);
-                if (!chroma) {
-                    uint8_t *q = dir == 0 ? yb + (line + 4) * DY_STRIDE + 4 + 4 * ed : yb + (4 + 4 * ed) * DY_STRIDE + 4 + line;
-                    if (first < 4) { if (b) filter_line_luma(q, dir == 0 ? 1 : DY_STRIDE, b, alpha, beta, tcv(k, b - 1)); }
-                    else filter_line_luma(q, dir == 0 ? 1 : DY_STRIDE, 4, alpha, beta, 0);
-                } else {
-                    uint8_t *q = dir == 0 ? cb + (line + 2) * DC_STRIDE + 4 + 2 * ed : cb + (2 + 2 * ed) * DC_STRIDE + 4 + line;
-                    if (first < 4) { if (b) filter_line_chroma(q, dir == 0 ? 1 : DC_STRIDE, b, alpha, beta, tcv(k, b - 1)); }
-                    else filter_line_chroma(q, dir == 0 ? 1 : DC_STRIDE, 4, alpha, beta, 0);
-                }
-            }
-            wave_lds_fence();
-        }
+// wave-uniform accessors into the 12 dwords of an EdgeInfo
+struct EdgeRegs {
+    uint32_t e[12];
+    __device__ __forceinline__ uint32_t nib(int dir, int ed) const { return (e[dir * 2 + (ed >> 1)] >> ((ed & 1) * 16)) & 0xffffu; }
+    __device__ __forceinline__ int ab(int k, int j) const { int i = 16 + k * 2 + j; return (int)((e[i >> 2] >> (8 * (i & 3))) & 255); }
+    // k is a compile-time constant at every call site; only b (0..2) varies per lane, so the three bytes are
+    // gathered with static indices and b selects by shift (a dynamic e[] index would push the array to memory)
+    __device__ __forceinline__ int byte_at(int i) const { return (int)((e[i >> 2] >> (8 * (i & 3))) & 255); }
+    __device__ __forceinline__ int tc(int k, int b) const
+    {
+        uint32_t three = (uint32_t)byte_at(28 + k * 3) | ((uint32_t)byte_at(29 + k * 3) << 8) | ((uint32_t)byte_at(30 + k * 3) << 16);
+        return (int)((three >> (8 * b)) & 255);
     }
-}
+    __device__ __forceinline__ bool any() const { return (e[11] >> 16) & 255; }
+};
+__device__ __forceinline__ int edge_class(int dir, int ed) { return ed == 0 ? (dir == 0 ? EC_LEFT : EC_TOP) : EC_INNER; }
 
 // ------------------------------------------------------------------------------------------
 // K4b
 // ------------------------------------------------------------------------------------------
-// Lane -> dword maps of the per-macroblock pixel traffic.  "own": the MB's 16x16 luma (64 dwords);
-// "aux": 16 dwords of the 4 luma rows above, 32 dwords of the two 8x8 chroma blocks, 8 dwords of the
-// 2 chroma rows above each.
-struct AuxMap { int plane, row, dwcol; bool luma, valid; };      // row / dwcol relative to the MB (dwcol in dwords, 0 = col 0)
-__device__ __forceinline__ AuxMap aux_map(int lane)
-{
-    AuxMap a; a.valid = lane < 56; a.luma = lane < 16; a.plane = 0;
-    if (lane < 16) { a.row = (lane >> 2) - 4; a.dwcol = lane & 3; }
-    else if (lane < 48) { int l = lane - 16; a.plane = l >> 4; a.row = (l >> 1) & 7; a.dwcol = l & 1; }
-    else { int l = lane - 48; a.plane = l >> 2; a.row = ((l >> 1) & 1) - 2; a.dwcol = l & 1; }
-    return a;
-}
-
+// Lane roles inside a wavefront (one macroblock at a time):
+//   0..15   luma row `lane`:        v[0] = cols -4..-1 (carried over from the previous MB), v[1..4] = cols 0..15
+//   16..31  chroma plane (lane>>3)&1, row lane&7:  v[0] = cols -4..-1, v[1..2] = cols 0..7
+//   32..35  luma row lane-36 (-4..-1) of the MB above: v[1..4]
+//   36..39  chroma plane (lane>>1)&1, row (lane&1)-2 of the MB above: v[1..2]
+// Vertical edges are filtered in these registers (an edge sits on a dword boundary); horizontal
+// edges need columns, so the tile takes one trip through LDS: rows in, columns out, columns in,
+// rows out.  The right-hand dword of every row stays in its lane for the next macroblock.
 __global__ __launch_bounds__(ROW_WAVES * 64)
 void k_deblock(const PicDev *__restrict__ pics, Geom g, const EdgeInfo *__restrict__ info, int *status)
 {
     __shared__ RowSync sync;
-    __shared__ DeblockLds lds[ROW_WAVES];
+    __shared__ uint32_t tiles[ROW_WAVES][20 * DY_DW + 2 * 10 * DC_DW];
     const PicDev *pd = pics + blockIdx.x;
     if (!pd->deblock) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     rows_init(sync, g.mb_h);
-    DeblockLds &L = lds[wave];
+    uint32_t *ty = tiles[wave];
     uint8_t *Y = pd->dst, *U = pd->dst + g.off_u, *V = pd->dst + g.off_v;
     const EdgeInfo *pinfo = info + (size_t)blockIdx.x * g.n_mb;
-    const AuxMap am = aux_map(lane);
+    const bool isY = lane < 16, isC = lane >= 16 && lane < 32, isTY = lane >= 32 && lane < 36, isTC = lane >= 36 && lane < 40;
+    const int cpl = isC ? (lane >> 3) & 1 : (lane >> 1) & 1;          // chroma plane of this lane (C and TC roles)
+    uint32_t *tc_ = ty + 20 * DY_DW + cpl * 10 * DC_DW;                 // this lane's chroma tile
     bool ok = true;
 
     for (int row = wave; row < g.mb_h; row += ROW_WAVES) {
-        const bool fT = row > 0;                    // rows above exist (their filtering is what we wait for)
+        const bool fT = row > 0;
         const int Y0 = row * 16;
-        uint32_t pre_own = 0, pre_aux = 0;          // prefetched pixels of the next macroblock
-        uint32_t ei[12];                            // edge info of macroblock (chunk base + lane)
+        // address of this lane's row segment for macroblock 0 (advances by 16 / 8 bytes per macroblock)
+        const uint8_t *src = Y;
+        if (isY) src = Y + (size_t)(Y0 + lane) * g.w;
+        else if (isC) src = (cpl ? V : U) + (size_t)(Y0 / 2 + (lane & 7)) * g.cw;
+        else if (isTY) src = Y + (size_t)(Y0 + lane - 36) * g.w;
+        else if (isTC) src = (cpl ? V : U) + (size_t)(Y0 / 2 + (lane & 1) - 2) * g.cw;
+        const bool wide = isY || (isTY && fT), narrow = isC || (isTC && fT);
+        uint4 pre4 = make_uint4(0, 0, 0, 0); uint2 pre2 = make_uint2(0, 0);
+        uint32_t v[5] = { 0, 0, 0, 0, 0 };
+        uint32_t ei[12];
 
-        // prefetch of macroblock x (pixels only; row-above dependency first)
         auto prefetch = [&](int x) {
-            if (fT && ok) ok = row_wait(sync, row - 1, min(x + 2, g.mb_w), status);
-            const int X0 = x * 16;
-            pre_own = *(const uint32_t *)(Y + (size_t)(Y0 + (lane >> 2)) * g.w + X0 + (lane & 3) * 4);
-            pre_aux = 0;
-            if (am.valid && (am.row >= 0 || fT)) {
-                if (am.luma) pre_aux = *(const uint32_t *)(Y + (size_t)(Y0 + am.row) * g.w + X0 + am.dwcol * 4);
-                else pre_aux = *(const uint32_t *)((am.plane ? V : U) + (size_t)(Y0 / 2 + am.row) * g.cw + X0 / 2 + am.dwcol * 4);
-            }
-        };
-        // land the prefetched registers in tile t
-        auto land = [&](int t) {
-            L.y[t][((lane >> 2) + 4) * DY_DW + 1 + (lane & 3)] = pre_own;
-            if (am.valid) {
-                if (am.luma) L.y[t][(am.row + 4) * DY_DW + 1 + am.dwcol] = pre_aux;
-                else L.c[t][am.plane][(am.row + 2) * DC_DW + 1 + am.dwcol] = pre_aux;
-            }
+            if (fT && ok && !EXPD_NOWAIT) ok = row_wait(sync, row - 1, min(x + 2, g.mb_w), status);
+            if (EXPD_NOLOAD) return;
+            if (wide) pre4 = *(const uint4 *)(src + x * 16);
+            if (narrow) pre2 = *(const uint2 *)(src + x * 8);
         };
 
         prefetch(0);
-        int cur = 0;
         for (int x = 0; x < g.mb_w; x++) {
             if ((x & 63) == 0) {                    // edge info of the next 64 macroblocks: 3 x 16 bytes per lane
                 int xi = min(x + lane, g.mb_w - 1);
-                const uint4 *src = (const uint4 *)(pinfo + row * g.mb_w + xi);
-                uint4 a = src[0], b = src[1], c = src[2];
+                const uint4 *s4 = (const uint4 *)(pinfo + row * g.mb_w + xi);
+                uint4 a = s4[0], b = s4[1], c = s4[2];
                 ei[0] = a.x; ei[1] = a.y; ei[2] = a.z; ei[3] = a.w; ei[4] = b.x; ei[5] = b.y; ei[6] = b.z; ei[7] = b.w;
                 ei[8] = c.x; ei[9] = c.y; ei[10] = c.z; ei[11] = c.w;
             }
-            if (x == 0) { land(cur); wave_lds_fence(); }
-            // (1) pixels of the next macroblock start their trip now
-            if (x + 1 < g.mb_w) prefetch(x + 1);
-            // (2) filter macroblock x in tile `cur`
-            uint32_t e[12];
+            // the prefetched pixels of macroblock x move into place (v[0] holds the carried-over columns)
+            if (isY || isTY) { v[1] = pre4.x; v[2] = pre4.y; v[3] = pre4.z; v[4] = pre4.w; }
+            else { v[1] = pre2.x; v[2] = pre2.y; }
+            if (x + 1 < g.mb_w) prefetch(x + 1);    // pixels of the next macroblock start their trip now
+            EdgeRegs E;
 #pragma unroll
-            for (int k = 0; k < 12; k++) e[k] = (uint32_t)__builtin_amdgcn_readlane((int)ei[k], x & 63);
-            if ((e[11] >> 16) & 255) filter_mb(L.y[cur], L.c[cur][0], L.c[cur][1], e, lane);
-            // (3) everything issued before this point has completed: the stores of macroblock x-1 and the
-            //     prefetch of x+1.  Publish x-1 (release = s_waitcnt vmcnt(0) + the LDS store).
+            for (int k = 0; k < 12; k++) E.e[k] = (uint32_t)__builtin_amdgcn_readlane((int)ei[k], x & 63);
+
+            if (E.any() && !EXPD_NOFILTER) {
+                // ---------- vertical edges, in registers ----------
+                if (E.e[0] | E.e[1]) {
+                    if (isY) {
+                        const int seg = lane >> 2;
+#pragma unroll
+                        for (int ed = 0; ed < 4; ed++) {
+                            const uint32_t nib = E.nib(0, ed);
+                            if (nib == 0) continue;
+                            const int b = (nib >> (4 * seg)) & 15, first = nib & 15, k = edge_class(0, ed);
+                            if (first >= 4 || b) {
+                                int p[4] = { (int)(v[ed] >> 24), (int)((v[ed] >> 16) & 255), (int)((v[ed] >> 8) & 255), (int)(v[ed] & 255) };
+                                int q[4] = { (int)(v[ed+1] & 255), (int)((v[ed+1] >> 8) & 255), (int)((v[ed+1] >> 16) & 255), (int)(v[ed+1] >> 24) };
+                                filter_luma(p, q, first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
+                                v[ed] = (uint32_t)p[3] | ((uint32_t)p[2] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[0] << 24);
+                                v[ed+1] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                            }
+                        }
+                    } else if (isC) {
+                        const int seg = (lane & 7) >> 1;
+#pragma unroll
+                        for (int ed = 0; ed < 4; ed += 2) {
+                            const uint32_t nib = E.nib(0, ed);
+                            if (nib == 0) continue;
+                            const int b = (nib >> (4 * seg)) & 15, first = nib & 15, k = edge_class(0, ed) + 3;
+                            if (first >= 4 || b) {
+                                const int j = ed >> 1;
+                                int p1 = (int)((v[j] >> 16) & 255), p0 = (int)(v[j] >> 24), q0 = (int)(v[j+1] & 255), q1 = (int)((v[j+1] >> 8) & 255);
+                                filter_chroma(p0, p1, q0, q1, first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
+                                v[j] = (v[j] & 0x00ffffffu) | ((uint32_t)p0 << 24);
+                                v[j+1] = (v[j+1] & 0xffffff00u) | (uint32_t)q0;
+                            }
+                        }
+                    }
+                }
+                // ---------- horizontal edges: rows -> LDS -> columns ----------
+                if (E.e[2] | E.e[3]) {
+                    if (isY) { uint32_t *r = ty + (lane + 4) * DY_DW; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; r[4] = v[4]; }
+                    else if (isC) { uint32_t *r = tc_ + ((lane & 7) + 2) * DC_DW; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; }
+                    else if (isTY) { uint32_t *r = ty + (lane - 32) * DY_DW; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; r[4] = v[4]; }
+                    else if (isTC) { uint32_t *r = tc_ + (lane & 1) * DC_DW; r[1] = v[1]; r[2] = v[2]; }
+                    wave_lds_fence();
+                    if (isY) {
+                        uint8_t *colp = (uint8_t *)ty + 4 + lane;       // column `lane`, row r at colp[(r+4)*DY_STRIDE]
+                        int c[20];
+#pragma unroll
+                        for (int r = 0; r < 20; r++) c[r] = colp[r * DY_STRIDE];
+                        const int seg = lane >> 2;
+#pragma unroll
+                        for (int ed = 0; ed < 4; ed++) {
+                            const uint32_t nib = E.nib(1, ed);
+                            if (nib == 0) continue;
+                            const int b = (nib >> (4 * seg)) & 15, first = nib & 15, k = edge_class(1, ed);
+                            if (first >= 4 || b) {
+                                int p[4] = { c[4*ed+3], c[4*ed+2], c[4*ed+1], c[4*ed] }, q[4] = { c[4*ed+4], c[4*ed+5], c[4*ed+6], c[4*ed+7] };
+                                filter_luma(p, q, first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
+                                c[4*ed+3] = p[0]; c[4*ed+2] = p[1]; c[4*ed+1] = p[2]; c[4*ed+4] = q[0]; c[4*ed+5] = q[1]; c[4*ed+6] = q[2];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 1; r < 19; r++) colp[r * DY_STRIDE] = (uint8_t)c[r];
+                    } else if (isC) {
+                        uint8_t *colp = (uint8_t *)tc_ + 4 + (lane & 7);
+                        int c[10];
+#pragma unroll
+                        for (int r = 0; r < 10; r++) c[r] = colp[r * DC_STRIDE];
+                        const int seg = (lane & 7) >> 1;
+#pragma unroll
+                        for (int ed = 0; ed < 4; ed += 2) {
+                            const uint32_t nib = E.nib(1, ed);
+                            if (nib == 0) continue;
+                            const int b = (nib >> (4 * seg)) & 15, first = nib & 15, k = edge_class(1, ed) + 3;
+                            if (first >= 4 || b)
+                                filter_chroma(c[2*ed+1], c[2*ed], c[2*ed+2], c[2*ed+3], first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
+                        }
+#pragma unroll
+                        for (int r = 1; r < 9; r++) colp[r * DC_STRIDE] = (uint8_t)c[r];
+                    }
+                    wave_lds_fence();
+                    if (isY) { const uint32_t *r = ty + (lane + 4) * DY_DW; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; v[4] = r[4]; }
+                    else if (isC) { const uint32_t *r = tc_ + ((lane & 7) + 2) * DC_DW; v[1] = r[1]; v[2] = r[2]; }
+                    else if (isTY) { const uint32_t *r = ty + (lane - 32) * DY_DW; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; v[4] = r[4]; }
+                    else if (isTC) { const uint32_t *r = tc_ + (lane & 1) * DC_DW; v[1] = r[1]; v[2] = r[2]; }
+                    wave_lds_fence();
+                }
+            }
+            // everything issued before this point has completed at the release below: the stores of macroblock x-1
+            // and the prefetch of x+1.  Publish x-1.
             row_publish(sync, row, x);
-            // (4) hand the right-hand columns over to the next tile, land the prefetch next to them
-            const int nxt = cur ^ 1;
-            if (x + 1 < g.mb_w) {
-                land(nxt);
-                if (lane < 16) L.y[nxt][(lane + 4) * DY_DW] = L.y[cur][(lane + 4) * DY_DW + 4];
-                else if (lane < 32) { int p = (lane >> 3) & 1, r = lane & 7; L.c[nxt][p][(r + 2) * DC_DW] = L.c[cur][p][(r + 2) * DC_DW + 2]; }
-            }
-            // (5) write macroblock x back: columns -4..11 (and 12..15 for the last MB of the row), rows above included
-            {
-                const int X0 = x * 16;
+            // write macroblock x back: columns -4..11 now, 12..15 (chroma 4..7) with the next macroblock
+            if (!EXPD_NOSTORE) {
                 const bool last = x + 1 == g.mb_w;
-                const int r = lane >> 2, d = lane & 3;                          // luma rows 0..15, tile dwords 0..3
-                if (d > 0 || x > 0) *(uint32_t *)(Y + (size_t)(Y0 + r) * g.w + X0 - 4 + d * 4) = L.y[cur][(r + 4) * DY_DW + d];
-                if (am.valid && (am.row >= 0 || fT)) {
-                    if (am.luma) *(uint32_t *)(Y + (size_t)(Y0 + am.row) * g.w + X0 + am.dwcol * 4) = L.y[cur][(am.row + 4) * DY_DW + 1 + am.dwcol];
-                    else if (am.row < 0) *(uint32_t *)((am.plane ? V : U) + (size_t)(Y0 / 2 + am.row) * g.cw + X0 / 2 + am.dwcol * 4) = L.c[cur][am.plane][(am.row + 2) * DC_DW + 1 + am.dwcol];
-                    else if (am.dwcol > 0 || x > 0)                             // chroma rows 0..7: tile dwords 0..1 = cols -4..3
-                        *(uint32_t *)((am.plane ? V : U) + (size_t)(Y0 / 2 + am.row) * g.cw + X0 / 2 - 4 + am.dwcol * 4) = L.c[cur][am.plane][(am.row + 2) * DC_DW + am.dwcol];
-                }
-                if (last) {
-                    if (lane < 16) *(uint32_t *)(Y + (size_t)(Y0 + lane) * g.w + X0 + 12) = L.y[cur][(lane + 4) * DY_DW + 4];
-                    else if (lane < 32) { int p = (lane >> 3) & 1, rr = lane & 7; *(uint32_t *)((p ? V : U) + (size_t)(Y0 / 2 + rr) * g.cw + X0 / 2 + 4) = L.c[cur][p][(rr + 2) * DC_DW + 2]; }
-                }
+                uint8_t *dst = (uint8_t *)src;
+                if (isY) {                                   // naturally aligned pieces only
+                    if (x > 0) *(uint32_t *)(dst + x * 16 - 4) = v[0];
+                    *(uint2 *)(dst + x * 16) = make_uint2(v[1], v[2]);
+                    *(uint32_t *)(dst + x * 16 + 8) = v[3];
+                    if (last) *(uint32_t *)(dst + x * 16 + 12) = v[4];
+                } else if (isC) {
+                    if (x > 0) *(uint32_t *)(dst + x * 8 - 4) = v[0];
+                    *(uint32_t *)(dst + x * 8) = v[1];
+                    if (last) *(uint32_t *)(dst + x * 8 + 4) = v[2];
+                } else if (isTY && fT) *(uint4 *)(dst + x * 16) = make_uint4(v[1], v[2], v[3], v[4]);
+                else if (isTC && fT) *(uint2 *)(dst + x * 8) = make_uint2(v[1], v[2]);
             }
-            wave_lds_fence();
-            cur = nxt;
+            // the right-hand columns become the left-hand columns of the next macroblock
+            if (isY) v[0] = v[4]; else if (isC) v[0] = v[2];
         }
         row_publish(sync, row, g.mb_w);             // waits for the last stores of the row
     }

@@ -282,7 +282,14 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                 todo &= todo - 1;
                 int mbx = base + bit, mbi = row * g.mb_w + mbx;
                 row_publish(sync, row, mbx);                                      // everything left of mbx is final
-                if (row > 0 && ok) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
+                // Only intra neighbours in the row above can still be in flight (inter MBs were finished by
+                // k_inter), so the wavefront dependency only bites where intra macroblocks touch.
+                if (row > 0 && ok) {
+                    const p264hip_mb_t *up = pd->mb + mbi - g.mb_w;
+                    bool dep = P264_MB_IS_INTRA(up[0].mb_type) || (mbx > 0 && P264_MB_IS_INTRA(up[-1].mb_type)) ||
+                               (mbx + 1 < g.mb_w && P264_MB_IS_INTRA(up[1].mb_type));
+                    if (dep) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
+                }
                 intra_mb(pd, g, lds[wave], mbi, pd->mb[mbi], lane);
             }
         }

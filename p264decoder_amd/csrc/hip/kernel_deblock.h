@@ -198,7 +198,10 @@ __device__ __forceinline__ int edge_class(int dir, int ed) { return ed == 0 ? (d
 // Vertical edges are filtered in these registers (an edge sits on a dword boundary); horizontal
 // edges need columns, so the tile takes one trip through LDS: rows in, columns out, columns in,
 // rows out.  The right-hand dword of every row stays in its lane for the next macroblock.
-__global__ __launch_bounds__(ROW_WAVES * 64)
+#ifndef DEBLOCK_WAVES_PER_EU
+#define DEBLOCK_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(ROW_WAVES * 64, DEBLOCK_WAVES_PER_EU)
 void k_deblock(const PicDev *__restrict__ pics, Geom g, const EdgeInfo *__restrict__ info, int *status)
 {
     __shared__ RowSync sync;

@@ -28,6 +28,15 @@
 #ifndef EXP_NOCOMPUTE
 #define EXP_NOCOMPUTE 0
 #endif
+#ifndef EXP_NT
+#define EXP_NT 0
+#endif
+#if EXP_NT
+typedef const __attribute__((address_space(1))) uint32_t *gu32p;
+#define WLOAD(p) __builtin_nontemporal_load((gu32p)(const uint32_t *)(p))
+#else
+#define WLOAD(p) (*(const uint32_t *)(p))
+#endif
 #ifndef EXP_NORESID
 #define EXP_NORESID 0
 #endif
@@ -318,13 +327,13 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
             yv[k] = 0;
             if (i < 126 && !EXP_NOLOAD) {
                 int yy = clip3i(Y0 + (ly >> 2) - 2 + r, 0, g.h - 1);
-                yv[k] = *(const uint32_t *)(rf + (size_t)yy * g.w + (ux0 & ~3) + d * 4);
+                yv[k] = WLOAD(rf + (size_t)yy * g.w + (ux0 & ~3) + d * 4);
             }
         }
         if (lane < 54 && !EXP_NOLOAD) {
             int p = lane >= 27, l2 = lane - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
             int yy = clip3i(Y0 / 2 + (ly >> 3) + r, 0, g.ch - 1);
-            cvv = *(const uint32_t *)(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (ucx0 & ~3) + d * 4);
+            cvv = WLOAD(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (ucx0 & ~3) + d * 4);
         }
         uint32_t *yw = &L.ywin[0][0], *cw = &L.cwin[0][0][0];
         yw[lane] = yv[0];
@@ -364,7 +373,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
                 if (((fast >> q) & 1) && lane < 52) {
                     int wx0 = X0 + (q & 1) * 8 + (mv_x(qmv[q]) >> 2) - 2;
                     int yy = clip3i(Y0 + (q >> 1) * 8 + (mv_y(qmv[q]) >> 2) - 2 + r, 0, g.h - 1);
-                    yv[q] = *(const uint32_t *)(qref[q] + (size_t)yy * g.w + (wx0 & ~3) + d * 4);
+                    yv[q] = WLOAD(qref[q] + (size_t)yy * g.w + (wx0 & ~3) + d * 4);
                 }
             }
             const int q4 = lane >> 4, rr = lane & 15, cr = rr >> 1, cd = rr & 1;   // chroma: one instruction per plane, 16 lanes per quadrant
@@ -376,7 +385,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 cv[p] = 0;
-                if (cok) cv[p] = *(const uint32_t *)(crf + (p ? g.off_v : g.off_u) + (size_t)cyy * g.cw + (cx0 & ~3) + cd * 4);
+                if (cok) cv[p] = WLOAD(crf + (p ? g.off_v : g.off_u) + (size_t)cyy * g.cw + (cx0 & ~3) + cd * 4);
             }
         }
         if (lane < 52) {

@@ -8,23 +8,17 @@
 //                      strengths of a macroblock (core/frame.c:535-581) and, per edge class
 //                      {left, top, inner} x {luma, chroma}, alpha / beta / tc0[bS] from the averaged
 //                      QPs (core/frame.c:472-488,593-601).  Fully parallel, one launch per batch,
-//                      48 bytes of "edge info" per macroblock.
+//                      64 bytes of "edge info" per macroblock.
 // K4b k_deblock      - the sample filters.  The filter is defined in macroblock raster order
 //                      (left edge, inner vertical edges, top edge, inner horizontal edges of one MB
 //                      before the next MB) and the result depends on that order: MB (x,y) must see
 //                      (x-1,y) and (x+1,y-1) completely filtered ("all vertical, then all
 //                      horizontal edges" is NOT bit-exact).  So this is a row wavefront
-//                      (wavefront_sync.h): one workgroup per picture, one wavefront per MB row.
+//                      (wavefront_sync.h).
 //
-// v2 of K4b is software-pipelined along the row so that no global round trip sits on the
-// macroblock-to-macroblock critical path:
-//   * edge info of 64 macroblocks is fetched with one coalesced load per lane;
-//   * while MB x is filtered in LDS tile A, the pixels of MB x+1 are already in flight
-//     (own 16x16 + 2 x 8x8 and the 4 / 2 rows above it) and land in tile B;
-//   * the 4 (2) rightmost columns of MB x stay in LDS and become the left neighbourhood of
-//     MB x+1, and are written back with it - every sample is read once and written once;
-//   * progress is published one macroblock late, at the point where the wavefront waits for
-//     its prefetch anyway, so the stores of MB x-1 have long completed.
+// K4b is issue-bound, not bandwidth-bound (profiles/): the design below is about instructions per
+// macroblock.  Eight lanes own one macroblock, every lane filters TWO lines at a time in packed
+// 16-bit arithmetic without branches, and a wavefront walks eight macroblock rows as a diagonal.
 #pragma once
 #include "device_common.h"
 #ifndef EXPD_NOFILTER
@@ -177,264 +171,355 @@ __device__ __forceinline__ void filter_chroma(int &p0, int p1, int &q0, int q1, 
     }
 }
 
-// the 16 dwords of a macroblock's EdgeInfo, held per lane (all 16 lanes of a row group hold the same values)
+// A macroblock's EdgeInfo as its eight lanes see it: the four boundary-strength words in registers, the class
+// parameters fetched from the octet's LDS copy where an edge needs them.
 struct EdgeRegs {
-    uint32_t e[EDGE_DW];
+    uint32_t e[4];
+    const uint32_t *lds;            // the octet's copy of the 16 dwords
     __device__ __forceinline__ uint32_t nib(int dir, int ed) const { return (e[dir * 2 + (ed >> 1)] >> ((ed & 1) * 16)) & 0xffffu; }
-    // class k occupies dwords 4+2k (alpha, beta, tc[0], tc[1]) and 5+2k (tc[2], any); k is a compile-time constant
-    __device__ __forceinline__ int ab(int k, int j) const { return (int)((e[4 + 2 * k] >> (8 * j)) & 255); }
-    __device__ __forceinline__ int tc(int k, int b) const
-    {
-        uint32_t three = (e[4 + 2 * k] >> 16) | (e[5 + 2 * k] << 16);          // tc[0], tc[1], tc[2]; b (0..2) varies per lane
-        return (int)((three >> (8 * b)) & 255);
-    }
+};
+// class k occupies dwords 4+2k (alpha, beta, tc[0], tc[1]) and 5+2k (tc[2], any); k is a compile-time constant
+struct EdgeParams {
+    uint32_t lo, hi;
+    __device__ __forceinline__ EdgeParams(const EdgeRegs &E, int k) { uint2 v = *(const uint2 *)(E.lds + 4 + 2 * k); lo = v.x; hi = v.y; }
+    __device__ __forceinline__ int alpha() const { return (int)(lo & 255); }
+    __device__ __forceinline__ int beta() const { return (int)((lo >> 8) & 255); }
+    __device__ __forceinline__ int tc(int b) const { return (int)((((lo >> 16) | (hi << 16)) >> (8 * b)) & 255); }   // b = bS-1 in 0..2, per lane
 };
 __device__ __forceinline__ int edge_class(int dir, int ed) { return ed == 0 ? (dir == 0 ? EC_LEFT : EC_TOP) : EC_INNER; }
 
 // ------------------------------------------------------------------------------------------
+// sample filters on two lines at once: every value is a pair of 16-bit lanes (v_pk_*_i16)
+// ------------------------------------------------------------------------------------------
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t as_u(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pk_splat(int v) { return as_pk((uint32_t)v | ((uint32_t)v << 16)); }    // 0 <= v < 65536
+__device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ pk16 pk_clamp(pk16 v, pk16 lo, pk16 hi) { return pk_min(pk_max(v, lo), hi); }
+__device__ __forceinline__ pk16 pk_absd(pk16 a, pk16 b) { pk16 d = a - b; return pk_max(d, -d); }
+__device__ __forceinline__ pk16 pk_lt(pk16 a, pk16 b) { return (a - b) >> (pk16)15; }                  // a < b ? 0xffff : 0
+__device__ __forceinline__ pk16 pk_sel(pk16 m, pk16 a, pk16 b) { return (a & m) | (b & ~m); }            // v_bfi_b32
+
+// the three "filterSamplesFlag" conditions, core/frame.c:311,357,398,444
+__device__ __forceinline__ pk16 pk_edge_flag(pk16 p1, pk16 p0, pk16 q0, pk16 q1, pk16 A, pk16 B)
+{
+    return pk_lt(pk_absd(p0, q0), A) & pk_lt(pk_absd(p1, p0), B) & pk_lt(pk_absd(q1, q0), B);
+}
+
+// bS 1..3 on a luma edge (core/frame.c:302-341).  en = all ones in the lanes whose bS is 1..3.
+__device__ __forceinline__ void pk_luma_normal(pk16 p2, pk16 &p1, pk16 &p0, pk16 &q0, pk16 &q1, pk16 q2,
+                                               pk16 f, pk16 ap, pk16 aq, pk16 T0)
+{
+    const pk16 avg = (p0 + q0 + (pk16)1) >> (pk16)1;
+    const pk16 dp = pk_clamp(((p2 + avg) >> (pk16)1) - p1, -T0, T0) & (f & ap);
+    const pk16 dq = pk_clamp(((q2 + avg) >> (pk16)1) - q1, -T0, T0) & (f & aq);
+    const pk16 tc = T0 - ap - aq;                                   // the masks are -1 where true
+    const pk16 delta = pk_clamp((((q0 - p0) << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -tc, tc) & f;
+    p1 += dp; q1 += dq;
+    p0 = pk_clamp(p0 + delta, (pk16)0, (pk16)255);
+    q0 = pk_clamp(q0 - delta, (pk16)0, (pk16)255);
+}
+// bS 4 on a luma edge (core/frame.c:387-432); s = f & str in the lanes that take it
+__device__ __forceinline__ void pk_luma_strong(pk16 p3, pk16 &p2, pk16 &p1, pk16 &p0, pk16 &q0, pk16 &q1, pk16 &q2, pk16 q3,
+                                               pk16 s, pk16 ap, pk16 aq, pk16 A)
+{
+    const pk16 small = pk_lt(pk_absd(p0, q0), (A >> (pk16)2) + (pk16)2);
+    const pk16 sp = small & ap, sq = small & aq;
+    const pk16 pq = p0 + q0;
+    const pk16 p0w = (p1 + p1 + p0 + q1 + (pk16)2) >> (pk16)2, q0w = (q1 + q1 + q0 + p1 + (pk16)2) >> (pk16)2;
+    const pk16 p0s = (p2 + p1 + p1 + pq + pq + q1 + (pk16)4) >> (pk16)3, q0s = (p1 + pq + pq + q1 + q1 + q2 + (pk16)4) >> (pk16)3;
+    const pk16 p1s = (p2 + p1 + pq + (pk16)2) >> (pk16)2, q1s = (pq + q1 + q2 + (pk16)2) >> (pk16)2;
+    const pk16 p2s = (p3 + p3 + p2 + p2 + p2 + p1 + pq + (pk16)4) >> (pk16)3, q2s = (q3 + q3 + q2 + q2 + q2 + q1 + pq + (pk16)4) >> (pk16)3;
+    p0 = pk_sel(s, pk_sel(sp, p0s, p0w), p0); q0 = pk_sel(s, pk_sel(sq, q0s, q0w), q0);
+    p1 = pk_sel(s & sp, p1s, p1); q1 = pk_sel(s & sq, q1s, q1);
+    p2 = pk_sel(s & sp, p2s, p2); q2 = pk_sel(s & sq, q2s, q2);
+}
+// chroma edge, any bS (core/frame.c:351-377, 438-462); T = tc0+1 (from K4a), en/str = masks of the bS 1..3 / bS 4 lanes
+__device__ __forceinline__ void pk_chroma(pk16 p1, pk16 &p0, pk16 &q0, pk16 q1, pk16 f, pk16 en, pk16 str, pk16 T)
+{
+    const pk16 delta = pk_clamp((((q0 - p0) << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -T, T) & (f & en);
+    const pk16 p0w = (p1 + p1 + p0 + q1 + (pk16)2) >> (pk16)2, q0w = (q1 + q1 + q0 + p1 + (pk16)2) >> (pk16)2;
+    const pk16 s = f & str;
+    p0 = pk_sel(s, p0w, pk_clamp(p0 + delta, (pk16)0, (pk16)255));
+    q0 = pk_sel(s, q0w, pk_clamp(q0 - delta, (pk16)0, (pk16)255));
+}
+
+// byte K of two dwords as a 16-bit pair (a -> low half, b -> high half)
+template <int K> __device__ __forceinline__ pk16 pair_byte(uint32_t a, uint32_t b)
+{
+    return as_pk(__builtin_amdgcn_perm(b, a, 0x0c040c00u + (uint32_t)K * 0x00010001u));
+}
+__device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+
+// ------------------------------------------------------------------------------------------
 // K4b
 // ------------------------------------------------------------------------------------------
-// A wavefront owns a BAND of four macroblock rows and walks them as a diagonal: in iteration t row
-// group g (lanes 16g..16g+15) works on macroblock x = t - 2g, which is exactly the 2-MB lag the
-// raster order demands between neighbouring rows.  All four groups execute the same instructions, so
-// every filter instruction does useful work in all 64 lanes, and rows inside a band hand their bottom
-// samples to the row below through LDS.  Only bands synchronise through the progress counters
-// (wavefront_sync.h), with pixels of the band above travelling through global memory.
+// Lanes: an OCTET of eight lanes owns one macroblock; lane j of the octet holds
+//   * luma rows 2j, 2j+1 as ya[0..4] / yb[0..4] = columns -4..15 (column group 0 is carried over from
+//     the previous macroblock), and
+//   * rows 2(j&3), 2(j&3)+1 of chroma plane j>>2 as ca[0..2] / cb[0..2] = columns -4..7.
+// Vertical edges sit on dword boundaries: the lane unpacks the bytes either side into 16-bit pairs
+// (row 2j in the low half, 2j+1 in the high half - both in the same 4-line bS segment), filters both
+// rows with one stream of v_pk instructions and no branches, and packs them back.  For horizontal edges
+// the rows go to an LDS tile and come back as column pairs (lane j: luma columns 2j, 2j+1 over the 4
+// rows above + 16 rows; chroma columns 2(j&3), +1 of plane j>>2), again two lines per instruction.
 //
-// Per lane, luma view: lane (g,i) holds luma row i of its macroblock as five dwords yl[0..4] = columns
-// -4..15 (yl[0] is carried over from the previous macroblock); chroma view: lane (g, p = i>>3, j = i&7)
-// holds chroma row j of plane p as cl[0..2] = columns -4..7.  Vertical edges sit on dword boundaries and
-// are filtered in these registers.  For horizontal edges the rows go to an LDS tile, every lane picks up
-// one column (20 luma / 10 chroma samples), filters it and puts it back.  The four (two) rows above a
-// macroblock live in a small LDS ring written by the row group above (or loaded from the band above).
+// A wavefront's eight octets are `8 >> rb_log2` pictures x `1 << rb_log2` consecutive macroblock rows
+// (a BAND).  Octet g of a band works on macroblock x = t - 2g in iteration t, which is exactly the lag
+// the raster order demands, and hands the bottom rows of a finished macroblock to the octet below
+// through an LDS ring.  Bands synchronise through progress counters in LDS (wavefront_sync.h); the
+// pixels of the band above travel through global memory (same CU, same L1).
+//
+// Every sample is loaded once and stored once, both as whole 16-byte (8-byte chroma) rows: the store
+// of macroblock x-1 waits one iteration for its last four columns, which the left edge of x changes.
 #define RING_SLOTS   4
 #define RING_DW      24            // per slot: 4 luma rows x 4 dwords, then 2 planes x 2 rows x 2 dwords
-#define TILE_DW      (16 * 4 + 2 * 8 * 2)   // per group: 16 luma rows x 4 dwords, 2 planes x 8 rows x 2 dwords
-struct BandLds {                   // per wavefront
-    uint32_t tile[4][TILE_DW];
-    uint32_t ring[4][RING_SLOTS][RING_DW];
-    uint32_t edge[4][EDGE_DW];
+#define TILE_DW      100           // 16 luma rows x 4 dwords, 2 planes x 8 rows x 2 dwords, +4 so that octets land on different banks
+struct OctLds {                    // per octet: 212 dwords
+    uint32_t tile[TILE_DW];
+    uint32_t ring[RING_SLOTS][RING_DW];
+    uint32_t edge[EDGE_DW];
 };
-#define BAND_ROWS 4
-#define MAX_BANDS ((MAX_MB_ROWS + BAND_ROWS - 1) / BAND_ROWS)
+#define MAX_PICS_PER_WG 4
+#define MAX_BANDS (MAX_MB_ROWS / 2)
 
 __global__ __launch_bounds__(ROW_WAVES * 64)
-void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status)
+void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status, int n_pics, int rb_log2)
 {
-    __shared__ RowSync sync;                  // progress[band]
-    __shared__ BandLds lds[ROW_WAVES];
+    __shared__ int progress[MAX_PICS_PER_WG][MAX_BANDS];     // fully stored macroblocks of a band's last row
+    __shared__ OctLds lds[ROW_WAVES][8];
     const Geom g = g_;
-    const PicDev *pd = pics + blockIdx.x;
-    if (!pd->deblock) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n_bands = (g.mb_h + BAND_ROWS - 1) / BAND_ROWS;
-    rows_init(sync, n_bands);
-    BandLds &L = lds[wave];
+    const int RB = 1 << rb_log2, P = 8 >> rb_log2;
+    const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
+    const int o = lane >> 3, j = lane & 7;
+    const int gr = o & (RB - 1), pi = o >> rb_log2;           // row inside the band, picture inside the workgroup
+    const int n_bands = (g.mb_h + RB - 1) >> rb_log2;
+    for (int k = threadIdx.x; k < MAX_PICS_PER_WG * MAX_BANDS; k += blockDim.x) (&progress[0][0])[k] = 0;
+    __syncthreads();
+    const int pic = blockIdx.x * P + pi;
+    const PicDev *pd = pics + min(pic, n_pics - 1);
+    const bool pic_ok = pic < n_pics && pd->deblock;
+    OctLds &L = lds[wave][o];
     uint8_t *Y = pd->dst, *U = pd->dst + g.off_u, *V = pd->dst + g.off_v;
-    const EdgeInfo *pinfo = info + (size_t)blockIdx.x * g.n_mb;
-    const int grp = lane >> 4, i = lane & 15;                 // row group, line inside the group
-    const int cp = i >> 3, cj = i & 7;                        // chroma plane / row of this lane
-    uint32_t *tY = L.tile[grp], *tC = L.tile[grp] + 64 + cp * 16;
+    const EdgeInfo *pinfo = info + (size_t)min(pic, n_pics - 1) * g.n_mb;
+    const int seg = j >> 1, cseg = j & 3;                     // bS segment of this lane's luma / chroma lines
+    const int cp = j >> 2, cr = (j & 3) * 2;                  // chroma plane, first chroma line of this lane
+    uint8_t *tile8 = (uint8_t *)L.tile;
     bool ok = true;
 
-    for (int band = wave; band < n_bands; band += ROW_WAVES) {
-        const int R0 = band * BAND_ROWS;
-        const int nrows = min(BAND_ROWS, g.mb_h - R0), last = nrows - 1;
-        const int row = R0 + grp;
-        const bool have_row = grp < nrows;
-        const bool below_in_band = grp < last;                 // the row below is handled by the next group of this wave
+    for (int band = wave; band < n_bands; band += n_waves) {
+        const int R0 = band << rb_log2;
+        const int nrows = min(RB, g.mb_h - R0), last = nrows - 1;
+        const int row = R0 + gr;
+        const bool have_row = pic_ok && gr < nrows;
+        const bool below_in_band = gr < last;                  // the row below belongs to the next octet
         const bool top_exists = row > 0;
-        // this lane's luma / chroma row of macroblock 0 of its MB row (clamped for idle groups)
+        const bool from_above = have_row && gr == 0 && band > 0;   // the rows above come from the band above, through memory
         const int rowc = min(row, g.mb_h - 1);
-        uint8_t *srcY = Y + (size_t)(rowc * 16 + i) * g.w;
-        uint8_t *srcC = (cp ? V : U) + (size_t)(rowc * 8 + cj) * g.cw;
-        // group 0's rows above come from the band above: lanes 0..3 luma rows -4..-1, lanes 4..7 chroma (plane, row)
-        uint8_t *srcT = Y;
-        if (lane < 4) srcT = Y + (size_t)(R0 * 16 - 4 + lane) * g.w;
-        else if (lane < 8) srcT = ((lane >> 1) & 1 ? V : U) + (size_t)(R0 * 8 - 2 + (lane & 1)) * g.cw;
-        const bool band_above = R0 > 0;
+        uint8_t *rowYa = Y + (size_t)(rowc * 16 + 2 * j) * g.w, *rowYb = rowYa + g.w;
+        uint8_t *rowCa = (cp ? V : U) + (size_t)(rowc * 8 + cr) * g.cw, *rowCb = rowCa + g.cw;
+        // the rows above: lanes 0..3 luma rows -4..-1, lanes 4..7 chroma (plane, row) = ((j>>1)&1, j&1); valid if top_exists
+        uint8_t *topP = j < 4 ? Y + ((ptrdiff_t)rowc * 16 - 4 + j) * g.w : ((j >> 1) & 1 ? V : U) + ((ptrdiff_t)rowc * 8 - 2 + (j & 1)) * g.cw;
+        int *my_progress = &progress[pi & (MAX_PICS_PER_WG - 1)][band];
+        const bool publisher = have_row && gr == last && j == 0;
+        OctLds &Lnext = lds[wave][min(o + 1, 7)];
 
-        uint32_t yl[5] = { 0, 0, 0, 0, 0 }, cl[3] = { 0, 0, 0 };
-        uint4 pY = make_uint4(0, 0, 0, 0), pT = make_uint4(0, 0, 0, 0), pE = make_uint4(0, 0, 0, 0);
-        uint2 pC = make_uint2(0, 0);
-        const int n_iter = g.mb_w + 2 * last;
+        uint32_t ya0 = 0, yb0 = 0, ca0 = 0, cb0 = 0;                  // columns -4..-1: the previous macroblock's last four
+        uint4 fYa = make_uint4(0, 0, 0, 0), fYb = fYa, fT = fYa, fE = fYa;   // in flight for the next iteration
+        uint2 fCa = make_uint2(0, 0), fCb = fCa;
+        const int n_iter = g.mb_w + 1 + 2 * last;
+        const int *wait_on = from_above ? my_progress - 1 : my_progress;
+        // tile addresses of this lane's rows
+        uint32_t *tYa = L.tile + (2 * j) * 4, *tYb = tYa + 4, *tCa = L.tile + 64 + cp * 16 + cr * 2, *tCb = tCa + 2;
 
-        // prefetch for iteration t: own rows of x = t - 2*grp, top rows of group 0's macroblock, edge info of all four
+        // loads for iteration t
         auto prefetch = [&](int t) {
-            const int x = t - 2 * grp;
-            const bool act = have_row && x >= 0 && x < g.mb_w;
-            const int x0 = t;                                   // group 0's macroblock
-            if (band_above && x0 < g.mb_w && ok && !EXPD_NOWAIT) ok = row_wait(sync, band - 1, min(x0 + 2, g.mb_w), status);
-            if (act) { pY = *(const uint4 *)(srcY + x * 16); pC = *(const uint2 *)(srcC + x * 8); }
-            if (band_above && x0 < g.mb_w) {
-                if (lane < 4) pT = *(const uint4 *)(srcT + x0 * 16);
-                else if (lane < 8) { uint2 v2 = *(const uint2 *)(srcT + x0 * 8); pT.x = v2.x; pT.y = v2.y; }
+            const int x = t - 2 * gr;
+            const bool actn = have_row && x >= 0 && x < g.mb_w;
+            if (!EXPD_NOWAIT && ok) {
+                // macroblock x needs the band above to have stored x completely
+                const bool need = from_above && actn;
+                const int want = x + 1;
+                int spins = 0;
+                while (__ballot(need && __hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(status, 1); ok = false; break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            if (lane < 16) {                                    // 4 groups x 4 x 16 bytes
-                const int eg = lane >> 2, ex = t - 2 * eg, er = R0 + eg;
-                pE = make_uint4(0, 0, 0, 0);
-                if (eg < nrows && ex >= 0 && ex < g.mb_w) pE = ((const uint4 *)(pinfo + er * g.mb_w + ex))[lane & 3];
+            if (actn) {
+                if (j < 4) fE = ((const uint4 *)(pinfo + row * g.mb_w + x))[j];
+                if (from_above) {
+                    if (j < 4) fT = *(const uint4 *)(topP + x * 16);
+                    else { uint2 v2 = *(const uint2 *)(topP + x * 8); fT.x = v2.x; fT.y = v2.y; }
+                }
+                fYa = *(const uint4 *)(rowYa + x * 16); fYb = *(const uint4 *)(rowYb + x * 16);
+                fCa = *(const uint2 *)(rowCa + x * 8);  fCb = *(const uint2 *)(rowCb + x * 8);
             }
         };
 
         prefetch(0);
         for (int t = 0; t < n_iter; t++) {
-            const int x = t - 2 * grp;
-            const bool act = have_row && x >= 0 && x < g.mb_w;
-            const int slot = x & 3;
-            // ---- land what was prefetched for this iteration ----
-            if (act) { yl[1] = pY.x; yl[2] = pY.y; yl[3] = pY.z; yl[4] = pY.w; cl[1] = pC.x; cl[2] = pC.y; }
-            if (band_above && t < g.mb_w) {
-                uint32_t *rg = L.ring[0][t & 3];
-                if (lane < 4) { rg[lane * 4] = pT.x; rg[lane * 4 + 1] = pT.y; rg[lane * 4 + 2] = pT.z; rg[lane * 4 + 3] = pT.w; }
-                else if (lane < 8) { rg[16 + (lane - 4) * 2] = pT.x; rg[16 + (lane - 4) * 2 + 1] = pT.y; }
+            const int x = t - 2 * gr;
+            const bool act = have_row && x >= 0 && x < g.mb_w;         // filter macroblock x
+            const bool flush = have_row && x >= 1 && x <= g.mb_w;       // store macroblock x-1
+            uint32_t *ring = L.ring[x & 3];
+            // ---- land what was prefetched for this iteration: pixels stay in registers for the vertical pass ----
+            uint32_t ya[5] = { ya0, fYa.x, fYa.y, fYa.z, fYa.w }, yb[5] = { yb0, fYb.x, fYb.y, fYb.z, fYb.w };
+            uint32_t ca[3] = { ca0, fCa.x, fCa.y }, cb[3] = { cb0, fCb.x, fCb.y };
+            if (act) {
+                if (from_above) {
+                    if (j < 4) *(uint4 *)(ring + j * 4) = fT;
+                    else *(uint2 *)(ring + 16 + (j - 4) * 2) = make_uint2(fT.x, fT.y);
+                }
+                if (j < 4) *(uint4 *)(L.edge + j * 4) = fE;
             }
-            if (lane < 16) { uint32_t *ed = &L.edge[lane >> 2][(lane & 3) * 4]; ed[0] = pE.x; ed[1] = pE.y; ed[2] = pE.z; ed[3] = pE.w; }
+            // Everything this wave has issued is complete here (the prefetch was issued before the previous
+            // iteration's horizontal pass, its stores before that): macroblocks 0 .. x-2 of this row are in memory.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (publisher) __hip_atomic_store(my_progress, min(max(x - 1, 0), g.mb_w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             wave_lds_fence();
-            if (t + 1 < n_iter) prefetch(t + 1);                // the next iteration's loads start their trip now
+            // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
+            if (flush && top_exists && !EXPD_NOSTORE) {
+                const uint32_t *pr = L.ring[(x - 1) & 3];
+                if (j < 4) *(uint4 *)(topP + (x - 1) * 16) = *(const uint4 *)(pr + j * 4);
+                else *(uint2 *)(topP + (x - 1) * 8) = *(const uint2 *)(pr + 16 + (j - 4) * 2);
+            }
             EdgeRegs E;
-#pragma unroll
-            for (int k = 0; k < EDGE_DW; k++) E.e[k] = act ? L.edge[grp][k] : 0u;
-            uint32_t *ringY = L.ring[grp][slot], *ringC = L.ring[grp][slot] + 16 + cp * 4;
+            {
+                const uint4 v = act ? *(const uint4 *)L.edge : make_uint4(0, 0, 0, 0);
+                E.e[0] = v.x; E.e[1] = v.y; E.e[2] = v.z; E.e[3] = v.w; E.lds = L.edge;
+            }
+            const bool any_edges = __ballot((E.e[0] | E.e[1] | E.e[2] | E.e[3]) != 0) != 0;
 
-            if (!EXPD_NOFILTER) {
-                // ---------- vertical edges, in registers (luma: lane = row i; chroma: lane = (plane, row)) ----------
+            if (!EXPD_NOFILTER && any_edges) {
+                // ---------- vertical edges, in registers ----------
 #pragma unroll
                 for (int ed = 0; ed < 4; ed++) {
-                    const uint32_t nib = E.nib(0, ed);
-                    const int b = (nib >> (4 * (i >> 2))) & 15, first = nib & 15, k = edge_class(0, ed);
-                    const bool go = first >= 4 || b;
-                    if (__ballot(go) == 0) continue;
-                    if (go) {
-                        int p[4] = { (int)(yl[ed] >> 24), (int)((yl[ed] >> 16) & 255), (int)((yl[ed] >> 8) & 255), (int)(yl[ed] & 255) };
-                        int q[4] = { (int)(yl[ed+1] & 255), (int)((yl[ed+1] >> 8) & 255), (int)((yl[ed+1] >> 16) & 255), (int)(yl[ed+1] >> 24) };
-                        filter_luma(p, q, first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
-                        yl[ed] = (uint32_t)p[3] | ((uint32_t)p[2] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[0] << 24);
-                        yl[ed+1] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                    const int b = (E.nib(0, ed) >> (4 * seg)) & 15, k = edge_class(0, ed);
+                    if (__ballot(b != 0) == 0) continue;
+                    pk16 p2 = pair_byte<1>(ya[ed], yb[ed]), p1 = pair_byte<2>(ya[ed], yb[ed]), p0 = pair_byte<3>(ya[ed], yb[ed]);
+                    pk16 q0 = pair_byte<0>(ya[ed+1], yb[ed+1]), q1 = pair_byte<1>(ya[ed+1], yb[ed+1]), q2 = pair_byte<2>(ya[ed+1], yb[ed+1]);
+                    const EdgeParams ep(E, k);
+                    const pk16 A = pk_splat(ep.alpha()), B = pk_splat(ep.beta());
+                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
+                    const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
+                    const pk16 en = as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u);
+                    const pk16 op2 = p2, op1 = p1, op0 = p0, oq0 = q0, oq1 = q1, oq2 = q2;
+                    pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, pk_splat(ep.tc((b - 1) & 3)));
+                    if (__ballot(b == 4)) {
+                        const pk16 str = as_pk(b == 4 ? 0xffffffffu : 0u);
+                        pk16 sp2 = op2, sp1 = op1, sp0 = op0, sq0 = oq0, sq1 = oq1, sq2 = oq2;
+                        pk_luma_strong(pair_byte<0>(ya[ed], yb[ed]), sp2, sp1, sp0, sq0, sq1, sq2, pair_byte<3>(ya[ed+1], yb[ed+1]), f & str, ap, aq, A);
+                        p1 = pk_sel(str, sp1, p1); p0 = pk_sel(str, sp0, p0); q0 = pk_sel(str, sq0, q0); q1 = pk_sel(str, sq1, q1);
+                        ya[ed] = perm(as_u(sp2), ya[ed], 0x03020400u);   yb[ed] = perm(as_u(sp2), yb[ed], 0x03020600u);
+                        ya[ed+1] = perm(as_u(sq2), ya[ed+1], 0x03040100u); yb[ed+1] = perm(as_u(sq2), yb[ed+1], 0x03060100u);
                     }
+                    const uint32_t tp = as_u(p1) | (as_u(p0) << 8), tq = as_u(q0) | (as_u(q1) << 8);
+                    ya[ed] = perm(tp, ya[ed], 0x05040100u);     yb[ed] = perm(tp, yb[ed], 0x07060100u);
+                    ya[ed+1] = perm(tq, ya[ed+1], 0x03020504u); yb[ed+1] = perm(tq, yb[ed+1], 0x03020706u);
                 }
 #pragma unroll
                 for (int ed = 0; ed < 4; ed += 2) {
-                    const uint32_t nib = E.nib(0, ed);
-                    const int b = (nib >> (4 * (cj >> 1))) & 15, first = nib & 15, k = edge_class(0, ed) + 3;
-                    const bool go = first >= 4 || b;
-                    if (__ballot(go) == 0) continue;
-                    if (go) {
-                        const int j = ed >> 1;
-                        int p1 = (int)((cl[j] >> 16) & 255), p0 = (int)(cl[j] >> 24), q0 = (int)(cl[j+1] & 255), q1 = (int)((cl[j+1] >> 8) & 255);
-                        filter_chroma(p0, p1, q0, q1, first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
-                        cl[j] = (cl[j] & 0x00ffffffu) | ((uint32_t)p0 << 24);
-                        cl[j+1] = (cl[j+1] & 0xffffff00u) | (uint32_t)q0;
-                    }
+                    const int b = (E.nib(0, ed) >> (4 * cseg)) & 15, k = edge_class(0, ed) + 3, c = ed >> 1;
+                    if (__ballot(b != 0) == 0) continue;
+                    pk16 p1 = pair_byte<2>(ca[c], cb[c]), p0 = pair_byte<3>(ca[c], cb[c]);
+                    pk16 q0 = pair_byte<0>(ca[c+1], cb[c+1]), q1 = pair_byte<1>(ca[c+1], cb[c+1]);
+                    const EdgeParams ep(E, k);
+                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, pk_splat(ep.alpha()), pk_splat(ep.beta()));
+                    pk_chroma(p1, p0, q0, q1, f, as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u), as_pk(b == 4 ? 0xffffffffu : 0u),
+                              pk_splat(ep.tc((b - 1) & 3)));
+                    ca[c] = perm(as_u(p0), ca[c], 0x04020100u);     cb[c] = perm(as_u(p0), cb[c], 0x06020100u);
+                    ca[c+1] = perm(as_u(q0), ca[c+1], 0x03020104u); cb[c+1] = perm(as_u(q0), cb[c+1], 0x03020106u);
                 }
             }
-            // the previous macroblock's right-hand columns are final now: its bottom rows go to the group below
-            if (act && below_in_band && x > 0) {
-                uint32_t *nr = L.ring[grp + 1][(x - 1) & 3];
-                if (i >= 12) nr[(i - 12) * 4 + 3] = yl[0];
-                if (cj >= 6) nr[16 + cp * 4 + (cj - 6) * 2 + 1] = cl[0];
-            }
-            // ---------- horizontal edges: rows -> LDS -> columns -> LDS -> rows ----------
-            if (act) {
-                tY[i * 4] = yl[1]; tY[i * 4 + 1] = yl[2]; tY[i * 4 + 2] = yl[3]; tY[i * 4 + 3] = yl[4];
-                tC[cj * 2] = cl[1]; tC[cj * 2 + 1] = cl[2];
+            // ---- macroblock x-1 is final now: columns 0..11 still sit in the tile, its last four columns are ya[0]/yb[0].
+            // Store it as whole rows; rows 12..15 go to the octet below instead, which stores them as its "rows above".
+            if (flush) {
+                uint4 sa = *(const uint4 *)tYa, sb = *(const uint4 *)tYb;
+                uint2 ta = *(const uint2 *)tCa, tb = *(const uint2 *)tCb;
+                sa.w = ya[0]; sb.w = yb[0]; ta.y = ca[0]; tb.y = cb[0];
+                uint32_t *nr = Lnext.ring[(x - 1) & 3];
+                if (below_in_band && j >= 6) { *(uint4 *)(nr + (2 * j - 12) * 4) = sa; *(uint4 *)(nr + (2 * j - 11) * 4) = sb; }
+                else if (!EXPD_NOSTORE) { *(uint4 *)(rowYa + (x - 1) * 16) = sa; *(uint4 *)(rowYb + (x - 1) * 16) = sb; }
+                if (below_in_band && (j & 3) == 3) { *(uint2 *)(nr + 16 + cp * 4) = ta; *(uint2 *)(nr + 16 + cp * 4 + 2) = tb; }
+                else if (!EXPD_NOSTORE) { *(uint2 *)(rowCa + (x - 1) * 8) = ta; *(uint2 *)(rowCb + (x - 1) * 8) = tb; }
             }
             wave_lds_fence();
-            if (!EXPD_NOFILTER) {
-                const uint32_t hb = E.e[2] | E.e[3];
-                if (__ballot(hb != 0)) {
-                    if (hb) {
-                        // luma: this lane takes column i
-                        const uint8_t *top = (const uint8_t *)ringY + i, *col = (const uint8_t *)tY + i;
-                        int c[20];
+            // ---------- rows of macroblock x -> tile ----------
+            if (act) {
+                *(uint4 *)tYa = make_uint4(ya[1], ya[2], ya[3], ya[4]); *(uint4 *)tYb = make_uint4(yb[1], yb[2], yb[3], yb[4]);
+                *(uint2 *)tCa = make_uint2(ca[1], ca[2]);               *(uint2 *)tCb = make_uint2(cb[1], cb[2]);
+            }
+            wave_lds_fence();
+            if (t + 1 < n_iter) prefetch(t + 1);                      // the next iteration's loads travel during the horizontal pass
+            // ---------- horizontal edges: column pairs out of the tile, filtered, back into the tile ----------
+            const bool h_edges = __ballot((E.e[2] | E.e[3]) != 0) != 0;
+            if (!EXPD_NOFILTER && h_edges) {
+                if (act) {
+                    // luma: columns 2j, 2j+1
+                    const uint8_t *top = (const uint8_t *)ring + 2 * j, *col = tile8 + 2 * j;
+                    pk16 c[20];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) c[r] = top[r * 16];
+                    for (int r = 0; r < 4; r++) { uint32_t v = *(const uint16_t *)(top + r * 16); c[r] = as_pk(perm(v, v, 0x0c010c00u)); }
 #pragma unroll
-                        for (int r = 0; r < 16; r++) c[4 + r] = col[r * 16];
+                    for (int r = 0; r < 16; r++) { uint32_t v = *(const uint16_t *)(col + r * 16); c[4 + r] = as_pk(perm(v, v, 0x0c010c00u)); }
 #pragma unroll
-                        for (int ed = 0; ed < 4; ed++) {
-                            const uint32_t nib = E.nib(1, ed);
-                            const int b = (nib >> (4 * (i >> 2))) & 15, first = nib & 15, k = edge_class(1, ed);
-                            if (first >= 4 || b) {
-                                int p[4] = { c[4*ed+3], c[4*ed+2], c[4*ed+1], c[4*ed] }, q[4] = { c[4*ed+4], c[4*ed+5], c[4*ed+6], c[4*ed+7] };
-                                filter_luma(p, q, first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
-                                c[4*ed+3] = p[0]; c[4*ed+2] = p[1]; c[4*ed+1] = p[2]; c[4*ed+4] = q[0]; c[4*ed+5] = q[1]; c[4*ed+6] = q[2];
-                            }
+                    for (int ed = 0; ed < 4; ed++) {
+                        const int b = (E.nib(1, ed) >> (4 * seg)) & 15, k = edge_class(1, ed);
+                        if (__ballot(b != 0) == 0) continue;
+                        pk16 &p3 = c[4*ed], &p2 = c[4*ed+1], &p1 = c[4*ed+2], &p0 = c[4*ed+3], &q0 = c[4*ed+4], &q1 = c[4*ed+5], &q2 = c[4*ed+6], &q3 = c[4*ed+7];
+                        const EdgeParams ep(E, k);
+                        const pk16 A = pk_splat(ep.alpha()), B = pk_splat(ep.beta());
+                        const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
+                        const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
+                        const pk16 en = as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u);
+                        pk16 sp2 = p2, sp1 = p1, sp0 = p0, sq0 = q0, sq1 = q1, sq2 = q2;
+                        pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, pk_splat(ep.tc((b - 1) & 3)));
+                        if (__ballot(b == 4)) {
+                            const pk16 str = as_pk(b == 4 ? 0xffffffffu : 0u);
+                            pk_luma_strong(p3, sp2, sp1, sp0, sq0, sq1, sq2, q3, f & str, ap, aq, A);
+                            p2 = pk_sel(str, sp2, p2); p1 = pk_sel(str, sp1, p1); p0 = pk_sel(str, sp0, p0);
+                            q0 = pk_sel(str, sq0, q0); q1 = pk_sel(str, sq1, q1); q2 = pk_sel(str, sq2, q2);
                         }
-                        uint8_t *topw = (uint8_t *)ringY + i, *colw = (uint8_t *)tY + i;
-#pragma unroll
-                        for (int r = 1; r < 4; r++) topw[r * 16] = (uint8_t)c[r];
-#pragma unroll
-                        for (int r = 0; r < 15; r++) colw[r * 16] = (uint8_t)c[4 + r];
-                        // chroma: this lane takes column cj of plane cp
-                        const uint8_t *ctop = (const uint8_t *)ringC + cj, *ccol = (const uint8_t *)tC + cj;
-                        int d[10];
-                        d[0] = ctop[0]; d[1] = ctop[8];
-#pragma unroll
-                        for (int r = 0; r < 8; r++) d[2 + r] = ccol[r * 8];
-#pragma unroll
-                        for (int ed = 0; ed < 4; ed += 2) {
-                            const uint32_t nib = E.nib(1, ed);
-                            const int b = (nib >> (4 * (cj >> 1))) & 15, first = nib & 15, k = edge_class(1, ed) + 3;
-                            if (first >= 4 || b)
-                                filter_chroma(d[2*ed+1], d[2*ed], d[2*ed+2], d[2*ed+3], first >= 4 ? 4 : b, E.ab(k, 0), E.ab(k, 1), first >= 4 ? 0 : E.tc(k, b - 1));
-                        }
-                        uint8_t *ctopw = (uint8_t *)ringC + cj, *ccolw = (uint8_t *)tC + cj;
-                        ctopw[8] = (uint8_t)d[1];
-#pragma unroll
-                        for (int r = 0; r < 7; r++) ccolw[r * 8] = (uint8_t)d[2 + r];
                     }
-                    wave_lds_fence();
-                    if (act) {
-                        yl[1] = tY[i * 4]; yl[2] = tY[i * 4 + 1]; yl[3] = tY[i * 4 + 2]; yl[4] = tY[i * 4 + 3];
-                        cl[1] = tC[cj * 2]; cl[2] = tC[cj * 2 + 1];
+                    uint8_t *topw = (uint8_t *)ring + 2 * j;
+#pragma unroll
+                    for (int r = 1; r < 4; r++) *(uint16_t *)(topw + r * 16) = (uint16_t)perm(as_u(c[r]), as_u(c[r]), 0x0c0c0200u);
+#pragma unroll
+                    for (int r = 0; r < 15; r++) *(uint16_t *)(tile8 + 2 * j + r * 16) = (uint16_t)perm(as_u(c[4 + r]), as_u(c[4 + r]), 0x0c0c0200u);
+                    // chroma: columns cr, cr+1 of plane cp; only rows -1, 0, 3, 4 can change
+                    const uint8_t *ctop = (const uint8_t *)ring + 64 + cp * 16 + cr;
+                    uint8_t *ccol = tile8 + 256 + cp * 64 + cr;
+                    pk16 d[10];
+#pragma unroll
+                    for (int r = 0; r < 2; r++) { uint32_t v = *(const uint16_t *)(ctop + r * 8); d[r] = as_pk(perm(v, v, 0x0c010c00u)); }
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { uint32_t v = *(const uint16_t *)(ccol + r * 8); d[2 + r] = as_pk(perm(v, v, 0x0c010c00u)); }
+#pragma unroll
+                    for (int ed = 0; ed < 4; ed += 2) {
+                        const int b = (E.nib(1, ed) >> (4 * cseg)) & 15, k = edge_class(1, ed) + 3;
+                        if (__ballot(b != 0) == 0) continue;
+                        const EdgeParams ep(E, k);
+                        const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], pk_splat(ep.alpha()), pk_splat(ep.beta()));
+                        pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], f, as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u),
+                                  as_pk(b == 4 ? 0xffffffffu : 0u), pk_splat(ep.tc((b - 1) & 3)));
                     }
+                    *(uint16_t *)((uint8_t *)ring + 64 + cp * 16 + cr + 8) = (uint16_t)perm(as_u(d[1]), as_u(d[1]), 0x0c0c0200u);
+                    *(uint16_t *)(ccol) = (uint16_t)perm(as_u(d[2]), as_u(d[2]), 0x0c0c0200u);
+                    *(uint16_t *)(ccol + 3 * 8) = (uint16_t)perm(as_u(d[5]), as_u(d[5]), 0x0c0c0200u);
+                    *(uint16_t *)(ccol + 4 * 8) = (uint16_t)perm(as_u(d[6]), as_u(d[6]), 0x0c0c0200u);
                 }
+                wave_lds_fence();
             }
-            // bottom rows of this macroblock (columns 0..11, plus 12..15 if it is the last of its row) go to the group below
-            if (act && below_in_band) {
-                uint32_t *nr = L.ring[grp + 1][slot];
-                const bool lastmb = x + 1 == g.mb_w;
-                if (i >= 12) { uint32_t *r = nr + (i - 12) * 4; r[0] = yl[1]; r[1] = yl[2]; r[2] = yl[3]; if (lastmb) r[3] = yl[4]; }
-                if (cj >= 6) { uint32_t *r = nr + 16 + cp * 4 + (cj - 6) * 2; r[0] = cl[1]; if (lastmb) r[1] = cl[2]; }
-            }
-            // everything issued before this point has completed at the release below: the stores of the previous
-            // iteration and the prefetch for the next one.  Publish the last row's progress, one macroblock late.
-            {
-                const int xl = t - 2 * last;
-                if (xl >= 0) row_publish(sync, band, min(xl, g.mb_w));
-                else wave_lds_fence();
-            }
-            // ---- write back ----
-            if (act && !EXPD_NOSTORE) {
-                const bool lastmb = x + 1 == g.mb_w;
-                if (!below_in_band || i < 12) {              // rows 12..15 are written by the group below, as its "rows above"
-                    uint8_t *dY = srcY + x * 16;
-                    if (x > 0) *(uint32_t *)(dY - 4) = yl[0];
-                    *(uint2 *)dY = make_uint2(yl[1], yl[2]);
-                    *(uint32_t *)(dY + 8) = yl[3];
-                    if (lastmb) *(uint32_t *)(dY + 12) = yl[4];
-                }
-                if (!below_in_band || cj < 6) {
-                    uint8_t *dC = srcC + x * 8;
-                    if (x > 0) *(uint32_t *)(dC - 4) = cl[0];
-                    *(uint32_t *)dC = cl[1];
-                    if (lastmb) *(uint32_t *)(dC + 4) = cl[2];
-                }
-                if (top_exists) {                             // the rows above this macroblock are final: lines 0..3 luma, 4..7 chroma
-                    if (i < 4) {
-                        const uint32_t *r = ringY + i * 4;
-                        *(uint4 *)(Y + (size_t)(row * 16 - 4 + i) * g.w + x * 16) = make_uint4(r[0], r[1], r[2], r[3]);
-                    } else if (i < 8) {
-                        const int tp = (i >> 1) & 1, tr = i & 1;
-                        const uint32_t *r = L.ring[grp][slot] + 16 + tp * 4 + tr * 2;
-                        *(uint2 *)((tp ? V : U) + (size_t)(row * 8 - 2 + tr) * g.cw + x * 8) = make_uint2(r[0], r[1]);
-                    }
-                }
-            }
-            yl[0] = yl[4]; cl[0] = cl[2];                     // right-hand columns become the left-hand columns of the next macroblock
+            // the last four columns of this macroblock are the next one's columns -4..-1
+            if (act) { ya0 = tYa[3]; yb0 = tYb[3]; ca0 = tCa[1]; cb0 = tCb[1]; }
             wave_lds_fence();
         }
-        row_publish(sync, band, g.mb_w);             // waits for the last stores of the band
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (publisher) __hip_atomic_store(my_progress, g.mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wave_lds_fence();
     }
 }

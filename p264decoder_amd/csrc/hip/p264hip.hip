@@ -45,7 +45,7 @@ struct PicSlot {                       // one device-resident parsed picture
 #define BATCH_RING 4
 
 struct p264hip_ctx {
-    int device = 0;
+    int device = 0, n_cu = 256;
     hipStream_t stream = nullptr;
     Geom g;
     int n_streams = 0, slots = 0, max_pictures = 0;
@@ -89,6 +89,7 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     g.off_v = g.off_u + align_up((size_t)g.cw * g.ch, 256);
     c->frame_bytes = g.off_v + align_up((size_t)g.cw * g.ch, 256) + 256;      // +256: dword loads may run past a row end
     c->pics.resize((size_t)max_pictures);
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->frames, c->frame_bytes * (size_t)n_streams * slots);
     if (e == hipSuccess) e = hipMemsetAsync(c->frames, 0, c->frame_bytes * (size_t)n_streams * slots, c->stream);
@@ -270,7 +271,14 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         ScopedStamp t(c, 2);
         int total = n * g.n_mb;
         hipLaunchKernelGGL(k_deblock_bs, dim3((total + 7) / 8), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, n);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(ROW_WAVES * 64), 0, c->stream, c->d_batch[r], g, (const EdgeInfo *)c->d_edge, c->d_status);
+        // a wavefront filters 8 macroblock rows at a time: 8 rows of one picture while there are no more
+        // pictures than compute units, else 4 rows of two pictures (or 2 of four) per workgroup
+        int rb_log2 = n > 3 * c->n_cu ? 1 : n > c->n_cu ? 2 : 3;
+        if (const char *e = getenv("P264AMD_DEBLOCK_RB_LOG2")) { int v = atoi(e); if (v >= 1 && v <= 3) rb_log2 = v; }
+        const int per_wg = 8 >> rb_log2, n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
+        const int waves = n_bands < ROW_WAVES ? n_bands : ROW_WAVES;
+        hipLaunchKernelGGL(k_deblock, dim3((n + per_wg - 1) / per_wg), dim3(waves * 64), 0, c->stream, c->d_batch[r], g,
+                           (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2);
     }
     HIPCHK(hipGetLastError());
     return P264HIP_OK;

@@ -16,7 +16,7 @@ struct PicDev {
     const int8_t       *ref_idx;   // [mb][4]
     const uint8_t      *i4modes;   // [mb][16]
     const int16_t      *coefs;     // [blocks][16]
-    uint8_t            *dst;       // frame base (Y plane); U and V at fixed offsets
+    uint8_t            *dst;       // frame base (macroblock-tiled, see MB_TILE)
     const uint8_t      *ref[P264HIP_MAX_REFS];
     int32_t n_ref, slice_type, chroma_qp_offset, deblock, alpha_off, beta_off;
     int32_t pad[2];
@@ -25,9 +25,28 @@ struct PicDev {
 // Geometry shared by every picture of a context.
 struct Geom {
     int mb_w, mb_h, n_mb;
-    int w, h, cw, ch;              // luma / chroma plane sizes (= strides)
-    size_t off_u, off_v;           // byte offsets of the chroma planes inside a frame
+    int w, h, cw, ch;              // luma / chroma plane sizes in samples
 };
+
+// ---- frame layout in HBM -------------------------------------------------------------------
+// Frames are stored macroblock-tiled, not as planes: macroblock (mx,my) owns MB_TILE = 384 consecutive
+// bytes = three 128-byte cache lines: 16 luma rows x 16 bytes, then 8 U rows x 8 bytes, then 8 V rows
+// x 8 bytes.  Every kernel of the path touches whole macroblocks, so a wavefront's loads and stores
+// cover whole lines (a planar frame costs one line per 16-byte row piece and thrashes L1/L2: measured
+// 3-5x HBM write amplification in the row-wavefront kernels), and a motion-compensation window spans
+// 2x2..3x3 tiles instead of 21 row lines.  Planar views exist only at the host boundary
+// (p264hip_read_frame / p264hip_write_frame).
+#define MB_TILE    384
+#define MB_TILE_U  256
+#define MB_TILE_V  320
+__device__ __forceinline__ uint32_t luma_off(const Geom &g, int x, int y)
+{
+    return (uint32_t)((y >> 4) * g.mb_w + (x >> 4)) * MB_TILE + (uint32_t)((y & 15) * 16 + (x & 15));
+}
+__device__ __forceinline__ uint32_t chroma_off(const Geom &g, int plane, int x, int y)
+{
+    return (uint32_t)((y >> 3) * g.mb_w + (x >> 3)) * MB_TILE + (uint32_t)(MB_TILE_U + plane * 64 + (y & 7) * 8 + (x & 7));
+}
 
 __device__ __forceinline__ int clip3i(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }

@@ -302,7 +302,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
     const PicDev *pd = pics + min(pic, n_pics - 1);
     const bool pic_ok = pic < n_pics && pd->deblock;
     OctLds &L = lds[wave][o];
-    uint8_t *Y = pd->dst, *U = pd->dst + g.off_u, *V = pd->dst + g.off_v;
+    uint8_t *F = pd->dst;                                     // macroblock-tiled frame (device_common.h)
     const EdgeInfo *pinfo = info + (size_t)min(pic, n_pics - 1) * g.n_mb;
     const int seg = j >> 1, cseg = j & 3;                     // bS segment of this lane's luma / chroma lines
     const int cp = j >> 2, cr = (j & 3) * 2;                  // chroma plane, first chroma line of this lane
@@ -318,17 +318,19 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         const bool top_exists = row > 0;
         const bool from_above = have_row && gr == 0 && band > 0;   // the rows above come from the band above, through memory
         const int rowc = min(row, g.mb_h - 1);
-        uint8_t *rowYa = Y + (size_t)(rowc * 16 + 2 * j) * g.w, *rowYb = rowYa + g.w;
-        uint8_t *rowCa = (cp ? V : U) + (size_t)(rowc * 8 + cr) * g.cw, *rowCb = rowCa + g.cw;
-        // the rows above: lanes 0..3 luma rows -4..-1, lanes 4..7 chroma (plane, row) = ((j>>1)&1, j&1); valid if top_exists
-        uint8_t *topP = j < 4 ? Y + ((ptrdiff_t)rowc * 16 - 4 + j) * g.w : ((j >> 1) & 1 ? V : U) + ((ptrdiff_t)rowc * 8 - 2 + (j & 1)) * g.cw;
+        // Tiled frame: macroblock x of this row is the 384 bytes at rowT + x*384.  This lane's two luma rows are the 32
+        // bytes at +32j, its two chroma rows the 16 bytes at +256+16j: an octet reads and writes whole cache lines.
+        uint8_t *rowT = F + (size_t)rowc * g.mb_w * MB_TILE;
+        uint8_t *ownY = rowT + j * 32, *ownC = rowT + MB_TILE_U + j * 16;
+        // the rows above (valid if top_exists): lanes 0..3 luma rows 12..15 of the macroblock above, lanes 4..7 its chroma
+        // rows 6,7 of plane (j>>1)&1
+        uint8_t *topP = rowT - (ptrdiff_t)g.mb_w * MB_TILE + (j < 4 ? 192 + j * 16 : MB_TILE_U + ((j >> 1) & 1) * 64 + 48 + (j & 1) * 8);
         int *my_progress = &progress[pi & (MAX_PICS_PER_WG - 1)][band];
         const bool publisher = have_row && gr == last && j == 0;
         OctLds &Lnext = lds[wave][min(o + 1, 7)];
 
         uint32_t ya0 = 0, yb0 = 0, ca0 = 0, cb0 = 0;                  // columns -4..-1: the previous macroblock's last four
-        uint4 fYa = make_uint4(0, 0, 0, 0), fYb = fYa, fT = fYa, fE = fYa;   // in flight for the next iteration
-        uint2 fCa = make_uint2(0, 0), fCb = fCa;
+        uint4 fYa = make_uint4(0, 0, 0, 0), fYb = fYa, fC = fYa, fT = fYa, fE = fYa;   // in flight for the next iteration
         const int n_iter = g.mb_w + 1 + 2 * last;
         const int *wait_on = from_above ? my_progress - 1 : my_progress;
         // tile addresses of this lane's rows
@@ -352,11 +354,11 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             if (actn) {
                 if (j < 4) fE = ((const uint4 *)(pinfo + row * g.mb_w + x))[j];
                 if (from_above) {
-                    if (j < 4) fT = *(const uint4 *)(topP + x * 16);
-                    else { uint2 v2 = *(const uint2 *)(topP + x * 8); fT.x = v2.x; fT.y = v2.y; }
+                    if (j < 4) fT = *(const uint4 *)(topP + x * MB_TILE);
+                    else { uint2 v2 = *(const uint2 *)(topP + x * MB_TILE); fT.x = v2.x; fT.y = v2.y; }
                 }
-                fYa = *(const uint4 *)(rowYa + x * 16); fYb = *(const uint4 *)(rowYb + x * 16);
-                fCa = *(const uint2 *)(rowCa + x * 8);  fCb = *(const uint2 *)(rowCb + x * 8);
+                fYa = *(const uint4 *)(ownY + x * MB_TILE); fYb = *(const uint4 *)(ownY + x * MB_TILE + 16);
+                fC = *(const uint4 *)(ownC + x * MB_TILE);
             }
         };
 
@@ -368,7 +370,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             uint32_t *ring = L.ring[x & 3];
             // ---- land what was prefetched for this iteration: pixels stay in registers for the vertical pass ----
             uint32_t ya[5] = { ya0, fYa.x, fYa.y, fYa.z, fYa.w }, yb[5] = { yb0, fYb.x, fYb.y, fYb.z, fYb.w };
-            uint32_t ca[3] = { ca0, fCa.x, fCa.y }, cb[3] = { cb0, fCb.x, fCb.y };
+            uint32_t ca[3] = { ca0, fC.x, fC.y }, cb[3] = { cb0, fC.z, fC.w };
             if (act) {
                 if (from_above) {
                     if (j < 4) *(uint4 *)(ring + j * 4) = fT;
@@ -384,8 +386,8 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
             if (flush && top_exists && !EXPD_NOSTORE) {
                 const uint32_t *pr = L.ring[(x - 1) & 3];
-                if (j < 4) *(uint4 *)(topP + (x - 1) * 16) = *(const uint4 *)(pr + j * 4);
-                else *(uint2 *)(topP + (x - 1) * 8) = *(const uint2 *)(pr + 16 + (j - 4) * 2);
+                if (j < 4) *(uint4 *)(topP + (x - 1) * MB_TILE) = *(const uint4 *)(pr + j * 4);
+                else *(uint2 *)(topP + (x - 1) * MB_TILE) = *(const uint2 *)(pr + 16 + (j - 4) * 2);
             }
             EdgeRegs E;
             {
@@ -443,9 +445,9 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 sa.w = ya[0]; sb.w = yb[0]; ta.y = ca[0]; tb.y = cb[0];
                 uint32_t *nr = Lnext.ring[(x - 1) & 3];
                 if (below_in_band && j >= 6) { *(uint4 *)(nr + (2 * j - 12) * 4) = sa; *(uint4 *)(nr + (2 * j - 11) * 4) = sb; }
-                else if (!EXPD_NOSTORE) { *(uint4 *)(rowYa + (x - 1) * 16) = sa; *(uint4 *)(rowYb + (x - 1) * 16) = sb; }
+                else if (!EXPD_NOSTORE) { *(uint4 *)(ownY + (x - 1) * MB_TILE) = sa; *(uint4 *)(ownY + (x - 1) * MB_TILE + 16) = sb; }
                 if (below_in_band && (j & 3) == 3) { *(uint2 *)(nr + 16 + cp * 4) = ta; *(uint2 *)(nr + 16 + cp * 4 + 2) = tb; }
-                else if (!EXPD_NOSTORE) { *(uint2 *)(rowCa + (x - 1) * 8) = ta; *(uint2 *)(rowCb + (x - 1) * 8) = tb; }
+                else if (!EXPD_NOSTORE) *(uint4 *)(ownC + (x - 1) * MB_TILE) = make_uint4(ta.x, ta.y, tb.x, tb.y);
             }
             wave_lds_fence();
             // ---------- rows of macroblock x -> tile ----------

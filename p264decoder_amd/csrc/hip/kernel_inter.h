@@ -155,16 +155,20 @@ template <int P> __device__ __forceinline__ uint32_t qpel4(const uint32_t *w, in
 
 // ---- per-sample fallback on the clamped plane (same arithmetic, one sample at a time) -------
 struct ClampedPlane {
-    const uint8_t *p; int w, h;
+    const uint8_t *p; int w, h, mb_w, plane;          // plane: -1 luma, 0 U, 1 V (tiled frame, device_common.h)
     __device__ __forceinline__ int operator()(int x, int y) const
-    { return p[clip3i(y, 0, h - 1) * w + clip3i(x, 0, w - 1)]; }
+    {
+        x = clip3i(x, 0, w - 1); y = clip3i(y, 0, h - 1);
+        if (plane < 0) return p[(uint32_t)((y >> 4) * mb_w + (x >> 4)) * MB_TILE + (y & 15) * 16 + (x & 15)];
+        return p[(uint32_t)((y >> 3) * mb_w + (x >> 3)) * MB_TILE + MB_TILE_U + plane * 64 + (y & 7) * 8 + (x & 7)];
+    }
 };
 // Deliberately rolled loops: this path is rare (sub-8x8 partitions, windows crossing the left/right
 // picture edge) and must not set the register budget of the kernel.
 __device__ __forceinline__ int tap_coef(int k) { return (k == 0 || k == 5) ? 1 : (k == 1 || k == 4) ? -5 : 20; }
-__device__ __noinline__ int half_sample(const uint8_t *p, int w, int h, int x, int y, int hx, int hy)
+__device__ __noinline__ int half_sample(const uint8_t *p, int w, int h, int mb_w, int x, int y, int hx, int hy)
 {
-    ClampedPlane f = { p, w, h };
+    ClampedPlane f = { p, w, h, mb_w, -1 };
     x += hx >> 1; y += hy >> 1;
     int which = (hx & 1) | ((hy & 1) << 1);
     if (which == 0) return f(x, y);
@@ -188,11 +192,11 @@ __device__ __noinline__ int half_sample(const uint8_t *p, int w, int h, int x, i
     }
     return clip255((s + 512) >> 10);
 }
-__device__ __forceinline__ int qpel_sample(const uint8_t *p, int w, int h, int x, int y, int fx, int fy)
+__device__ __forceinline__ int qpel_sample(const uint8_t *p, int w, int h, int mb_w, int x, int y, int fx, int fy)
 {
     int corr = (fx & 1) && (fy & 1) && ((fx & 2) ^ (fy & 2));
-    int a = half_sample(p, w, h, x, y, fx >> 1, (fy + 1 - corr) >> 1);
-    if ((fx | fy) & 1) a = (a + half_sample(p, w, h, x, y, (fx + 1) >> 1, (fy + corr) >> 1) + 1) >> 1;
+    int a = half_sample(p, w, h, mb_w, x, y, fx >> 1, (fy + 1 - corr) >> 1);
+    if ((fx | fy) & 1) a = (a + half_sample(p, w, h, mb_w, x, y, (fx + 1) >> 1, (fy + corr) >> 1) + 1) >> 1;
     return a;
 }
 __device__ __forceinline__ int chroma_sample(const ClampedPlane &c, int sx, int sy, int mvx, int mvy)
@@ -248,16 +252,16 @@ template <int P> __device__ __forceinline__ uint32_t chroma4(const uint32_t *w, 
 }
 
 // rare paths kept out of line so that they do not set the register budget of the kernel
-__device__ __noinline__ uint32_t slow_luma4(const uint8_t *ref, int w, int h, int x, int y, int mv)
+__device__ __noinline__ uint32_t slow_luma4(const uint8_t *ref, int w, int h, int mb_w, int x, int y, int mv)
 {
     uint32_t out = 0;
 #pragma unroll 1
-    for (int i = 0; i < 4; i++) out |= (uint32_t)qpel_sample(ref, w, h, x + i + (mv_x(mv) >> 2), y + (mv_y(mv) >> 2), mv_x(mv) & 3, mv_y(mv) & 3) << (8 * i);
+    for (int i = 0; i < 4; i++) out |= (uint32_t)qpel_sample(ref, w, h, mb_w, x + i + (mv_x(mv) >> 2), y + (mv_y(mv) >> 2), mv_x(mv) & 3, mv_y(mv) & 3) << (8 * i);
     return out;
 }
-__device__ __noinline__ uint32_t slow_chroma4(const uint8_t *ref, int w, int h, int x, int y, int mvA, int mvB)
+__device__ __noinline__ uint32_t slow_chroma4(const uint8_t *ref, int w, int h, int mb_w, int plane, int x, int y, int mvA, int mvB)
 {
-    ClampedPlane f = { ref, w, h };
+    ClampedPlane f = { ref, w, h, mb_w, plane };
     uint32_t out = 0;
 #pragma unroll 1
     for (int i = 0; i < 4; i++) { int m2 = i < 2 ? mvA : mvB; out |= (uint32_t)chroma_sample(f, x + i, y, mv_x(m2), mv_y(m2)) << (8 * i); }
@@ -327,13 +331,13 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
             yv[k] = 0;
             if (i < 126 && !EXP_NOLOAD) {
                 int yy = clip3i(Y0 + (ly >> 2) - 2 + r, 0, g.h - 1);
-                yv[k] = WLOAD(rf + (size_t)yy * g.w + (ux0 & ~3) + d * 4);
+                yv[k] = WLOAD(rf + luma_off(g, (ux0 & ~3) + d * 4, yy));
             }
         }
         if (lane < 54 && !EXP_NOLOAD) {
             int p = lane >= 27, l2 = lane - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
             int yy = clip3i(Y0 / 2 + (ly >> 3) + r, 0, g.ch - 1);
-            cvv = WLOAD(rf + (p ? g.off_v : g.off_u) + (size_t)yy * g.cw + (ucx0 & ~3) + d * 4);
+            cvv = WLOAD(rf + chroma_off(g, p, (ucx0 & ~3) + d * 4, yy));
         }
         uint32_t *yw = &L.ywin[0][0], *cw = &L.cwin[0][0][0];
         yw[lane] = yv[0];
@@ -373,7 +377,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
                 if (((fast >> q) & 1) && lane < 52) {
                     int wx0 = X0 + (q & 1) * 8 + (mv_x(qmv[q]) >> 2) - 2;
                     int yy = clip3i(Y0 + (q >> 1) * 8 + (mv_y(qmv[q]) >> 2) - 2 + r, 0, g.h - 1);
-                    yv[q] = WLOAD(qref[q] + (size_t)yy * g.w + (wx0 & ~3) + d * 4);
+                    yv[q] = WLOAD(qref[q] + luma_off(g, (wx0 & ~3) + d * 4, yy));
                 }
             }
             const int q4 = lane >> 4, rr = lane & 15, cr = rr >> 1, cd = rr & 1;   // chroma: one instruction per plane, 16 lanes per quadrant
@@ -385,7 +389,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 cv[p] = 0;
-                if (cok) cv[p] = WLOAD(crf + (p ? g.off_v : g.off_u) + (size_t)cyy * g.cw + (cx0 & ~3) + cd * 4);
+                if (cok) cv[p] = WLOAD(crf + chroma_off(g, p, (cx0 & ~3) + cd * 4, cyy));
             }
         }
         if (lane < 52) {
@@ -416,8 +420,8 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
             } else {
                 // sub-8x8 partitions with differing vectors, or a window crossing the left/right
                 // picture edge: every lane samples the clamped plane with its own vectors
-                if ((group >> lq) & 1) outY = slow_luma4(qref[q0], g.w, g.h, X0 + dw * 4, Y0 + row, mvl);
-                if (lane < 32 && ((group >> cq) & 1)) outC = slow_chroma4(qref[q0] + (cp ? g.off_v : g.off_u), g.cw, g.ch, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
+                if ((group >> lq) & 1) outY = slow_luma4(qref[q0], g.w, g.h, g.mb_w, X0 + dw * 4, Y0 + row, mvl);
+                if (lane < 32 && ((group >> cq) & 1)) outC = slow_chroma4(qref[q0], g.cw, g.ch, g.mb_w, cp, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
             }
         }
     }
@@ -464,7 +468,9 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 
     // ---------------- the lane stores its own dword ----------------
     if (EXP_NOSTORE && outY != 0x12345678u) return;
-    *(uint32_t *)(pd->dst + (size_t)(Y0 + row) * g.w + X0 + dw * 4) = outY;
-    if (lane < 32)
-        *(uint32_t *)(pd->dst + (cp ? g.off_v : g.off_u) + (size_t)(Y0 / 2 + crow) * g.cw + X0 / 2 + cdw * 4) = outC;
+    // (tiled frame: luma dword (row, dw) sits at lane*4, chroma dword (plane, row, dw) at 256 + lane*4 - the
+    // macroblock goes out as three whole cache lines)
+    uint8_t *tile = pd->dst + (size_t)mbi * MB_TILE;
+    *(uint32_t *)(tile + lane * 4) = outY;
+    if (lane < 32) *(uint32_t *)(tile + MB_TILE_U + lane * 4) = outC;
 }

@@ -73,7 +73,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w, X0 = mbx * 16, Y0 = mby * 16;
     const bool aL = m.avail & P264_AVAIL_LEFT, aT = m.avail & P264_AVAIL_TOP;
     const bool aTR = m.avail & P264_AVAIL_TOPRIGHT, aTL = m.avail & P264_AVAIL_TOPLEFT;
-    uint8_t *Y = pd->dst, *U = pd->dst + g.off_u, *V = pd->dst + g.off_v;
+    uint8_t *F = pd->dst;                                  // macroblock-tiled frame (device_common.h)
     const unsigned mask = m.coef_mask;
     const int16_t *cf = pd->coefs + (size_t)m.coef_index * 16;
 
@@ -81,18 +81,18 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     if (lane < 21) {                                        // top row: corner, 16 top, 4 top-right
         int x = lane - 1;
         bool ok = x < 0 ? aTL : x < 16 ? aT : aTR;
-        L.y[3 + lane] = ok ? Y[(size_t)(Y0 - 1) * g.w + X0 + x] : 128;
+        L.y[3 + lane] = ok ? F[luma_off(g, X0 + x, Y0 - 1)] : 128;
     } else if (lane < 37) {                                 // left column
         int r = lane - 21;
-        L.y[(r + 1) * IT_STRIDE + 3] = aL ? Y[(size_t)(Y0 + r) * g.w + X0 - 1] : 128;
+        L.y[(r + 1) * IT_STRIDE + 3] = aL ? F[luma_off(g, X0 - 1, Y0 + r)] : 128;
     } else if (lane < 55) {                                 // chroma top rows (corner + 8) of both planes
         int p = (lane - 37) / 9, x = (lane - 37) % 9 - 1;
         bool ok = x < 0 ? aTL : aT;
-        L.c[p][3 + x + 1] = ok ? (p ? V : U)[(size_t)(Y0 / 2 - 1) * g.cw + X0 / 2 + x] : 128;
+        L.c[p][3 + x + 1] = ok ? F[chroma_off(g, p, X0 / 2 + x, Y0 / 2 - 1)] : 128;
     }
     if (lane < 16) {                                        // chroma left columns
         int p = lane >> 3, r = lane & 7;
-        L.c[p][(r + 1) * CT_STRIDE + 3] = aL ? (p ? V : U)[(size_t)(Y0 / 2 + r) * g.cw + X0 / 2 - 1] : 128;
+        L.c[p][(r + 1) * CT_STRIDE + 3] = aL ? F[chroma_off(g, p, X0 / 2 - 1, Y0 / 2 + r)] : 128;
     }
     wave_lds_fence();
     if (!aTR && lane < 4) L.y[20 + lane] = L.y[19];         // top-right of the MB missing: replicate t15 (:706-709)
@@ -254,10 +254,11 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     // ---- write the macroblock out ----
     {
         int row = lane >> 2, d = lane & 3;
-        *(uint32_t *)(Y + (size_t)(Y0 + row) * g.w + X0 + d * 4) = *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4);
+        uint8_t *tile = F + (size_t)mbi * MB_TILE;             // lane (row, d) owns luma dword lane, (p, r, dd) chroma dword lane
+        *(uint32_t *)(tile + lane * 4) = *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4);
         if (lane < 32) {
             int p = lane >> 4, r = (lane >> 1) & 7, dd = lane & 1;
-            *(uint32_t *)((p ? V : U) + (size_t)(Y0 / 2 + r) * g.cw + X0 / 2 + dd * 4) = *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4);
+            *(uint32_t *)(tile + MB_TILE_U + lane * 4) = *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4);
         }
     }
 }

@@ -44,6 +44,23 @@ struct PicSlot {                       // one device-resident parsed picture
 
 #define BATCH_RING 4
 
+// tiled frame <-> planar staging (host boundary only): one thread per dword of the tiled frame
+__global__ void k_tile_convert(uint8_t *tiled, uint8_t *planar, Geom g, int to_planar)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n_mb * (MB_TILE / 4)) return;
+    const int mb = i / (MB_TILE / 4), d = i - mb * (MB_TILE / 4);
+    const int mx = mb % g.mb_w, my = mb / g.mb_w;
+    size_t po;
+    if (d < 64) po = (size_t)(my * 16 + (d >> 2)) * g.w + mx * 16 + (d & 3) * 4;
+    else {
+        const int e = d - 64, p = e >> 4, r = (e >> 1) & 7, dd = e & 1;
+        po = (size_t)g.w * g.h + (size_t)p * g.cw * g.ch + (size_t)(my * 8 + r) * g.cw + mx * 8 + dd * 4;
+    }
+    uint32_t *t = (uint32_t *)(tiled + (size_t)i * 4), *q = (uint32_t *)(planar + po);
+    if (to_planar) *q = *t; else *t = *q;
+}
+
 struct p264hip_ctx {
     int device = 0, n_cu = 256;
     hipStream_t stream = nullptr;
@@ -57,6 +74,7 @@ struct p264hip_ctx {
     int batch_cap = 0, ring = 0;
     int *d_status = nullptr;
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
+    uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
     bool timing = false;
     struct Stamp { hipEvent_t a, b; int k; };
     std::vector<Stamp> stamps;
@@ -85,9 +103,7 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     Geom &g = c->g;
     g.mb_w = mb_w; g.mb_h = mb_h; g.n_mb = mb_w * mb_h;
     g.w = mb_w * 16; g.h = mb_h * 16; g.cw = g.w / 2; g.ch = g.h / 2;
-    g.off_u = align_up((size_t)g.w * g.h, 256);
-    g.off_v = g.off_u + align_up((size_t)g.cw * g.ch, 256);
-    c->frame_bytes = g.off_v + align_up((size_t)g.cw * g.ch, 256) + 256;      // +256: dword loads may run past a row end
+    c->frame_bytes = align_up((size_t)g.n_mb * MB_TILE + MB_TILE, 256);        // macroblock-tiled (device_common.h), one spare tile
     c->pics.resize((size_t)max_pictures);
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -120,6 +136,7 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->frames) (void)hipFree(c->frames);
     if (c->d_edge) (void)hipFree(c->d_edge);
+    if (c->d_planar) (void)hipFree(c->d_planar);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -326,15 +343,26 @@ static int frame_io(p264hip_ctx *c, int stream, int slot, uint8_t *y, int ys, ui
     HIPCHK(hipSetDevice(c->device));
     int rc = p264hip_sync(c);
     if (rc) return rc;
+    // frames live macroblock-tiled on the device; the host sees planes, through a planar staging buffer
     uint8_t *f = frame_ptr(c, stream, slot);
     const Geom &g = c->g;
+    const size_t ysz = (size_t)g.w * g.h, csz = (size_t)g.cw * g.ch;
+    if (!c->d_planar) HIPCHK(hipMalloc((void **)&c->d_planar, ysz + 2 * csz));
+    uint8_t *s = c->d_planar;
     hipMemcpyKind k = read ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
     struct { uint8_t *host; int hs; uint8_t *dev; int w, h; } pl[3] = {
-        { y, ys, f, g.w, g.h }, { u, cs, f + g.off_u, g.cw, g.ch }, { v, cs, f + g.off_v, g.cw, g.ch } };
-    for (auto &p : pl) {
-        if (read) HIPCHK(hipMemcpy2D(p.host, (size_t)p.hs, p.dev, (size_t)p.w, (size_t)p.w, (size_t)p.h, k));
-        else      HIPCHK(hipMemcpy2D(p.dev, (size_t)p.w, p.host, (size_t)p.hs, (size_t)p.w, (size_t)p.h, k));
+        { y, ys, s, g.w, g.h }, { u, cs, s + ysz, g.cw, g.ch }, { v, cs, s + ysz + csz, g.cw, g.ch } };
+    const int n_dw = g.n_mb * (MB_TILE / 4);
+    if (read) {
+        hipLaunchKernelGGL(k_tile_convert, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, f, s, g, 1);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (auto &p : pl) HIPCHK(hipMemcpy2D(p.host, (size_t)p.hs, p.dev, (size_t)p.w, (size_t)p.w, (size_t)p.h, k));
+    } else {
+        for (auto &p : pl) HIPCHK(hipMemcpy2D(p.dev, (size_t)p.w, p.host, (size_t)p.hs, (size_t)p.w, (size_t)p.h, k));
+        hipLaunchKernelGGL(k_tile_convert, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, f, s, g, 0);
+        HIPCHK(hipStreamSynchronize(c->stream));
     }
+    HIPCHK(hipGetLastError());
     return P264HIP_OK;
 }
 

@@ -48,6 +48,22 @@ __device__ __forceinline__ uint32_t chroma_off(const Geom &g, int plane, int x, 
     return (uint32_t)((y >> 3) * g.mb_w + (x >> 3)) * MB_TILE + (uint32_t)(MB_TILE_U + plane * 64 + (y & 7) * 8 + (x & 7));
 }
 
+// ---- global-memory accessors ------------------------------------------------------------
+// Pointers that reach a kernel through memory (the fields of PicDev) are "flat" to the compiler:
+// it cannot prove they are not LDS or scratch, emits flat_load/flat_store, and has to wait for
+// vmcnt AND lgkmcnt on every use, which ties the global and LDS pipelines together.  Everything
+// those pointers address is HBM, so all accesses go through address-space-1 views.
+#define AS1 __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ AS1 T *glob(T *p) { return (AS1 T *)p; }
+__device__ __forceinline__ uint4 gload4(const void *p) { u32x4 v = *(const AS1 u32x4 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 gload2(const void *p) { u32x2 v = *(const AS1 u32x2 *)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint32_t gload1(const void *p) { return *(const AS1 uint32_t *)p; }
+__device__ __forceinline__ void gstore4(void *p, uint4 v) { u32x4 t = { v.x, v.y, v.z, v.w }; *(AS1 u32x4 *)p = t; }
+__device__ __forceinline__ void gstore2(void *p, uint2 v) { u32x2 t = { v.x, v.y }; *(AS1 u32x2 *)p = t; }
+__device__ __forceinline__ void gstore1(void *p, uint32_t v) { *(AS1 uint32_t *)p = v; }
+
 __device__ __forceinline__ int clip3i(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 

@@ -53,60 +53,60 @@ struct EdgeInfo {                  // 64 bytes per macroblock, written by k_debl
 // K4a
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info, int n_pics)
+void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info)
 {
-    // 32 lanes per macroblock (one per edge segment), 8 macroblocks per workgroup
-    const int t = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int pic = t / g.n_mb, mbi = t - pic * g.n_mb;
-    if (pic >= n_pics) return;
-    const PicDev *pd = pics + pic;
+    // grid = (mb_w / 8 rounded up, mb_h, pictures); 32 lanes per macroblock (one per edge segment), 8 macroblocks
+    // per workgroup.  The picture is uniform per workgroup, so its descriptor comes through scalar loads.
+    const PicDev *pd = pics + blockIdx.z;
     if (!pd->deblock) return;
+    const int mbx = blockIdx.x * 8 + (threadIdx.x >> 5), mby = blockIdx.y;
+    if (mbx >= g.mb_w) return;
+    const int mbi = mby * g.mb_w + mbx;
     const int lane = threadIdx.x & 31;
-    // lanes 0,1,2 fetch the records of this MB, its left and its top neighbour; everybody gets the few
-    // fields it needs by shuffle (width 32 = one macroblock)
+    const int dir = lane >> 4, e = (lane >> 2) & 3, i = lane & 3;
+    const bool outer = e == 0;
+    // the two 4x4 blocks either side of this lane's edge segment: p in the neighbour (or this MB), q in this MB
+    const int x = dir == 0 ? e : i, y = dir == 0 ? i : e;
+    const int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
+    const bool has_nb = dir == 0 ? mbx > 0 : mby > 0;
+    const int nbi = !outer ? mbi : !has_nb ? mbi : dir == 0 ? mbi - 1 : mbi - g.mb_w;
+    // every load of the kernel is issued here, before anything depends on one: a single round trip
     uint4 rec = make_uint4(0, 0, 0, 0);
     {
-        const uint4 *recs = (const uint4 *)pd->mb;
         int src = mbi;
-        if (lane == 1) src = mbi % g.mb_w > 0 ? mbi - 1 : mbi;
-        if (lane == 2) src = mbi >= g.mb_w ? mbi - g.mb_w : mbi;
-        if (lane < 3) rec = recs[src];
+        if (lane == 1) src = mbx > 0 ? mbi - 1 : mbi;
+        if (lane == 2) src = mby > 0 ? mbi - g.mb_w : mbi;
+        if (lane < 3) rec = gload4((const uint4 *)pd->mb + src);
     }
+    const AS1 int8_t *refs = glob(pd->ref_idx);
+    const AS1 int *mvs = glob(pd->mv);
+    const int rp = refs[mbi * 4 + (y >> 1) * 2 + (x >> 1)], rq = refs[nbi * 4 + (yn >> 1) * 2 + (xn >> 1)];
+    const int vp = mvs[mbi * 16 + y * 4 + x], vq = mvs[nbi * 16 + yn * 4 + xn];
+
     const unsigned m0 = __shfl((int)rec.x, 0, 32), mmask = __shfl((int)rec.y, 0, 32), mflags = __shfl((int)rec.w, 0, 32);
     const unsigned l0 = __shfl((int)rec.x, 1, 32), lmask = __shfl((int)rec.y, 1, 32);
     const unsigned t0 = __shfl((int)rec.x, 2, 32), tmask = __shfl((int)rec.y, 2, 32);
     const int m_type = m0 & 255, m_qp = (m0 >> 8) & 255, m_edges = (mflags >> 8) & 255;
     const bool fL = m_edges & P264_EDGE_LEFT, fT = m_edges & P264_EDGE_TOP;
-    EdgeInfo *out = info + (size_t)pic * g.n_mb + mbi;
+    EdgeInfo *out = info + (size_t)blockIdx.z * g.n_mb + mbi;
 
     // ---- boundary strengths, core/frame.c:535-581; lane = dir*16 + edge*4 + segment ----
     int bS = 0;
     {
-        const int dir = lane >> 4, e = (lane >> 2) & 3, i = lane & 3;
-        const bool outer = e == 0;
         const bool enabled = m_edges && (outer ? (dir == 0 ? fL : fT) : true);
         const int n_type = outer ? ((dir == 0 ? l0 : t0) & 255) : m_type;
         const unsigned n_mask = outer ? (dir == 0 ? lmask : tmask) : mmask;
-        const int nbi = outer ? (dir == 0 ? mbi - 1 : mbi - g.mb_w) : mbi;
         if (enabled) {
             if (P264_MB_IS_INTRA(m_type) || P264_MB_IS_INTRA(n_type)) bS = outer ? 4 : 3;
-            else {
-                int x = dir == 0 ? e : i, y = dir == 0 ? i : e;
-                int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
-                if (((mmask >> blk_at(x, y)) & 1) || ((n_mask >> blk_at(xn, yn)) & 1)) bS = 2;
-                else {
-                    int rp = pd->ref_idx[mbi * 4 + (y >> 1) * 2 + (x >> 1)], rq = pd->ref_idx[nbi * 4 + (yn >> 1) * 2 + (xn >> 1)];
-                    int vp = pd->mv[mbi * 16 + y * 4 + x], vq = pd->mv[nbi * 16 + yn * 4 + xn];
-                    bS = (rp != rq || abs((int)(int16_t)vp - (int)(int16_t)vq) >= 4 || abs((vp >> 16) - (vq >> 16)) >= 4) ? 1 : 0;
-                }
-            }
+            else if (((mmask >> blk_at(x, y)) & 1) || ((n_mask >> blk_at(xn, yn)) & 1)) bS = 2;
+            else bS = (rp != rq || abs((int)(int16_t)vp - (int)(int16_t)vq) >= 4 || abs((vp >> 16) - (vq >> 16)) >= 4) ? 1 : 0;
         }
     }
     // pack 8 nibbles per word: lanes 8w .. 8w+7 -> word w; lane 0 writes all four
     uint32_t word = (uint32_t)bS << (4 * (lane & 7));
     word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
     const uint32_t w1 = __shfl((int)word, 8, 32), w2 = __shfl((int)word, 16, 32), w3 = __shfl((int)word, 24, 32);
-    if (lane == 0) *(uint4 *)out->bs = make_uint4(word, w1, w2, w3);
+    if (lane == 0) gstore4(out->bs, make_uint4(word, w1, w2, w3));
     const bool any = (word | w1 | w2 | w3) != 0;
 
     // ---- per edge class: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted: A-Q3) ----
@@ -120,54 +120,7 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
         uint32_t lo = (uint32_t)c_alpha[ia] | ((uint32_t)c_beta[clip3i(q + pd->beta_off, 0, 51)] << 8) |
                       ((uint32_t)(c_tc0[ia][0] + chroma) << 16) | ((uint32_t)(c_tc0[ia][1] + chroma) << 24);
         uint32_t hi = (uint32_t)(c_tc0[ia][2] + chroma) | ((uint32_t)(any ? 1 : 0) << 8);
-        *(uint2 *)&out->cls[lane] = make_uint2(lo, hi);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// sample filters on register values
-// ------------------------------------------------------------------------------------------
-// One line across one edge: p[0..3] = p0..p3, q[0..3] = q0..q3 (ints), updated in place.
-// bS < 4: core/frame.c:302-341 (luma) / 351-377 (chroma); bS == 4: :387-462.
-__device__ __forceinline__ void filter_luma(int (&p)[4], int (&q)[4], int bS, int alpha, int beta, int tc0)
-{
-    const int p0 = p[0], p1 = p[1], p2 = p[2], q0 = q[0], q1 = q[1], q2 = q[2];
-    if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
-    if (bS < 4) {
-        int tc = tc0;
-        if (abs(p2 - p0) < beta) { p[1] = p1 + clip3i(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0); tc++; }
-        if (abs(q2 - q0) < beta) { q[1] = q1 + clip3i(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0); tc++; }
-        int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-        p[0] = clip255(p0 + delta);
-        q[0] = clip255(q0 - delta);
-    } else {
-        if (abs(p0 - q0) < ((alpha >> 2) + 2)) {
-            if (abs(p2 - p0) < beta) {
-                p[0] = (p2 + 2*p1 + 2*p0 + 2*q0 + q1 + 4) >> 3;
-                p[1] = (p2 + p1 + p0 + q0 + 2) >> 2;
-                p[2] = (2*p[3] + 3*p2 + p1 + p0 + q0 + 4) >> 3;
-            } else p[0] = (2*p1 + p0 + q1 + 2) >> 2;
-            if (abs(q2 - q0) < beta) {
-                q[0] = (p1 + 2*p0 + 2*q0 + 2*q1 + q2 + 4) >> 3;
-                q[1] = (p0 + q0 + q1 + q2 + 2) >> 2;
-                q[2] = (2*q[3] + 3*q2 + q1 + q0 + p0 + 4) >> 3;
-            } else q[0] = (2*q1 + q0 + p1 + 2) >> 2;
-        } else {
-            p[0] = (2*p1 + p0 + q1 + 2) >> 2;
-            q[0] = (2*q1 + q0 + p1 + 2) >> 2;
-        }
-    }
-}
-__device__ __forceinline__ void filter_chroma(int &p0, int p1, int &q0, int q1, int bS, int alpha, int beta, int tc)
-{
-    if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
-    if (bS < 4) {
-        int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-        int np = clip255(p0 + delta), nq = clip255(q0 - delta);
-        p0 = np; q0 = nq;
-    } else {
-        int np = (2*p1 + p0 + q1 + 2) >> 2, nq = (2*q1 + q0 + p1 + 2) >> 2;
-        p0 = np; q0 = nq;
+        gstore2(&out->cls[lane], make_uint2(lo, hi));
     }
 }
 
@@ -352,13 +305,13 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             if (actn) {
-                if (j < 4) fE = ((const uint4 *)(pinfo + row * g.mb_w + x))[j];
+                if (j < 4) fE = gload4((const uint4 *)(pinfo + row * g.mb_w + x) + j);
                 if (from_above) {
-                    if (j < 4) fT = *(const uint4 *)(topP + x * MB_TILE);
-                    else { uint2 v2 = *(const uint2 *)(topP + x * MB_TILE); fT.x = v2.x; fT.y = v2.y; }
+                    if (j < 4) fT = gload4(topP + x * MB_TILE);
+                    else { uint2 v2 = gload2(topP + x * MB_TILE); fT.x = v2.x; fT.y = v2.y; }
                 }
-                fYa = *(const uint4 *)(ownY + x * MB_TILE); fYb = *(const uint4 *)(ownY + x * MB_TILE + 16);
-                fC = *(const uint4 *)(ownC + x * MB_TILE);
+                fYa = gload4(ownY + x * MB_TILE); fYb = gload4(ownY + x * MB_TILE + 16);
+                fC = gload4(ownC + x * MB_TILE);
             }
         };
 
@@ -386,8 +339,8 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
             if (flush && top_exists && !EXPD_NOSTORE) {
                 const uint32_t *pr = L.ring[(x - 1) & 3];
-                if (j < 4) *(uint4 *)(topP + (x - 1) * MB_TILE) = *(const uint4 *)(pr + j * 4);
-                else *(uint2 *)(topP + (x - 1) * MB_TILE) = *(const uint2 *)(pr + 16 + (j - 4) * 2);
+                if (j < 4) gstore4(topP + (x - 1) * MB_TILE, *(const uint4 *)(pr + j * 4));
+                else gstore2(topP + (x - 1) * MB_TILE, *(const uint2 *)(pr + 16 + (j - 4) * 2));
             }
             EdgeRegs E;
             {
@@ -445,9 +398,9 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 sa.w = ya[0]; sb.w = yb[0]; ta.y = ca[0]; tb.y = cb[0];
                 uint32_t *nr = Lnext.ring[(x - 1) & 3];
                 if (below_in_band && j >= 6) { *(uint4 *)(nr + (2 * j - 12) * 4) = sa; *(uint4 *)(nr + (2 * j - 11) * 4) = sb; }
-                else if (!EXPD_NOSTORE) { *(uint4 *)(ownY + (x - 1) * MB_TILE) = sa; *(uint4 *)(ownY + (x - 1) * MB_TILE + 16) = sb; }
+                else if (!EXPD_NOSTORE) { gstore4(ownY + (x - 1) * MB_TILE, sa); gstore4(ownY + (x - 1) * MB_TILE + 16, sb); }
                 if (below_in_band && (j & 3) == 3) { *(uint2 *)(nr + 16 + cp * 4) = ta; *(uint2 *)(nr + 16 + cp * 4 + 2) = tb; }
-                else if (!EXPD_NOSTORE) *(uint4 *)(ownC + (x - 1) * MB_TILE) = make_uint4(ta.x, ta.y, tb.x, tb.y);
+                else if (!EXPD_NOSTORE) gstore4(ownC + (x - 1) * MB_TILE, make_uint4(ta.x, ta.y, tb.x, tb.y));
             }
             wave_lds_fence();
             // ---------- rows of macroblock x -> tile ----------

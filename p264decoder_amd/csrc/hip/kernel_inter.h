@@ -35,7 +35,7 @@
 typedef const __attribute__((address_space(1))) uint32_t *gu32p;
 #define WLOAD(p) __builtin_nontemporal_load((gu32p)(const uint32_t *)(p))
 #else
-#define WLOAD(p) (*(const uint32_t *)(p))
+#define WLOAD(p) gload1(p)
 #endif
 #ifndef EXP_NORESID
 #define EXP_NORESID 0
@@ -159,8 +159,8 @@ struct ClampedPlane {
     __device__ __forceinline__ int operator()(int x, int y) const
     {
         x = clip3i(x, 0, w - 1); y = clip3i(y, 0, h - 1);
-        if (plane < 0) return p[(uint32_t)((y >> 4) * mb_w + (x >> 4)) * MB_TILE + (y & 15) * 16 + (x & 15)];
-        return p[(uint32_t)((y >> 3) * mb_w + (x >> 3)) * MB_TILE + MB_TILE_U + plane * 64 + (y & 7) * 8 + (x & 7)];
+        if (plane < 0) return glob(p)[(uint32_t)((y >> 4) * mb_w + (x >> 4)) * MB_TILE + (y & 15) * 16 + (x & 15)];
+        return glob(p)[(uint32_t)((y >> 3) * mb_w + (x >> 3)) * MB_TILE + MB_TILE_U + plane * 64 + (y & 7) * 8 + (x & 7)];
     }
 };
 // Deliberately rolled loops: this path is rare (sub-8x8 partitions, windows crossing the left/right
@@ -284,13 +284,13 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     const PicDev *pd = pics + pic;
 
     // ---------------- header: everything wave-uniform goes to SGPRs ----------------
-    const uint4 rec = *(const uint4 *)(pd->mb + mbi);
+    const uint4 rec = gload4(pd->mb + mbi);
     const unsigned w0 = (unsigned)rfl((int)rec.x), mask = (unsigned)rfl((int)rec.y);
     const int mb_type = w0 & 255, qp = (w0 >> 8) & 255, cbp = (w0 >> 16) & 255;
     if (P264_MB_IS_INTRA(mb_type)) return;
     const int16_t *cf = pd->coefs + (size_t)(unsigned)rfl((int)rec.z) * 16;
-    const int mvreg = lane < 16 ? pd->mv[mbi * 16 + lane] : 0;
-    const int refs4 = rfl(*(const int *)(pd->ref_idx + mbi * 4));
+    const int mvreg = lane < 16 ? glob(pd->mv)[mbi * 16 + lane] : 0;
+    const int refs4 = rfl((int)gload1(pd->ref_idx + mbi * 4));
     const int n_ref = pd->n_ref;
 
     InterLds &L = lds[wave];
@@ -302,10 +302,10 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     uint2 lc = make_uint2(0, 0); uint32_t cc = 0; int cdc = 0;
     if (mask) {
         int lb = lane >> 2;
-        if ((mask >> lb) & 1) lc = *(const uint2 *)(cf + coef_slot(mask, lb) * 16 + (lane & 3) * 4);
+        if ((mask >> lb) & 1) lc = gload2(cf + coef_slot(mask, lb) * 16 + (lane & 3) * 4);
         int cb = 16 + (lane >> 3);
-        if ((mask >> cb) & 1) cc = *(const uint32_t *)(cf + coef_slot(mask, cb) * 16 + (lane & 7) * 2);
-        if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdc = cf[((mask >> 24) & 1) * 16 + lane];
+        if ((mask >> cb) & 1) cc = gload1(cf + coef_slot(mask, cb) * 16 + (lane & 7) * 2);
+        if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdc = glob(cf)[((mask >> 24) & 1) * 16 + lane];
     }
 
     if (EXP_HDRONLY) { if (mvreg == 0x7fffffff) pd->dst[0] = 1; return; }
@@ -471,6 +471,6 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     // (tiled frame: luma dword (row, dw) sits at lane*4, chroma dword (plane, row, dw) at 256 + lane*4 - the
     // macroblock goes out as three whole cache lines)
     uint8_t *tile = pd->dst + (size_t)mbi * MB_TILE;
-    *(uint32_t *)(tile + lane * 4) = outY;
-    if (lane < 32) *(uint32_t *)(tile + MB_TILE_U + lane * 4) = outC;
+    gstore1(tile + lane * 4, outY);
+    if (lane < 32) gstore1(tile + MB_TILE_U + lane * 4, outC);
 }

@@ -75,24 +75,24 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     const bool aTR = m.avail & P264_AVAIL_TOPRIGHT, aTL = m.avail & P264_AVAIL_TOPLEFT;
     uint8_t *F = pd->dst;                                  // macroblock-tiled frame (device_common.h)
     const unsigned mask = m.coef_mask;
-    const int16_t *cf = pd->coefs + (size_t)m.coef_index * 16;
+    const AS1 int16_t *cf = glob(pd->coefs) + (size_t)m.coef_index * 16;
 
     // ---- neighbour samples into the tiles; 128 where the neighbour does not exist ----
     if (lane < 21) {                                        // top row: corner, 16 top, 4 top-right
         int x = lane - 1;
         bool ok = x < 0 ? aTL : x < 16 ? aT : aTR;
-        L.y[3 + lane] = ok ? F[luma_off(g, X0 + x, Y0 - 1)] : 128;
+        L.y[3 + lane] = ok ? glob(F)[luma_off(g, X0 + x, Y0 - 1)] : 128;
     } else if (lane < 37) {                                 // left column
         int r = lane - 21;
-        L.y[(r + 1) * IT_STRIDE + 3] = aL ? F[luma_off(g, X0 - 1, Y0 + r)] : 128;
+        L.y[(r + 1) * IT_STRIDE + 3] = aL ? glob(F)[luma_off(g, X0 - 1, Y0 + r)] : 128;
     } else if (lane < 55) {                                 // chroma top rows (corner + 8) of both planes
         int p = (lane - 37) / 9, x = (lane - 37) % 9 - 1;
         bool ok = x < 0 ? aTL : aT;
-        L.c[p][3 + x + 1] = ok ? F[chroma_off(g, p, X0 / 2 + x, Y0 / 2 - 1)] : 128;
+        L.c[p][3 + x + 1] = ok ? glob(F)[chroma_off(g, p, X0 / 2 + x, Y0 / 2 - 1)] : 128;
     }
     if (lane < 16) {                                        // chroma left columns
         int p = lane >> 3, r = lane & 7;
-        L.c[p][(r + 1) * CT_STRIDE + 3] = aL ? F[chroma_off(g, p, X0 / 2 - 1, Y0 / 2 + r)] : 128;
+        L.c[p][(r + 1) * CT_STRIDE + 3] = aL ? glob(F)[chroma_off(g, p, X0 / 2 - 1, Y0 / 2 + r)] : 128;
     }
     wave_lds_fence();
     if (!aTR && lane < 4) L.y[20 + lane] = L.y[19];         // top-right of the MB missing: replicate t15 (:706-709)
@@ -150,7 +150,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         {
             int b = lane >> 2;                                                   // block in decode order
             bool present = (mask >> b) & 1;
-            const int16_t *src = cf + coef_slot(mask, b) * 16;
+            const AS1 int16_t *src = cf + coef_slot(mask, b) * 16;
             for (int kk = 0; kk < 4; kk++) {
                 int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
                 int v = k == 0 ? L.dc[blk_y(b) * 4 + blk_x(b)] : dequant_coef(present ? src[k - 1] : 0, pos, m.qp);
@@ -172,7 +172,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
             const bool left = bx > 0 || aL, top = by > 0 || aT;
             const bool topleft = (bx > 0 && by > 0) ? true : bx > 0 ? aT : by > 0 ? aL : aTL;
             const bool topright = by == 0 ? (bx < 3 ? aT : aTR) : (0x5744 >> i) & 1;   // core/macroblock.c:1210-1231
-            int mode = pd->i4modes[mbi * 16 + i];
+            int mode = glob(pd->i4modes)[mbi * 16 + i];
             if (mode == 2) mode = (left && top) ? 2 : left ? 9 : top ? 10 : 11;       // :677-695
             const uint8_t *o = L.y + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
             int l[4], t[8], lt;
@@ -200,7 +200,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         const int px = lane & 7, py = lane >> 3;
         const unsigned cmask = m.cbp >> 4 ? 15u : 0u;
         const int qpc = c_chroma_qp[clip3i(m.qp + pd->chroma_qp_offset, 0, 51)];
-        const int16_t *dcp = cf + ((mask >> 24) & 1) * 16;
+        const AS1 int16_t *dcp = cf + ((mask >> 24) & 1) * 16;
         const int j = lane >> 4, k = lane & 15, pos = c_zigzag[k];
         for (int p = 0; p < 2; p++) {
             const uint8_t *top = L.c[p] + 4, *tile = L.c[p] + CT_STRIDE;
@@ -255,10 +255,10 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     {
         int row = lane >> 2, d = lane & 3;
         uint8_t *tile = F + (size_t)mbi * MB_TILE;             // lane (row, d) owns luma dword lane, (p, r, dd) chroma dword lane
-        *(uint32_t *)(tile + lane * 4) = *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4);
+        gstore1(tile + lane * 4, *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4));
         if (lane < 32) {
             int p = lane >> 4, r = (lane >> 1) & 7, dd = lane & 1;
-            *(uint32_t *)(tile + MB_TILE_U + lane * 4) = *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4);
+            gstore1(tile + MB_TILE_U + lane * 4, *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4));
         }
     }
 }
@@ -276,7 +276,7 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
         for (int base = 0; base < g.mb_w; base += 64) {
             // which of the next 64 macroblocks of this row are intra?
             int x = base + lane;
-            bool intra = x < g.mb_w && P264_MB_IS_INTRA(pd->mb[row * g.mb_w + x].mb_type);
+            bool intra = x < g.mb_w && P264_MB_IS_INTRA(glob(pd->mb)[row * g.mb_w + x].mb_type);
             unsigned long long todo = __ballot(intra);
             while (todo) {
                 int bit = __ffsll((long long)todo) - 1;
@@ -286,12 +286,12 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                 // Only intra neighbours in the row above can still be in flight (inter MBs were finished by
                 // k_inter), so the wavefront dependency only bites where intra macroblocks touch.
                 if (row > 0 && ok) {
-                    const p264hip_mb_t *up = pd->mb + mbi - g.mb_w;
+                    const AS1 p264hip_mb_t *up = glob(pd->mb) + mbi - g.mb_w;
                     bool dep = P264_MB_IS_INTRA(up[0].mb_type) || (mbx > 0 && P264_MB_IS_INTRA(up[-1].mb_type)) ||
                                (mbx + 1 < g.mb_w && P264_MB_IS_INTRA(up[1].mb_type));
                     if (dep) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
                 }
-                intra_mb(pd, g, lds[wave], mbi, pd->mb[mbi], lane);
+                intra_mb(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, gload4(pd->mb + mbi)), lane);
             }
         }
         row_publish(sync, row, g.mb_w);

@@ -52,75 +52,88 @@ struct EdgeInfo {                  // 64 bytes per macroblock, written by k_debl
 // ------------------------------------------------------------------------------------------
 // K4a
 // ------------------------------------------------------------------------------------------
+struct BsLoads { uint4 rec; int rp, rq, vp, vq; };
+
 __global__ __launch_bounds__(256)
 void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info)
 {
-    // grid = (mb_w / 8 rounded up, mb_h, pictures); 32 lanes per macroblock (one per edge segment), 8 macroblocks
-    // per workgroup.  The picture is uniform per workgroup, so its descriptor comes through scalar loads.
-    const PicDev *pd = pics + blockIdx.z;
+    // grid = (mb_h, pictures): a workgroup walks one macroblock row, 32 lanes per macroblock (one per edge
+    // segment), 8 macroblocks at a time.  The picture is uniform per workgroup, so its descriptor comes through
+    // scalar loads, and the loads of the next 8 macroblocks are in flight while these 8 are worked out.
+    const PicDev *pd = pics + blockIdx.y;
     if (!pd->deblock) return;
-    const int mbx = blockIdx.x * 8 + (threadIdx.x >> 5), mby = blockIdx.y;
-    if (mbx >= g.mb_w) return;
-    const int mbi = mby * g.mb_w + mbx;
+    const int mby = blockIdx.x, grp = threadIdx.x >> 5;
     const int lane = threadIdx.x & 31;
     const int dir = lane >> 4, e = (lane >> 2) & 3, i = lane & 3;
     const bool outer = e == 0;
     // the two 4x4 blocks either side of this lane's edge segment: p in the neighbour (or this MB), q in this MB
     const int x = dir == 0 ? e : i, y = dir == 0 ? i : e;
     const int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
-    const bool has_nb = dir == 0 ? mbx > 0 : mby > 0;
-    const int nbi = !outer ? mbi : !has_nb ? mbi : dir == 0 ? mbi - 1 : mbi - g.mb_w;
-    // every load of the kernel is issued here, before anything depends on one: a single round trip
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    {
+    const AS1 int8_t *refs = glob(pd->ref_idx);
+    const AS1 int *mvs = glob(pd->mv);
+    const uint4 *recs = (const uint4 *)pd->mb;
+    const int chroma_qp_offset = pd->chroma_qp_offset, alpha_off = pd->alpha_off, beta_off = pd->beta_off;
+
+    // every load of a macroblock is issued together, before anything depends on one: a single round trip
+    auto fetch = [&](int mbx) {
+        BsLoads f;
+        const int mbi = mby * g.mb_w + min(mbx, g.mb_w - 1);
+        const bool has_nb = dir == 0 ? mbx > 0 : mby > 0;
+        const int nbi = !outer ? mbi : !has_nb ? mbi : dir == 0 ? mbi - 1 : mbi - g.mb_w;
         int src = mbi;
         if (lane == 1) src = mbx > 0 ? mbi - 1 : mbi;
         if (lane == 2) src = mby > 0 ? mbi - g.mb_w : mbi;
-        if (lane < 3) rec = gload4((const uint4 *)pd->mb + src);
-    }
-    const AS1 int8_t *refs = glob(pd->ref_idx);
-    const AS1 int *mvs = glob(pd->mv);
-    const int rp = refs[mbi * 4 + (y >> 1) * 2 + (x >> 1)], rq = refs[nbi * 4 + (yn >> 1) * 2 + (xn >> 1)];
-    const int vp = mvs[mbi * 16 + y * 4 + x], vq = mvs[nbi * 16 + yn * 4 + xn];
+        f.rec = make_uint4(0, 0, 0, 0);
+        if (lane < 3) f.rec = gload4(recs + src);
+        f.rp = refs[mbi * 4 + (y >> 1) * 2 + (x >> 1)]; f.rq = refs[nbi * 4 + (yn >> 1) * 2 + (xn >> 1)];
+        f.vp = mvs[mbi * 16 + y * 4 + x];               f.vq = mvs[nbi * 16 + yn * 4 + xn];
+        return f;
+    };
 
-    const unsigned m0 = __shfl((int)rec.x, 0, 32), mmask = __shfl((int)rec.y, 0, 32), mflags = __shfl((int)rec.w, 0, 32);
-    const unsigned l0 = __shfl((int)rec.x, 1, 32), lmask = __shfl((int)rec.y, 1, 32);
-    const unsigned t0 = __shfl((int)rec.x, 2, 32), tmask = __shfl((int)rec.y, 2, 32);
-    const int m_type = m0 & 255, m_qp = (m0 >> 8) & 255, m_edges = (mflags >> 8) & 255;
-    const bool fL = m_edges & P264_EDGE_LEFT, fT = m_edges & P264_EDGE_TOP;
-    EdgeInfo *out = info + (size_t)blockIdx.z * g.n_mb + mbi;
+    BsLoads nxt = fetch(grp);
+    for (int mbx = grp; mbx < g.mb_w; mbx += 8) {
+        const BsLoads f = nxt;
+        if (mbx + 8 < g.mb_w) nxt = fetch(mbx + 8);
+        const int mbi = mby * g.mb_w + mbx;
+        const unsigned m0 = __shfl((int)f.rec.x, 0, 32), mmask = __shfl((int)f.rec.y, 0, 32), mflags = __shfl((int)f.rec.w, 0, 32);
+        const unsigned l0 = __shfl((int)f.rec.x, 1, 32), lmask = __shfl((int)f.rec.y, 1, 32);
+        const unsigned t0 = __shfl((int)f.rec.x, 2, 32), tmask = __shfl((int)f.rec.y, 2, 32);
+        const int m_type = m0 & 255, m_qp = (m0 >> 8) & 255, m_edges = (mflags >> 8) & 255;
+        const bool fL = m_edges & P264_EDGE_LEFT, fT = m_edges & P264_EDGE_TOP;
+        EdgeInfo *out = info + (size_t)blockIdx.y * g.n_mb + mbi;
 
-    // ---- boundary strengths, core/frame.c:535-581; lane = dir*16 + edge*4 + segment ----
-    int bS = 0;
-    {
-        const bool enabled = m_edges && (outer ? (dir == 0 ? fL : fT) : true);
-        const int n_type = outer ? ((dir == 0 ? l0 : t0) & 255) : m_type;
-        const unsigned n_mask = outer ? (dir == 0 ? lmask : tmask) : mmask;
-        if (enabled) {
-            if (P264_MB_IS_INTRA(m_type) || P264_MB_IS_INTRA(n_type)) bS = outer ? 4 : 3;
-            else if (((mmask >> blk_at(x, y)) & 1) || ((n_mask >> blk_at(xn, yn)) & 1)) bS = 2;
-            else bS = (rp != rq || abs((int)(int16_t)vp - (int)(int16_t)vq) >= 4 || abs((vp >> 16) - (vq >> 16)) >= 4) ? 1 : 0;
+        // ---- boundary strengths, core/frame.c:535-581; lane = dir*16 + edge*4 + segment ----
+        int bS = 0;
+        {
+            const bool enabled = m_edges && (outer ? (dir == 0 ? fL : fT) : true);
+            const int n_type = outer ? ((dir == 0 ? l0 : t0) & 255) : m_type;
+            const unsigned n_mask = outer ? (dir == 0 ? lmask : tmask) : mmask;
+            if (enabled) {
+                if (P264_MB_IS_INTRA(m_type) || P264_MB_IS_INTRA(n_type)) bS = outer ? 4 : 3;
+                else if (((mmask >> blk_at(x, y)) & 1) || ((n_mask >> blk_at(xn, yn)) & 1)) bS = 2;
+                else bS = (f.rp != f.rq || abs((int)(int16_t)f.vp - (int)(int16_t)f.vq) >= 4 || abs((f.vp >> 16) - (f.vq >> 16)) >= 4) ? 1 : 0;
+            }
         }
-    }
-    // pack 8 nibbles per word: lanes 8w .. 8w+7 -> word w; lane 0 writes all four
-    uint32_t word = (uint32_t)bS << (4 * (lane & 7));
-    word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
-    const uint32_t w1 = __shfl((int)word, 8, 32), w2 = __shfl((int)word, 16, 32), w3 = __shfl((int)word, 24, 32);
-    if (lane == 0) gstore4(out->bs, make_uint4(word, w1, w2, w3));
-    const bool any = (word | w1 | w2 | w3) != 0;
+        // pack 8 nibbles per word: lanes 8w .. 8w+7 -> word w; lane 0 writes all four
+        uint32_t word = (uint32_t)bS << (4 * (lane & 7));
+        word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
+        const uint32_t w1 = __shfl((int)word, 8, 32), w2 = __shfl((int)word, 16, 32), w3 = __shfl((int)word, 24, 32);
+        if (lane == 0) gstore4(out->bs, make_uint4(word, w1, w2, w3));
+        const bool any = (word | w1 | w2 | w3) != 0;
 
-    // ---- per edge class: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted: A-Q3) ----
-    if (lane < 6) {
-        const int cls = lane % 3, chroma = lane / 3;
-        const int qp = m_qp, qpn = cls == EC_LEFT ? (int)((l0 >> 8) & 255) : cls == EC_TOP ? (int)((t0 >> 8) & 255) : m_qp;
-        int q;
-        if (!chroma) q = (qp + qpn + 1) >> 1;                                     // :593-595
-        else q = (c_chroma_qp[clip3i(qp + pd->chroma_qp_offset, 0, 51)] + c_chroma_qp[clip3i(qpn + pd->chroma_qp_offset, 0, 51)] + 1) >> 1;   // :600-601
-        const int ia = clip3i(q + pd->alpha_off, 0, 51);
-        uint32_t lo = (uint32_t)c_alpha[ia] | ((uint32_t)c_beta[clip3i(q + pd->beta_off, 0, 51)] << 8) |
-                      ((uint32_t)(c_tc0[ia][0] + chroma) << 16) | ((uint32_t)(c_tc0[ia][1] + chroma) << 24);
-        uint32_t hi = (uint32_t)(c_tc0[ia][2] + chroma) | ((uint32_t)(any ? 1 : 0) << 8);
-        gstore2(&out->cls[lane], make_uint2(lo, hi));
+        // ---- per edge class: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted: A-Q3) ----
+        if (lane < 6) {
+            const int cls = lane % 3, chroma = lane / 3;
+            const int qp = m_qp, qpn = cls == EC_LEFT ? (int)((l0 >> 8) & 255) : cls == EC_TOP ? (int)((t0 >> 8) & 255) : m_qp;
+            int q;
+            if (!chroma) q = (qp + qpn + 1) >> 1;                                     // :593-595
+            else q = (c_chroma_qp[clip3i(qp + chroma_qp_offset, 0, 51)] + c_chroma_qp[clip3i(qpn + chroma_qp_offset, 0, 51)] + 1) >> 1;   // :600-601
+            const int ia = clip3i(q + alpha_off, 0, 51);
+            uint32_t lo = (uint32_t)c_alpha[ia] | ((uint32_t)c_beta[clip3i(q + beta_off, 0, 51)] << 8) |
+                          ((uint32_t)(c_tc0[ia][0] + chroma) << 16) | ((uint32_t)(c_tc0[ia][1] + chroma) << 24);
+            uint32_t hi = (uint32_t)(c_tc0[ia][2] + chroma) | ((uint32_t)(any ? 1 : 0) << 8);
+            gstore2(&out->cls[lane], make_uint2(lo, hi));
+        }
     }
 }
 

@@ -49,6 +49,9 @@ typedef const __attribute__((address_space(1))) uint32_t *gu32p;
 #ifndef EXP_HDRONLY
 #define EXP_HDRONLY 0
 #endif
+#ifndef EXP_FORCE            // 1: every MB takes the whole-MB path, 2: every MB the quadrant path (timing experiments only)
+#define EXP_FORCE 0
+#endif
 
 #define YWIN_DW 56                // 13 rows x 4 dwords (+4 pad) per luma quadrant window
 #define CWIN_DW 10                // 5 rows x 2 dwords per chroma quadrant window
@@ -319,7 +322,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     const bool same_mv = __ballot(lane < 16 && mvreg != mv0) == 0 && (unsigned)refs4 == ((unsigned)(refs4 & 255) * 0x01010101u);
     const int ux0 = X0 + (mv_x(mv0) >> 2) - 2, ucx0 = X0 / 2 + (mv_x(mv0) >> 3);
 
-    if (same_mv && ux0 >= 0 && ux0 + 20 < g.w && ucx0 >= 0 && ucx0 + 8 < g.cw) {
+    if (EXP_FORCE != 2 && (EXP_FORCE == 1 || (same_mv && ux0 >= 0 && ux0 + 20 < g.w && ucx0 >= 0 && ucx0 + 8 < g.cw))) {
         // ======== one vector for the whole macroblock (16x16 partitions and P_SKIP) ========
         // luma window 21 rows x 6 dwords, chroma windows 2 x 9 rows x 3 dwords: three load instructions
         const uint8_t *rf = pd->ref[r0i];

@@ -286,7 +286,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     }
     {
         ScopedStamp t(c, 2);
-        hipLaunchKernelGGL(k_deblock_bs, dim3((g.mb_w + 7) / 8, g.mb_h, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge);
+        hipLaunchKernelGGL(k_deblock_bs, dim3(g.mb_h, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge);
         // a wavefront filters 8 macroblock rows at a time: 8 rows of one picture while there are no more
         // pictures than compute units, else 4 rows of two pictures (or 2 of four) per workgroup
         int rb_log2 = n > 3 * c->n_cu ? 1 : n > c->n_cu ? 2 : 3;

@@ -208,6 +208,24 @@ __device__ __forceinline__ int chroma_sample(const ClampedPlane &c, int sx, int 
     return ((8 - dx) * (8 - dy) * c(x, y) + dx * (8 - dy) * c(x + 1, y) + (8 - dx) * dy * c(x, y + 1) + dx * dy * c(x + 1, y + 1) + 32) >> 6;
 }
 
+// Window dwords on the padded plane.  The reference extends the picture by replicating its border
+// samples (core/frame.c:183-222, A-Q9); rows are clamped through y, and because dword loads are 4-aligned
+// and the plane widths are multiples of 8, a dword is either entirely inside the picture or entirely
+// outside: outside, it is the replicated first (last) byte of the row's first (last) dword.
+__device__ __forceinline__ uint32_t edge_fix(uint32_t v, int xa, int w)
+{
+    const uint32_t sel = xa < 0 ? 0x00000000u : xa >= w ? 0x03030303u : 0x03020100u;
+    return __builtin_amdgcn_perm(v, v, sel);
+}
+__device__ __forceinline__ uint32_t luma_dword(const uint8_t *ref, const Geom &g, int xa, int y)
+{
+    return edge_fix(WLOAD(ref + luma_off(g, clip3i(xa, 0, g.w - 4), clip3i(y, 0, g.h - 1))), xa, g.w);
+}
+__device__ __forceinline__ uint32_t chroma_dword(const uint8_t *ref, const Geom &g, int plane, int xa, int y)
+{
+    return edge_fix(WLOAD(ref + chroma_off(g, plane, clip3i(xa, 0, g.cw - 4), clip3i(y, 0, g.ch - 1))), xa, g.cw);
+}
+
 __device__ __forceinline__ int mv_x(int packed) { return (int)(int16_t)(packed & 0xffff); }
 __device__ __forceinline__ int mv_y(int packed) { return packed >> 16; }
 
@@ -271,8 +289,11 @@ __device__ __noinline__ uint32_t slow_chroma4(const uint8_t *ref, int w, int h, 
     return out;
 }
 
-__global__ __launch_bounds__(256)
-void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_blocks)
+#ifndef INTER_WAVES_PER_EU
+#define INTER_WAVES_PER_EU 8
+#endif
+__global__ __launch_bounds__(256, INTER_WAVES_PER_EU)
+void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_blocks, uint32_t inv_bpp, uint32_t inv_mbw)
 {
     __shared__ InterLds lds[4];
     // XCD-aware remap: the dispatcher deals workgroups round-robin over the 8 XCDs; give every XCD
@@ -281,23 +302,28 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= n_blocks) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pic = logical / blocks_per_pic;
+    // divisions by launch constants: multiply by the host's 2^32/d (+1), exact for these ranges
+    const int pic = blocks_per_pic == 1 ? logical : (int)__umulhi((unsigned)logical, inv_bpp);
     const int mbi = rfl((logical - pic * blocks_per_pic) * 4 + wave);
     if (mbi >= g.n_mb) return;
     const PicDev *pd = pics + pic;
 
     // ---------------- header: everything wave-uniform goes to SGPRs ----------------
+    // the three header loads go out together; nothing waits before all of them are in flight
     const uint4 rec = gload4(pd->mb + mbi);
+    const int mvreg_raw = glob(pd->mv)[mbi * 16 + (lane & 15)];
+    const int refs4_raw = (int)gload1(pd->ref_idx + mbi * 4);
+    const uint8_t *ref0 = pd->ref[0];                          // by far the most common reference: fetched with the descriptor
     const unsigned w0 = (unsigned)rfl((int)rec.x), mask = (unsigned)rfl((int)rec.y);
     const int mb_type = w0 & 255, qp = (w0 >> 8) & 255, cbp = (w0 >> 16) & 255;
     if (P264_MB_IS_INTRA(mb_type)) return;
     const int16_t *cf = pd->coefs + (size_t)(unsigned)rfl((int)rec.z) * 16;
-    const int mvreg = lane < 16 ? glob(pd->mv)[mbi * 16 + lane] : 0;
-    const int refs4 = rfl((int)gload1(pd->ref_idx + mbi * 4));
+    const int mvreg = lane < 16 ? mvreg_raw : 0;
+    const int refs4 = rfl(refs4_raw);
     const int n_ref = pd->n_ref;
 
     InterLds &L = lds[wave];
-    const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w;
+    const int mby = g.mb_w == 1 ? mbi : (int)__umulhi((unsigned)mbi, inv_mbw), mbx = mbi - mby * g.mb_w;
     const int X0 = mbx * 16, Y0 = mby * 16;
 
     // coded coefficients are fetched now, whatever path the prediction takes:
@@ -322,10 +348,10 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     const bool same_mv = __ballot(lane < 16 && mvreg != mv0) == 0 && (unsigned)refs4 == ((unsigned)(refs4 & 255) * 0x01010101u);
     const int ux0 = X0 + (mv_x(mv0) >> 2) - 2, ucx0 = X0 / 2 + (mv_x(mv0) >> 3);
 
-    if (EXP_FORCE != 2 && (EXP_FORCE == 1 || (same_mv && ux0 >= 0 && ux0 + 20 < g.w && ucx0 >= 0 && ucx0 + 8 < g.cw))) {
+    if (EXP_FORCE != 2 && (EXP_FORCE == 1 || same_mv)) {
         // ======== one vector for the whole macroblock (16x16 partitions and P_SKIP) ========
         // luma window 21 rows x 6 dwords, chroma windows 2 x 9 rows x 3 dwords: three load instructions
-        const uint8_t *rf = pd->ref[r0i];
+        const uint8_t *rf = r0i == 0 ? ref0 : pd->ref[r0i];
         const int lx = mv_x(mv0), ly = mv_y(mv0);
         uint32_t yv[2], cvv = 0;
 #pragma unroll
@@ -333,14 +359,12 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
             int i = lane + 64 * k, r = (i * 43) >> 8, d = i - r * 6;       // i / 6 for i < 128
             yv[k] = 0;
             if (i < 126 && !EXP_NOLOAD) {
-                int yy = clip3i(Y0 + (ly >> 2) - 2 + r, 0, g.h - 1);
-                yv[k] = WLOAD(rf + luma_off(g, (ux0 & ~3) + d * 4, yy));
+                yv[k] = luma_dword(rf, g, (ux0 & ~3) + d * 4, Y0 + (ly >> 2) - 2 + r);
             }
         }
         if (lane < 54 && !EXP_NOLOAD) {
             int p = lane >= 27, l2 = lane - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
-            int yy = clip3i(Y0 / 2 + (ly >> 3) + r, 0, g.ch - 1);
-            cvv = WLOAD(rf + chroma_off(g, p, (ucx0 & ~3) + d * 4, yy));
+            cvv = chroma_dword(rf, g, p, (ucx0 & ~3) + d * 4, Y0 / 2 + (ly >> 3) + r);
         }
         uint32_t *yw = &L.ywin[0][0], *cw = &L.cwin[0][0][0];
         yw[lane] = yv[0];
@@ -354,77 +378,75 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         if (lane < 32) outC = chroma4<3>(cw + cp * 27 + crow * 3, (ucx0 & 3) + cdw * 4, lx & 7, ly & 7);
 #endif
     } else {
-        // ======== general case: four 8x8 quadrants; all their windows are fetched at once ========
+        // ======== general case: four 8x8 quadrants with their own vectors ========
+        // Everything per quadrant stays in vector registers: a lane acts as (a) window loader of quadrant
+        // wq = lane>>4, (b) producer of a luma dword in quadrant lq, (c) producer of a chroma dword in quadrant cq.
         const int mvl = __shfl(mvreg, (row >> 2) * 4 + dw);
         const int mvA = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2), mvB = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2 + 1);
         const int lq = (row >> 3) * 2 + (dw >> 1), cq = (crow >> 2) * 2 + cdw;
-        int qmv[4]; const uint8_t *qref[4]; unsigned fast = 0;      // fully unrolled: SGPRs
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int b0 = (q >> 1) * 8 + (q & 1) * 2;      // raster 4x4 index of the quadrant's first block
-            qmv[q] = __builtin_amdgcn_readlane(mvreg, b0);
-            const bool uni = qmv[q] == __builtin_amdgcn_readlane(mvreg, b0 + 1) && qmv[q] == __builtin_amdgcn_readlane(mvreg, b0 + 4) &&
-                             qmv[q] == __builtin_amdgcn_readlane(mvreg, b0 + 5);
-            int ri = (int)(int8_t)(refs4 >> (8 * q));
-            if (ri < 0 || ri >= n_ref) ri = 0;
-            qref[q] = pd->ref[ri];
-            const int wx0 = X0 + (q & 1) * 8 + (mv_x(qmv[q]) >> 2) - 2, cx0 = X0 / 2 + (q & 1) * 4 + (mv_x(qmv[q]) >> 3);
-            if (uni && wx0 >= 0 && wx0 + 12 < g.w && cx0 >= 0 && cx0 + 4 < g.cw) fast |= 1u << q;
-        }
-        uint32_t yv[4], cv[2];
+        const int wq = lane >> 4, wl = lane & 15;
+        // quadrant q covers the 4x4 blocks b0, b0+1, b0+4, b0+5 (raster), b0 = (q>>1)*8 + (q&1)*2; lanes 0..15 hold the vectors
+        // (all three shuffles before any comparison: a shuffle inside a short-circuit branch would read lanes that are masked off)
+        const int mv_r = __shfl(mvreg, lane + 1), mv_d = __shfl(mvreg, lane + 4), mv_rd = __shfl(mvreg, lane + 5);
+        const bool quad_uni = (mvreg == mv_r) & (mvreg == mv_d) & (mvreg == mv_rd);
+        const unsigned uni_mask = (unsigned)__ballot(quad_uni);                      // bit b0(q) is meaningful
+        const int wb0 = (wq >> 1) * 8 + (wq & 1) * 2;
+        const int mvW = __shfl(mvreg, wb0);
+        int riW = (int)(int8_t)(refs4 >> (8 * wq));
+        if (riW < 0 || riW >= n_ref) riW = 0;
+        const uint8_t *refW = (const uint8_t *)glob((const uint64_t *)pd->ref)[riW];
+        const int wx0 = X0 + (wq & 1) * 8 + (mv_x(mvW) >> 2) - 2, wy0 = Y0 + (wq >> 1) * 8 + (mv_y(mvW) >> 2) - 2;
+        const int cx0 = X0 / 2 + (wq & 1) * 4 + (mv_x(mvW) >> 3), cy0 = Y0 / 2 + (wq >> 1) * 4 + (mv_y(mvW) >> 3);
+        const bool fastW = (uni_mask >> wb0) & 1;
+        const unsigned long long fast_lanes = __ballot(fastW);                       // 16 equal bits per quadrant
+        // ---- all windows at once: luma 13 rows x 4 dwords per quadrant (lane: dword wl&3 of rows (wl>>2) + 4k),
+        // chroma 5 rows x 2 dwords per quadrant and plane ----
         {
-            const int r = lane >> 2, d = lane & 3;           // luma: one instruction per quadrant, lanes 0..51
+            uint32_t yv[4], cv[2];
+            const int xa = (wx0 & ~3) + (wl & 3) * 4;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                yv[q] = 0;
-                if (((fast >> q) & 1) && lane < 52) {
-                    int wx0 = X0 + (q & 1) * 8 + (mv_x(qmv[q]) >> 2) - 2;
-                    int yy = clip3i(Y0 + (q >> 1) * 8 + (mv_y(qmv[q]) >> 2) - 2 + r, 0, g.h - 1);
-                    yv[q] = WLOAD(qref[q] + luma_off(g, (wx0 & ~3) + d * 4, yy));
-                }
+            for (int k = 0; k < 4; k++) {
+                const int r = (wl >> 2) + 4 * k;
+                yv[k] = 0;
+                if (fastW && r < 13) yv[k] = luma_dword(refW, g, xa, wy0 + r);
             }
-            const int q4 = lane >> 4, rr = lane & 15, cr = rr >> 1, cd = rr & 1;   // chroma: one instruction per plane, 16 lanes per quadrant
-            const int cmv = q4 == 0 ? qmv[0] : q4 == 1 ? qmv[1] : q4 == 2 ? qmv[2] : qmv[3];
-            const uint8_t *crf = q4 == 0 ? qref[0] : q4 == 1 ? qref[1] : q4 == 2 ? qref[2] : qref[3];
-            const int cx0 = X0 / 2 + (q4 & 1) * 4 + (mv_x(cmv) >> 3);
-            const int cyy = clip3i(Y0 / 2 + (q4 >> 1) * 4 + (mv_y(cmv) >> 3) + cr, 0, g.ch - 1);
-            const bool cok = ((fast >> q4) & 1) && rr < 10;
+            const int cr = wl >> 1, cxa = (cx0 & ~3) + (wl & 1) * 4;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 cv[p] = 0;
-                if (cok) cv[p] = WLOAD(crf + chroma_off(g, p, (cx0 & ~3) + cd * 4, cyy));
+                if (fastW && wl < 10) cv[p] = chroma_dword(refW, g, p, cxa, cy0 + cr);
             }
-        }
-        if (lane < 52) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) L.ywin[q][lane] = yv[q];
-        }
-        if ((lane & 15) < 10) {
-#pragma unroll
-            for (int p = 0; p < 2; p++) L.cwin[p][lane >> 4][lane & 15] = cv[p];
+            for (int k = 0; k < 4; k++) {
+                const int r = (wl >> 2) + 4 * k;
+                if (r < 13) L.ywin[wq][r * 4 + (wl & 3)] = yv[k];
+            }
+            if (wl < 10) { L.cwin[0][wq][wl] = cv[0]; L.cwin[1][wq][wl] = cv[1]; }
         }
         wave_lds_fence();
-        // one pass per distinct (vector, reference): the phase is wave-uniform inside a pass
+        // ---- one pass per distinct (vector, reference, path): the phase is wave-uniform inside a pass ----
         unsigned todo = 15;
-#pragma unroll
-        for (int q0 = 0; q0 < 4; q0++) {
-            if (!((todo >> q0) & 1)) continue;
-            unsigned group = 0;
-#pragma unroll
-            for (int q = q0; q < 4; q++)
-                if (qmv[q] == qmv[q0] && qref[q] == qref[q0] && ((fast >> q) & 1) == ((fast >> q0) & 1)) group |= 1u << q;
+#pragma unroll 1
+        while (todo) {
+            const int q0 = __ffs((int)todo) - 1;
+            const int b0 = (q0 >> 1) * 8 + (q0 & 1) * 2;
+            const int kmv = __builtin_amdgcn_readlane(mvreg, b0);
+            const int kri = __builtin_amdgcn_readlane(riW, q0 * 16);
+            const bool kfast = (fast_lanes >> (q0 * 16)) & 1;
+            const unsigned long long same = __ballot(mvW == kmv && riW == kri && fastW == kfast);
+            const unsigned group = (unsigned)(same & 1) | ((unsigned)(same >> 15) & 2) | ((unsigned)(same >> 30) & 4) | ((unsigned)(same >> 45) & 8);
             todo &= ~group;
-            if ((fast >> q0) & 1) {
-                const int lx = mv_x(qmv[q0]), ly = mv_y(qmv[q0]);
+            if (kfast) {
+                const int lx = mv_x(kmv), ly = mv_y(kmv);
                 if ((group >> lq) & 1)
                     outY = qpel4<4>(L.ywin[lq], (row & 7) + 2, ((X0 + (lx >> 2) - 2) & 3) + 2 + (dw & 1) * 4, lx & 3, ly & 3);
                 if (lane < 32 && ((group >> cq) & 1))
                     outC = chroma4<2>(L.cwin[cp][cq] + (crow & 3) * 2, (X0 / 2 + (lx >> 3)) & 3, lx & 7, ly & 7);
             } else {
-                // sub-8x8 partitions with differing vectors, or a window crossing the left/right
-                // picture edge: every lane samples the clamped plane with its own vectors
-                if ((group >> lq) & 1) outY = slow_luma4(qref[q0], g.w, g.h, g.mb_w, X0 + dw * 4, Y0 + row, mvl);
-                if (lane < 32 && ((group >> cq) & 1)) outC = slow_chroma4(qref[q0], g.cw, g.ch, g.mb_w, cp, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
+                // sub-8x8 partitions with differing vectors: every lane samples the clamped plane with its own vectors
+                const uint8_t *rf = pd->ref[kri];
+                if ((group >> lq) & 1) outY = slow_luma4(rf, g.w, g.h, g.mb_w, X0 + dw * 4, Y0 + row, mvl);
+                if (lane < 32 && ((group >> cq) & 1)) outC = slow_chroma4(rf, g.cw, g.ch, g.mb_w, cp, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
             }
         }
     }

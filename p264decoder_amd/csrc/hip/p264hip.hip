@@ -278,7 +278,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     if (any_p) {
         ScopedStamp t(c, 0);
         int per_pic = (g.n_mb + 3) / 4, n_blocks = per_pic * n, grid = (n_blocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(k_inter, dim3(grid), dim3(256), 0, c->stream, c->d_batch[r], g, per_pic, n_blocks);
+        hipLaunchKernelGGL(k_inter, dim3(grid), dim3(256), 0, c->stream, c->d_batch[r], g, per_pic, n_blocks,
+                           (uint32_t)((1ull << 32) / (unsigned)per_pic + 1), (uint32_t)((1ull << 32) / (unsigned)g.mb_w + 1));
     }
     {
         ScopedStamp t(c, 1);

@@ -252,21 +252,21 @@ struct OctLds {                    // per octet: 212 dwords
 #define MAX_BANDS (MAX_MB_ROWS / 2)
 
 __global__ __launch_bounds__(ROW_WAVES * 64)
-void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status, int n_pics, int rb_log2)
+void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status, int n_pics, int rb_log2, int pics_per_wg)
 {
     __shared__ int progress[MAX_PICS_PER_WG][MAX_BANDS];     // fully stored macroblocks of a band's last row
     __shared__ OctLds lds[ROW_WAVES][8];
     const Geom g = g_;
-    const int RB = 1 << rb_log2, P = 8 >> rb_log2;
+    const int RB = 1 << rb_log2;                               // pics_per_wg <= 8 >> rb_log2; octets beyond that idle
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     const int o = lane >> 3, j = lane & 7;
     const int gr = o & (RB - 1), pi = o >> rb_log2;           // row inside the band, picture inside the workgroup
     const int n_bands = (g.mb_h + RB - 1) >> rb_log2;
     for (int k = threadIdx.x; k < MAX_PICS_PER_WG * MAX_BANDS; k += blockDim.x) (&progress[0][0])[k] = 0;
     __syncthreads();
-    const int pic = blockIdx.x * P + pi;
+    const int pic = blockIdx.x * pics_per_wg + pi;
     const PicDev *pd = pics + min(pic, n_pics - 1);
-    const bool pic_ok = pic < n_pics && pd->deblock;
+    const bool pic_ok = pi < pics_per_wg && pic < n_pics && pd->deblock;
     OctLds &L = lds[wave][o];
     uint8_t *F = pd->dst;                                     // macroblock-tiled frame (device_common.h)
     const EdgeInfo *pinfo = info + (size_t)min(pic, n_pics - 1) * g.n_mb;

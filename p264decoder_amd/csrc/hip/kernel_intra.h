@@ -166,13 +166,26 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         wave_lds_fence();
     } else {
         // ---- I4x4: sixteen dependent blocks, 16 lanes each (decoder/macroblock.c:799-831) ----
+        // Nothing inside the block loop touches global memory: the 16 prediction modes sit in lanes 0..15, and all
+        // coded blocks are unscanned + dequantised into LDS up front (4 levels per lane, as in k_inter).
+        const int modebyte = glob(pd->i4modes)[mbi * 16 + (lane & 15)];
+        {
+            const int b = lane >> 2;
+            const bool present = (mask >> b) & 1;
+            const AS1 int16_t *src = cf + coef_slot(mask, b) * 16;
+            for (int kk = 0; kk < 4; kk++) {
+                int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
+                L.coef[b * 16 + pos] = (int16_t)dequant_coef(present ? src[k] : 0, pos, m.qp);
+            }
+        }
+        wave_lds_fence();
         const int x = lane & 3, y = (lane >> 2) & 3;
         for (int i = 0; i < 16; i++) {
             const int bx = blk_x(i), by = blk_y(i);
             const bool left = bx > 0 || aL, top = by > 0 || aT;
             const bool topleft = (bx > 0 && by > 0) ? true : bx > 0 ? aT : by > 0 ? aL : aTL;
             const bool topright = by == 0 ? (bx < 3 ? aT : aTR) : (0x5744 >> i) & 1;   // core/macroblock.c:1210-1231
-            int mode = glob(pd->i4modes)[mbi * 16 + i];
+            int mode = __builtin_amdgcn_readlane(modebyte, i);
             if (mode == 2) mode = (left && top) ? 2 : left ? 9 : top ? 10 : 11;       // :677-695
             const uint8_t *o = L.y + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
             int l[4], t[8], lt;
@@ -181,13 +194,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
             for (int k = 4; k < 8; k++) t[k] = topright ? o[-IT_STRIDE + k] : t[3];
             lt = topleft ? o[-IT_STRIDE - 1] : 128;
             int v = pred4x4_sample(mode, x, y, l, t, lt);
-            bool present = (mask >> i) & 1;
-            if (present) {
-                if (lane < 16) { int pos = c_zigzag[lane]; L.coef[pos] = (int16_t)dequant_coef(cf[coef_slot(mask, i) * 16 + lane], pos, m.qp); }
-                wave_lds_fence();
-                v = clip255(v + idct4x4_sample(L.coef, x, y));
-            }
-            wave_lds_fence();
+            if ((mask >> i) & 1) v = clip255(v + idct4x4_sample(L.coef + i * 16, x, y));
             if (lane < 16) L.y[(by * 4 + y + 1) * IT_STRIDE + 4 + bx * 4 + x] = (uint8_t)v;
             wave_lds_fence();
         }
@@ -274,23 +281,28 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
     bool ok = true;
     for (int row = wave; row < g.mb_h; row += ROW_WAVES) {
         for (int base = 0; base < g.mb_w; base += 64) {
-            // which of the next 64 macroblocks of this row are intra?
-            int x = base + lane;
-            bool intra = x < g.mb_w && P264_MB_IS_INTRA(glob(pd->mb)[row * g.mb_w + x].mb_type);
+            // which of the next 64 macroblocks of this row are intra, and which of them touch an intra macroblock of
+            // the row above?  Only those can still be in flight there (inter MBs were finished by k_inter), so the
+            // wavefront dependency only bites where intra macroblocks touch.  One batch of loads per 64 macroblocks.
+            const int x = base + lane;
+            const AS1 p264hip_mb_t *recs = glob(pd->mb) + row * g.mb_w;
+            bool intra = false, dep = false;
+            if (x < g.mb_w) {
+                intra = P264_MB_IS_INTRA(recs[x].mb_type);
+                if (row > 0) {
+                    const AS1 p264hip_mb_t *up = recs - g.mb_w;
+                    dep = P264_MB_IS_INTRA(up[x].mb_type) | P264_MB_IS_INTRA(up[max(x - 1, 0)].mb_type) |
+                          P264_MB_IS_INTRA(up[min(x + 1, g.mb_w - 1)].mb_type);
+                }
+            }
             unsigned long long todo = __ballot(intra);
+            const unsigned long long deps = __ballot(dep);
             while (todo) {
                 int bit = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 int mbx = base + bit, mbi = row * g.mb_w + mbx;
                 row_publish(sync, row, mbx);                                      // everything left of mbx is final
-                // Only intra neighbours in the row above can still be in flight (inter MBs were finished by
-                // k_inter), so the wavefront dependency only bites where intra macroblocks touch.
-                if (row > 0 && ok) {
-                    const AS1 p264hip_mb_t *up = glob(pd->mb) + mbi - g.mb_w;
-                    bool dep = P264_MB_IS_INTRA(up[0].mb_type) || (mbx > 0 && P264_MB_IS_INTRA(up[-1].mb_type)) ||
-                               (mbx + 1 < g.mb_w && P264_MB_IS_INTRA(up[1].mb_type));
-                    if (dep) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
-                }
+                if (((deps >> bit) & 1) && ok) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
                 intra_mb(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, gload4(pd->mb + mbi)), lane);
             }
         }

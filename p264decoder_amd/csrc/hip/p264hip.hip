@@ -292,10 +292,12 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // pictures than compute units, else 4 rows of two pictures (or 2 of four) per workgroup
         int rb_log2 = n > 3 * c->n_cu ? 1 : n > c->n_cu ? 2 : 3;
         if (const char *e = getenv("P264AMD_DEBLOCK_RB_LOG2")) { int v = atoi(e); if (v >= 1 && v <= 3) rb_log2 = v; }
-        const int per_wg = 8 >> rb_log2, n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
+        int per_wg = 8 >> rb_log2;
+        if (const char *e = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) { int v = atoi(e); if (v >= 1 && v <= per_wg) per_wg = v; }
+        const int n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
         const int waves = n_bands < ROW_WAVES ? n_bands : ROW_WAVES;
         hipLaunchKernelGGL(k_deblock, dim3((n + per_wg - 1) / per_wg), dim3(waves * 64), 0, c->stream, c->d_batch[r], g,
-                           (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2);
+                           (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2, per_wg);
     }
     HIPCHK(hipGetLastError());
     return P264HIP_OK;

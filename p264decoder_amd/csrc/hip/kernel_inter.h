@@ -302,8 +302,9 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= n_blocks) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // divisions by launch constants: multiply by the host's 2^32/d (+1), exact for these ranges
-    const int pic = blocks_per_pic == 1 ? logical : (int)__umulhi((unsigned)logical, inv_bpp);
+    // divisions by launch constants: multiply by the host's floor(2^32/d) and correct the estimate (never more than one short)
+    int pic = (int)__umulhi((unsigned)logical, inv_bpp);
+    if (logical - pic * blocks_per_pic >= blocks_per_pic) pic++;
     const int mbi = rfl((logical - pic * blocks_per_pic) * 4 + wave);
     if (mbi >= g.n_mb) return;
     const PicDev *pd = pics + pic;
@@ -323,7 +324,9 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     const int n_ref = pd->n_ref;
 
     InterLds &L = lds[wave];
-    const int mby = g.mb_w == 1 ? mbi : (int)__umulhi((unsigned)mbi, inv_mbw), mbx = mbi - mby * g.mb_w;
+    int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+    const int mbx = mbi - mby * g.mb_w;
     const int X0 = mbx * 16, Y0 = mby * 16;
 
     // coded coefficients are fetched now, whatever path the prediction takes:

@@ -279,7 +279,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         ScopedStamp t(c, 0);
         int per_pic = (g.n_mb + 3) / 4, n_blocks = per_pic * n, grid = (n_blocks + 7) / 8 * 8;
         hipLaunchKernelGGL(k_inter, dim3(grid), dim3(256), 0, c->stream, c->d_batch[r], g, per_pic, n_blocks,
-                           (uint32_t)((1ull << 32) / (unsigned)per_pic + 1), (uint32_t)((1ull << 32) / (unsigned)g.mb_w + 1));
+                           (uint32_t)(((1ull << 32) - 1) / (unsigned)per_pic), (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w));
     }
     {
         ScopedStamp t(c, 1);

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (written by profiles/collect.sh on the GPU box) into the committed summaries:
+  profiles/<tag>_bench.json          bench.py's JSON line
+  profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary (per-kernel calls / total / average ns)
+  profiles/<tag>_pmc.json            per-kernel, per-launch averages of every collected counter
+  profiles/traffic_latest.json       HBM bytes per launch per bench kernel name (read by bench.py -> roofline.traffic)
+HBM traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB as rocprofv3 reports them; FETCH_SIZE counts 128-byte requests as 64 bytes
+on gfx950 - MI355X_MICROARCH.md, section HBM)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+here = os.path.dirname(os.path.abspath(__file__))
+src = os.path.join(here, "..", "gpurun_out", tag)
+
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(here, tag + "_bench.json"))
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, os.path.join(here, tag + "_kernel_stats.csv"))
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("k_"):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# steady state only: the first launch of k_intra / k_deblock* is the IDR picture (all intra), k_inter has none for it
+pmc = {}
+for k, ctrs in agg.items():
+    pmc[k] = {}
+    for c, v in ctrs.items():
+        vals = v[1:] if k != "k_inter" and len(v) > 1 else v
+        pmc[k][c] = round(sum(vals) / len(vals))
+    pmc[k]["launches_averaged"] = len(vals)
+note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline` "
+        "(512 1080p pictures per launch), separate rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as reported")
+json.dump({"note": note, **pmc}, open(os.path.join(here, tag + "_pmc.json"), "w"), indent=1)
+
+def hbm(k):
+    return int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
+traffic = {"inter": hbm("k_inter"), "intra": hbm("k_intra"), "deblock": hbm("k_deblock") + hbm("k_deblock_bs"),
+           "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
+json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)
+print(json.dumps(traffic))
+print(open(os.path.join(here, tag + "_kernel_stats.csv")).read())

@@ -12,6 +12,7 @@
 // substituted in registers (128 / replicated t3) instead of being written into the frame as the
 // reference does (decoder/macroblock.c:697-713, SURVEY A-Q7).
 #pragma once
+#include <stddef.h>
 #include "device_common.h"
 #include "wavefront_sync.h"
 
@@ -67,38 +68,76 @@ __device__ __forceinline__ int pred4x4_sample(int mode, int x, int y, const int 
     return 128;
 }
 
-// Reconstruct one intra macroblock with one wavefront.
+// Reconstruct one intra macroblock with one wavefront.  Every global load the macroblock needs (neighbour samples,
+// prediction modes, coefficients of all three planes) is issued at the top, before anything waits: one memory round
+// trip per macroblock, everything after that runs out of registers and LDS.
 __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, const p264hip_mb_t m, int lane)
 {
     const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w, X0 = mbx * 16, Y0 = mby * 16;
     const bool aL = m.avail & P264_AVAIL_LEFT, aT = m.avail & P264_AVAIL_TOP;
     const bool aTR = m.avail & P264_AVAIL_TOPRIGHT, aTL = m.avail & P264_AVAIL_TOPLEFT;
     uint8_t *F = pd->dst;                                  // macroblock-tiled frame (device_common.h)
+    const AS1 uint8_t *Fg = glob(F);
     const unsigned mask = m.coef_mask;
     const AS1 int16_t *cf = glob(pd->coefs) + (size_t)m.coef_index * 16;
+    const bool is16 = m.mb_type == P264_MB_I16x16;
 
-    // ---- neighbour samples into the tiles; 128 where the neighbour does not exist ----
-    if (lane < 21) {                                        // top row: corner, 16 top, 4 top-right
+    // ---- (a) neighbour samples; 128 where the neighbour does not exist.  Role A: lanes 0..20 top row (corner, 16 top,
+    //      4 top-right), 21..36 left column, 37..54 chroma top rows (corner + 8) of both planes; role B: lanes 0..15
+    //      chroma left columns ----
+    uint32_t offA = 0, offB = 0; bool okA = false, okB = false;
+    uint8_t *const lds8 = (uint8_t *)&L;                   // byte offsets, so that the stores stay LDS stores
+    const int c_base = (int)offsetof(IntraLds, c), c_size = (int)sizeof(L.c[0]);
+    int dstA = 0, dstB = 0;
+    if (lane < 21) {
         int x = lane - 1;
-        bool ok = x < 0 ? aTL : x < 16 ? aT : aTR;
-        L.y[3 + lane] = ok ? glob(F)[luma_off(g, X0 + x, Y0 - 1)] : 128;
-    } else if (lane < 37) {                                 // left column
+        okA = x < 0 ? aTL : x < 16 ? aT : aTR;
+        offA = luma_off(g, X0 + x, Y0 - 1); dstA = 3 + lane;
+    } else if (lane < 37) {
         int r = lane - 21;
-        L.y[(r + 1) * IT_STRIDE + 3] = aL ? glob(F)[luma_off(g, X0 - 1, Y0 + r)] : 128;
-    } else if (lane < 55) {                                 // chroma top rows (corner + 8) of both planes
+        okA = aL; offA = luma_off(g, X0 - 1, Y0 + r); dstA = (r + 1) * IT_STRIDE + 3;
+    } else if (lane < 55) {
         int p = (lane - 37) / 9, x = (lane - 37) % 9 - 1;
-        bool ok = x < 0 ? aTL : aT;
-        L.c[p][3 + x + 1] = ok ? glob(F)[chroma_off(g, p, X0 / 2 + x, Y0 / 2 - 1)] : 128;
+        okA = x < 0 ? aTL : aT;
+        offA = chroma_off(g, p, X0 / 2 + x, Y0 / 2 - 1); dstA = c_base + p * c_size + 3 + x + 1;
     }
-    if (lane < 16) {                                        // chroma left columns
+    if (lane < 16) {
         int p = lane >> 3, r = lane & 7;
-        L.c[p][(r + 1) * CT_STRIDE + 3] = aL ? glob(F)[chroma_off(g, p, X0 / 2 - 1, Y0 / 2 + r)] : 128;
+        okB = aL; offB = chroma_off(g, p, X0 / 2 - 1, Y0 / 2 + r); dstB = c_base + p * c_size + (r + 1) * CT_STRIDE + 3;
     }
+    int vA = 128, vB = 128;
+    if (okA) vA = Fg[offA];
+    if (okB) vB = Fg[offB];
+    // ---- (b) luma levels: lane = (block lane>>2 in decode order, levels 4*(lane&3) .. +3 of its 16 slots) ----
+    const int lb = lane >> 2;
+    uint2 lv = make_uint2(0, 0);
+    if ((mask >> lb) & 1) lv = gload2(cf + coef_slot(mask, lb) * 16 + (lane & 3) * 4);
+    int ldc = 0;                                           // Intra16x16 DC levels, lanes 0..15
+    if (is16 && (mask & P264_COEF_LUMA_DC) && lane < 16) ldc = cf[lane];
+    // ---- (c) Intra4x4 prediction modes, lanes 0..15 ----
+    int modebyte = 0;
+    if (!is16) modebyte = glob(pd->i4modes)[mbi * 16 + (lane & 15)];
+    // ---- (d) chroma: AC level k-1 of block j = lane>>4 of each plane (k = lane&15), DC levels in lanes 0..7 ----
+    const bool has_chroma = (m.cbp >> 4) != 0;
+    int cac[2] = { 0, 0 }, cdcv = 0;
+    if (has_chroma) {
+        const int j = lane >> 4, k = lane & 15;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int blk = 16 + 4 * p + j;
+            if (k > 0 && ((mask >> blk) & 1)) cac[p] = cf[coef_slot(mask, blk) * 16 + k - 1];
+        }
+        if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdcv = cf[((mask >> 24) & 1) * 16 + lane];
+    }
+
+    // ---- land the neighbours ----
+    if (lane < 55) lds8[dstA] = (uint8_t)vA;
+    if (lane < 16) lds8[dstB] = (uint8_t)vB;
     wave_lds_fence();
     if (!aTR && lane < 4) L.y[20 + lane] = L.y[19];         // top-right of the MB missing: replicate t15 (:706-709)
     wave_lds_fence();
 
-    if (m.mb_type == P264_MB_I16x16) {
+    if (is16) {
         // ---- prediction: each lane 4 samples of one row ----
         int mode = m.intra_modes & 3;
         if (mode == 2) mode = aTL ? 2 : aL ? 4 : aT ? 5 : 6;                    // :635-667
@@ -125,7 +164,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
             for (int i = 0; i < 4; i++) pv[i] = s;
         }
         // ---- luma DC: unscan, idct4x4dc (core/dct.c:104-136), rounded dequant (core/quant.c:161-191) ----
-        if (lane < 16) L.dc[c_zigzag[lane]] = (mask & P264_COEF_LUMA_DC) ? cf[lane] : (int16_t)0;
+        if (lane < 16) L.dc[c_zigzag[lane]] = (int16_t)ldc;
         wave_lds_fence();
         int dcv = 0;
         if (lane < 16) {
@@ -146,15 +185,17 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         wave_lds_fence();
         if (lane < 16) L.dc[lane] = (int16_t)dcv;                                // raster (y*4+x) of the 4x4 block grid
         wave_lds_fence();
-        // ---- AC: 4 coefficients per lane, DC inserted at position 0 (:787-794) ----
+        // ---- AC: scan position k of the block holds level k-1 (the slots hold 15 AC levels), DC goes to position 0
+        // (:787-794).  This lane fetched levels 4q..4q+3 (q = lane&3); level 4q-1 comes from the lane before. ----
         {
-            int b = lane >> 2;                                                   // block in decode order
-            bool present = (mask >> b) & 1;
-            const AS1 int16_t *src = cf + coef_slot(mask, b) * 16;
+            const int e3 = (int)(int16_t)(lv.y >> 16);
+            const int prev = __shfl_up(e3, 1);
+            const int lev[4] = { prev, (int)(int16_t)(lv.x & 0xffff), (int)(int16_t)(lv.x >> 16), (int)(int16_t)(lv.y & 0xffff) };
+#pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
-                int v = k == 0 ? L.dc[blk_y(b) * 4 + blk_x(b)] : dequant_coef(present ? src[k - 1] : 0, pos, m.qp);
-                L.coef[b * 16 + pos] = (int16_t)v;
+                int v = k == 0 ? L.dc[blk_y(lb) * 4 + blk_x(lb)] : dequant_coef(lev[kk], pos, m.qp);
+                L.coef[lb * 16 + pos] = (int16_t)v;
             }
         }
         wave_lds_fence();
@@ -165,17 +206,14 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         }
         wave_lds_fence();
     } else {
-        // ---- I4x4: sixteen dependent blocks, 16 lanes each (decoder/macroblock.c:799-831) ----
-        // Nothing inside the block loop touches global memory: the 16 prediction modes sit in lanes 0..15, and all
-        // coded blocks are unscanned + dequantised into LDS up front (4 levels per lane, as in k_inter).
-        const int modebyte = glob(pd->i4modes)[mbi * 16 + (lane & 15)];
+        // ---- I4x4: sixteen dependent blocks, 16 lanes each (decoder/macroblock.c:799-831); all coded blocks are
+        // unscanned + dequantised into LDS first ----
         {
-            const int b = lane >> 2;
-            const bool present = (mask >> b) & 1;
-            const AS1 int16_t *src = cf + coef_slot(mask, b) * 16;
+            const int lev[4] = { (int)(int16_t)(lv.x & 0xffff), (int)(int16_t)(lv.x >> 16), (int)(int16_t)(lv.y & 0xffff), (int)(int16_t)(lv.y >> 16) };
+#pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
-                L.coef[b * 16 + pos] = (int16_t)dequant_coef(present ? src[k] : 0, pos, m.qp);
+                L.coef[lb * 16 + pos] = (int16_t)dequant_coef(lev[kk], pos, m.qp);
             }
         }
         wave_lds_fence();
@@ -205,9 +243,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         int mode = (m.intra_modes >> 4) & 3;
         if (mode == 0) mode = aTL ? 0 : aL ? 4 : aT ? 5 : 6;                     // :721-753
         const int px = lane & 7, py = lane >> 3;
-        const unsigned cmask = m.cbp >> 4 ? 15u : 0u;
         const int qpc = c_chroma_qp[clip3i(m.qp + pd->chroma_qp_offset, 0, 51)];
-        const AS1 int16_t *dcp = cf + ((mask >> 24) & 1) * 16;
         const int j = lane >> 4, k = lane & 15, pos = c_zigzag[k];
         for (int p = 0; p < 2; p++) {
             const uint8_t *top = L.c[p] + 4, *tile = L.c[p] + CT_STRIDE;
@@ -231,22 +267,18 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
                 else if (mode == 5) v = ((qd & 1) ? s1 + 2 : s0 + 2) >> 2;
                 else v = 128;
             }
-            if (cmask) {                                                          // residual, as in k_inter
+            if (has_chroma) {                                                     // residual, as in k_inter
+                // the four DC levels of plane p sit in lanes 4p .. 4p+3 (all shuffles before any use)
+                const int d0 = __shfl(cdcv, p * 4), d1 = __shfl(cdcv, p * 4 + 1), d2 = __shfl(cdcv, p * 4 + 2), d3 = __shfl(cdcv, p * 4 + 3);
                 int cv;
                 if (k == 0) {
-                    int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-                    if (mask & P264_COEF_CHROMA_DC) { d0 = dcp[p*4]; d1 = dcp[p*4+1]; d2 = dcp[p*4+2]; d3 = dcp[p*4+3]; }
                     int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
                     int f = j == 0 ? t0 + t2 : j == 1 ? t1 + t3 : j == 2 ? t0 - t2 : t1 - t3;
                     f = (int)(int16_t)f;
                     int qbits = qpc / 6 - 5, mf = c_dqmf[qpc % 6][0];
                     cv = qbits >= 0 ? f * (int)((unsigned)mf << qbits) : (f * mf) >> (-qbits);
                     cv = (int)(int16_t)cv;
-                } else {
-                    int blk = 16 + 4 * p + j;
-                    int c = (mask >> blk) & 1 ? cf[coef_slot(mask, blk) * 16 + k - 1] : 0;
-                    cv = dequant_coef(c, pos, qpc);
-                }
+                } else cv = dequant_coef(cac[p], pos, qpc);
                 L.coef[j * 16 + pos] = (int16_t)cv;
                 wave_lds_fence();
                 int jj = ((py >> 2) << 1) | (px >> 2);
@@ -287,8 +319,10 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
             const int x = base + lane;
             const AS1 p264hip_mb_t *recs = glob(pd->mb) + row * g.mb_w;
             bool intra = false, dep = false;
+            uint4 rec = make_uint4(0, 0, 0, 0);                                   // this lane's macroblock record
             if (x < g.mb_w) {
-                intra = P264_MB_IS_INTRA(recs[x].mb_type);
+                rec = gload4(pd->mb + row * g.mb_w + x);
+                intra = P264_MB_IS_INTRA(rec.x & 255);
                 if (row > 0) {
                     const AS1 p264hip_mb_t *up = recs - g.mb_w;
                     dep = P264_MB_IS_INTRA(up[x].mb_type) | P264_MB_IS_INTRA(up[max(x - 1, 0)].mb_type) |
@@ -303,7 +337,9 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                 int mbx = base + bit, mbi = row * g.mb_w + mbx;
                 row_publish(sync, row, mbx);                                      // everything left of mbx is final
                 if (((deps >> bit) & 1) && ok) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
-                intra_mb(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, gload4(pd->mb + mbi)), lane);
+                const uint4 mr = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)rec.x, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.y, bit),
+                                            (uint32_t)__builtin_amdgcn_readlane((int)rec.z, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.w, bit));
+                intra_mb(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane);
             }
         }
         row_publish(sync, row, g.mb_w);

@@ -71,7 +71,7 @@ __device__ __forceinline__ int pred4x4_sample(int mode, int x, int y, const int 
 // Reconstruct one intra macroblock with one wavefront.  Every global load the macroblock needs (neighbour samples,
 // prediction modes, coefficients of all three planes) is issued at the top, before anything waits: one memory round
 // trip per macroblock, everything after that runs out of registers and LDS.
-__device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, const p264hip_mb_t m, int lane)
+__device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, const p264hip_mb_t m, int lane, RowSync &sync, int row_publish_as)
 {
     const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w, X0 = mbx * 16, Y0 = mby * 16;
     const bool aL = m.avail & P264_AVAIL_LEFT, aT = m.avail & P264_AVAIL_TOP;
@@ -130,6 +130,9 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdcv = cf[((mask >> 24) & 1) * 16 + lane];
     }
 
+    // Everything left of this macroblock is final once the stores of the previous one have landed: publishing here, where
+    // the wave has to wait for its loads anyway, keeps the store latency off the macroblock-to-macroblock path.
+    row_publish(sync, mby, row_publish_as);
     // ---- land the neighbours ----
     if (lane < 55) lds8[dstA] = (uint8_t)vA;
     if (lane < 16) lds8[dstB] = (uint8_t)vB;
@@ -335,11 +338,10 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                 int bit = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 int mbx = base + bit, mbi = row * g.mb_w + mbx;
-                row_publish(sync, row, mbx);                                      // everything left of mbx is final
                 if (((deps >> bit) & 1) && ok) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
                 const uint4 mr = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)rec.x, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.y, bit),
                                             (uint32_t)__builtin_amdgcn_readlane((int)rec.z, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.w, bit));
-                intra_mb(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane);
+                intra_mb(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane, sync, mbx);
             }
         }
         row_publish(sync, row, g.mb_w);

@@ -102,8 +102,9 @@ typedef struct p264hip_picture {
 
 typedef struct p264hip_ctx p264hip_ctx;
 
-/* Device context: n_streams independent frame stores of `slots` frames each (planar 4:2:0,
- * MB-aligned, no padding) and `max_pictures` device-resident picture inputs. */
+/* Device context: n_streams independent frame stores of `slots` frames each (4:2:0, MB-aligned,
+ * no padding; kept macroblock-tiled in HBM - the host only ever sees planes, through
+ * p264hip_read_frame / p264hip_write_frame) and `max_pictures` device-resident picture inputs. */
 int  p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
                     int n_streams, int slots, int max_pictures);
 void p264hip_destroy(p264hip_ctx *ctx);

@@ -88,6 +88,14 @@ def build_tools(force=False):
         _run(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-I" + INC, "-I" + HOST_DIR, src, "-o", exe])
     if os.path.exists(exe):
         built.append(exe)
+    # command-line decoder on the drop-in API (same interface as the reference's `p264decoder -d`)
+    src = os.path.join(TOOLS_DIR, "p264decoder_cli.c")
+    exe = os.path.join(TOOLS_DIR, "p264decoder_amd")
+    if os.path.exists(src) and os.path.exists(LIB) and (force or _newer(exe, [src, LIB] + _headers())):
+        _run(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-I" + INC, src, "-o", exe,
+              "-L" + HERE, "-lp264amd", "-Wl,-rpath,$ORIGIN/.."])
+    if os.path.exists(exe):
+        built.append(exe)
     return built
 
 

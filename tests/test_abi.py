@@ -97,3 +97,15 @@ def test_open_fails_loudly_without_a_gpu(lib):
     h = C.c_void_p()
     assert lib.p264hip_create(C.byref(h), 0, 22, 18, 1, 2, 1) == -2      # P264HIP_ENODEV
     assert b"no HIP device" in lib.p264hip_last_error()
+
+
+def test_cli_builds_and_prints_usage():
+    """tools/p264decoder_amd (the `p264decoder -d` equivalent) is built with the library; without arguments it
+    prints the reference's usage line and fails, before touching any device (p264decoder.c:83-89,115-122)."""
+    import subprocess
+    from p264decoder_amd import build as _build
+    _build.build_tools()
+    cli = os.path.join(os.path.dirname(_build.__file__), "tools", "p264decoder_amd")
+    assert os.path.exists(cli)
+    r = subprocess.run([cli], stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "-d <test.264> [recon.yuv] [origin.yuv]" in r.stderr

@@ -305,16 +305,23 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     }
 }
 
-__global__ __launch_bounds__(ROW_WAVES * 64)
+#ifndef INTRA_ROW_WAVES
+#define INTRA_ROW_WAVES 16          // most wavefronts per picture workgroup
+#endif
+#ifndef INTRA_WAVES_PER_EU
+#define INTRA_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
 {
     __shared__ RowSync sync;
-    __shared__ IntraLds lds[ROW_WAVES];
+    __shared__ IntraLds lds[INTRA_ROW_WAVES];
     const PicDev *pd = pics + blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     rows_init(sync, g.mb_h);
     bool ok = true;
-    for (int row = wave; row < g.mb_h; row += ROW_WAVES) {
+    const int n_waves = blockDim.x >> 6;                       // 16 per picture, or 8 when two pictures share a CU (host's choice)
+    for (int row = wave; row < g.mb_h; row += n_waves) {
         for (int base = 0; base < g.mb_w; base += 64) {
             // which of the next 64 macroblocks of this row are intra, and which of them touch an intra macroblock of
             // the row above?  Only those can still be in flight there (inter MBs were finished by k_inter), so the

@@ -82,13 +82,6 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // ---- tables (H.264 standard data; the reference holds them at the cited places) --------
 // zig-zag scan -> raster position, decoder/macroblock.c:602-603
 __device__ __constant__ const uint8_t c_zigzag[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
-// dequant scale x 16 (flat scaling list), by qp%6 and position class; core/set.c:27-35,98
-__device__ __constant__ const uint16_t c_dqmf[6][3] = {
-    {160, 208, 256}, {176, 224, 288}, {208, 256, 320}, {224, 288, 368}, {256, 320, 400}, {288, 368, 464} };
-// core/macroblock.h:210-218
-__device__ __constant__ const uint8_t c_chroma_qp[52] = {
-     0, 1, 2, 3, 4, 5, 6, 7, 8, 9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,
-    29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39 };
 // core/frame.c:262-291
 __device__ __constant__ const uint8_t c_alpha[52] = {
     0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,
@@ -109,11 +102,29 @@ __device__ __forceinline__ int zigzag_pos(int k) { return (int)(((k & 8) ? 0xFEB
 
 // dequantisation parameters of one macroblock / plane: wave-uniform, so they live in SGPRs
 struct DqParams { int mf0, mf1, mf2, qbits; };
+// table-free: the six scales of a position class are 5-bit fields of one constant (scale / 16 <= 29), so a
+// macroblock's parameters cost a handful of scalar ALU operations instead of dependent constant-memory loads
+__device__ __forceinline__ int dq_scale(int cls, int rem)
+{   // core/set.c:27-35: {10,11,13,14,16,18}, {13,14,16,18,20,23}, {16,18,20,23,25,29}
+    const uint32_t k = cls == 0 ? (10u | 11u << 5 | 13u << 10 | 14u << 15 | 16u << 20 | 18u << 25)
+                     : cls == 1 ? (13u | 14u << 5 | 16u << 10 | 18u << 15 | 20u << 20 | 23u << 25)
+                                : (16u | 18u << 5 | 20u << 10 | 23u << 15 | 25u << 20 | 29u << 25);
+    return (int)((k >> (5 * rem)) & 31u) * 16;
+}
 __device__ __forceinline__ DqParams dq_params(int qp)
 {
-    int rem = qp % 6;
-    DqParams d = { c_dqmf[rem][0], c_dqmf[rem][1], c_dqmf[rem][2], qp / 6 - 4 };
+    const int per = (qp * 43) >> 8, rem = qp - per * 6;          // qp / 6 and qp % 6 for 0 <= qp < 64
+    DqParams d = { dq_scale(0, rem), dq_scale(1, rem), dq_scale(2, rem), per - 4 };
     return d;
+}
+// chroma QP of a luma QP index 0..51 (core/macroblock.h:210-218 = H.264 table 8-15): identity below 30, then
+// qp minus a 4-bit correction
+__device__ __forceinline__ int chroma_qp(int qi)
+{
+    const int k = qi - 30;
+    if (k < 0) return qi;
+    const int corr = k < 16 ? (int)((0x7765544332221111ull >> (4 * k)) & 15) : (int)((0xCBA998u >> (4 * (k - 16))) & 15);
+    return qi - corr;
 }
 __device__ __forceinline__ int dequant_coef(int c, int pos, const DqParams &d)
 {   // core/quant.c:66-99; position class (pos&1) + ((pos>>2)&1); int16 store wrap = A-Q8
@@ -138,8 +149,9 @@ __device__ __forceinline__ uint32_t coef_slot(uint32_t mask, int blk)
 // ---- dequantisation, one coefficient (core/quant.c:66-99; int16 store wrap = A-Q8) -------
 __device__ __forceinline__ int dequant_coef(int c, int pos, int qp)
 {
-    int mf = c_dqmf[qp % 6][(pos & 1) + ((pos >> 2) & 1)];
-    int qbits = qp / 6 - 4;
+    const int per = (qp * 43) >> 8, rem = qp - per * 6;
+    int mf = dq_scale((pos & 1) + ((pos >> 2) & 1), rem);
+    int qbits = per - 4;
     int v = c * mf;
     v = qbits >= 0 ? (int)((unsigned)v << qbits) : (v + (1 << (-qbits - 1))) >> (-qbits);
     return (int)(int16_t)v;

@@ -127,7 +127,7 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
             const int qp = m_qp, qpn = cls == EC_LEFT ? (int)((l0 >> 8) & 255) : cls == EC_TOP ? (int)((t0 >> 8) & 255) : m_qp;
             int q;
             if (!chroma) q = (qp + qpn + 1) >> 1;                                     // :593-595
-            else q = (c_chroma_qp[clip3i(qp + chroma_qp_offset, 0, 51)] + c_chroma_qp[clip3i(qpn + chroma_qp_offset, 0, 51)] + 1) >> 1;   // :600-601
+            else q = (chroma_qp(clip3i(qp + chroma_qp_offset, 0, 51)) + chroma_qp(clip3i(qpn + chroma_qp_offset, 0, 51)) + 1) >> 1;   // :600-601
             const int ia = clip3i(q + alpha_off, 0, 51);
             uint32_t lo = (uint32_t)c_alpha[ia] | ((uint32_t)c_beta[clip3i(q + beta_off, 0, 51)] << 8) |
                           ((uint32_t)(c_tc0[ia][0] + chroma) << 16) | ((uint32_t)(c_tc0[ia][1] + chroma) << 24);

@@ -356,23 +356,23 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         // luma window 21 rows x 6 dwords, chroma windows 2 x 9 rows x 3 dwords: three load instructions
         const uint8_t *rf = r0i == 0 ? ref0 : pd->ref[r0i];
         const int lx = mv_x(mv0), ly = mv_y(mv0);
+        // (lanes past the end of a window repeat its last dword and write it to unused LDS words: cheaper than masking them off)
         uint32_t yv[2], cvv = 0;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            int i = lane + 64 * k, r = (i * 43) >> 8, d = i - r * 6;       // i / 6 for i < 128
+            const int i = min(lane + 64 * k, 125), r = (i * 43) >> 8, d = i - r * 6;       // i / 6 for i < 128
             yv[k] = 0;
-            if (i < 126 && !EXP_NOLOAD) {
-                yv[k] = luma_dword(rf, g, (ux0 & ~3) + d * 4, Y0 + (ly >> 2) - 2 + r);
-            }
+            if (!EXP_NOLOAD) yv[k] = luma_dword(rf, g, (ux0 & ~3) + d * 4, Y0 + (ly >> 2) - 2 + r);
         }
-        if (lane < 54 && !EXP_NOLOAD) {
-            int p = lane >= 27, l2 = lane - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
+        if (!EXP_NOLOAD) {
+            const int cl = min(lane, 53);
+            int p = cl >= 27, l2 = cl - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
             cvv = chroma_dword(rf, g, p, (ucx0 & ~3) + d * 4, Y0 / 2 + (ly >> 3) + r);
         }
         uint32_t *yw = &L.ywin[0][0], *cw = &L.cwin[0][0][0];
         yw[lane] = yv[0];
-        if (lane < 62) yw[64 + lane] = yv[1];
-        if (lane < 54) cw[lane] = cvv;
+        yw[64 + lane] = yv[1];
+        cw[lane] = cvv;
         wave_lds_fence();
 #if EXP_NOCOMPUTE
         outY = yw[lane]; outC = cw[lane & 31];
@@ -467,7 +467,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
             }
         }
         if (cbp >> 4) {                                       // chroma: DC (core/dct.c:55-68, core/quant.c:138-159) + AC
-            const int qpc = c_chroma_qp[clip3i(qp + pd->chroma_qp_offset, 0, 51)];
+            const int qpc = chroma_qp(clip3i(qp + pd->chroma_qp_offset, 0, 51));
             const DqParams dq = dq_params(qpc);
             int cb = 16 + (lane >> 3), i2 = lane & 7;
 #pragma unroll

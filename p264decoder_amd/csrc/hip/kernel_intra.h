@@ -181,7 +181,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
             int s01 = tcol[0] + tcol[1], d01 = tcol[0] - tcol[1], s23 = tcol[2] + tcol[3], d23 = tcol[2] - tcol[3];
             int v = j == 0 ? s01 + s23 : j == 1 ? s01 - s23 : j == 2 ? d01 - d23 : d01 + d23;
             v = (int)(int16_t)v;
-            int qbits = m.qp / 6 - 6, mf = c_dqmf[m.qp % 6][0];
+            int qbits = m.qp / 6 - 6, mf = dq_scale(0, m.qp % 6);
             v = qbits >= 0 ? v * (int)((unsigned)mf << qbits) : (v * mf + (1 << (-qbits - 1))) >> (-qbits);
             dcv = (int)(int16_t)v;
         }
@@ -246,7 +246,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         int mode = (m.intra_modes >> 4) & 3;
         if (mode == 0) mode = aTL ? 0 : aL ? 4 : aT ? 5 : 6;                     // :721-753
         const int px = lane & 7, py = lane >> 3;
-        const int qpc = c_chroma_qp[clip3i(m.qp + pd->chroma_qp_offset, 0, 51)];
+        const int qpc = chroma_qp(clip3i(m.qp + pd->chroma_qp_offset, 0, 51));
         const int j = lane >> 4, k = lane & 15, pos = c_zigzag[k];
         for (int p = 0; p < 2; p++) {
             const uint8_t *top = L.c[p] + 4, *tile = L.c[p] + CT_STRIDE;
@@ -278,7 +278,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
                     int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
                     int f = j == 0 ? t0 + t2 : j == 1 ? t1 + t3 : j == 2 ? t0 - t2 : t1 - t3;
                     f = (int)(int16_t)f;
-                    int qbits = qpc / 6 - 5, mf = c_dqmf[qpc % 6][0];
+                    int qbits = qpc / 6 - 5, mf = dq_scale(0, qpc % 6);
                     cv = qbits >= 0 ? f * (int)((unsigned)mf << qbits) : (f * mf) >> (-qbits);
                     cv = (int)(int16_t)cv;
                 } else cv = dequant_coef(cac[p], pos, qpc);

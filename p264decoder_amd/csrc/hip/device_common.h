@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include "p264hip.h"
 
 #define WAVE 64
@@ -21,6 +22,30 @@ struct PicDev {
     int32_t n_ref, slice_type, chroma_qp_offset, deblock, alpha_off, beta_off;
     int32_t pad[2];
 };
+
+// The fields of a PicDev a kernel needs, fetched with TWO loads issued together (the descriptor address is
+// wave-uniform, so these are scalar loads).  Reading the fields one by one where they are used makes the compiler
+// emit a chain of dependent scalar loads - pointer, record, next pointer, ... - each a full round trip.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+struct PicHead {
+    const p264hip_mb_t *mb; const int *mv; const int8_t *ref_idx; const uint8_t *i4modes; const int16_t *coefs;
+    uint8_t *dst; const uint8_t *ref0, *ref1;
+    int n_ref, slice_type, chroma_qp_offset, deblock;
+};
+__device__ __forceinline__ PicHead load_pic_head(const PicDev *pd)
+{
+    static_assert(offsetof(PicDev, ref) == 48 && offsetof(PicDev, n_ref) == 176 && sizeof(PicDev) == 208, "PicDev layout");
+    const u32x16 a = *(const u32x16 *)pd;
+    const u32x4v b = *(const u32x4v *)((const char *)pd + 176);
+    auto p64 = [&](int i) { return ((uint64_t)a[2 * i + 1] << 32) | a[2 * i]; };
+    PicHead h;
+    h.mb = (const p264hip_mb_t *)p64(0); h.mv = (const int *)p64(1); h.ref_idx = (const int8_t *)p64(2);
+    h.i4modes = (const uint8_t *)p64(3); h.coefs = (const int16_t *)p64(4); h.dst = (uint8_t *)p64(5);
+    h.ref0 = (const uint8_t *)p64(6); h.ref1 = (const uint8_t *)p64(7);
+    h.n_ref = (int)b[0]; h.slice_type = (int)b[1]; h.chroma_qp_offset = (int)b[2]; h.deblock = (int)b[3];
+    return h;
+}
 
 // Geometry shared by every picture of a context.
 struct Geom {

@@ -311,17 +311,20 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 
     // ---------------- header: everything wave-uniform goes to SGPRs ----------------
     // the three header loads go out together; nothing waits before all of them are in flight
-    const uint4 rec = gload4(pd->mb + mbi);
-    const int mvreg_raw = glob(pd->mv)[mbi * 16 + (lane & 15)];
-    const int refs4_raw = (int)gload1(pd->ref_idx + mbi * 4);
-    const uint8_t *ref0 = pd->ref[0];                          // by far the most common reference: fetched with the descriptor
+    const PicHead ph = load_pic_head(pd);                      // one round trip for the whole descriptor
+    const uint4 rec = gload4(ph.mb + mbi);
+    const int mvreg_raw = glob(ph.mv)[mbi * 16 + (lane & 15)];
+    const int refs4_raw = (int)gload1(ph.ref_idx + mbi * 4);
+    const uint8_t *ref0 = ph.ref0;                             // by far the most common reference
     const unsigned w0 = (unsigned)rfl((int)rec.x), mask = (unsigned)rfl((int)rec.y);
     const int mb_type = w0 & 255, qp = (w0 >> 8) & 255, cbp = (w0 >> 16) & 255;
-    if (P264_MB_IS_INTRA(mb_type)) return;
-    const int16_t *cf = pd->coefs + (size_t)(unsigned)rfl((int)rec.z) * 16;
+    // (the second term is never true; it makes the vector and the reference indices part of this branch, so that their
+    // loads are issued with the record's instead of being sunk below it - one round trip instead of two)
+    if (P264_MB_IS_INTRA(mb_type) | ((ph.n_ref < 0) & (__ballot(mvreg_raw == 0x7fffffff) != 0) & (refs4_raw == 0x7fffffff))) return;
+    const int16_t *cf = ph.coefs + (size_t)(unsigned)rfl((int)rec.z) * 16;
     const int mvreg = lane < 16 ? mvreg_raw : 0;
     const int refs4 = rfl(refs4_raw);
-    const int n_ref = pd->n_ref;
+    const int n_ref = ph.n_ref;
 
     InterLds &L = lds[wave];
     int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
@@ -340,7 +343,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdc = glob(cf)[((mask >> 24) & 1) * 16 + lane];
     }
 
-    if (EXP_HDRONLY) { if (mvreg == 0x7fffffff) pd->dst[0] = 1; return; }
+    if (EXP_HDRONLY) { if (mvreg == 0x7fffffff) ph.dst[0] = 1; return; }
     const int row = lane >> 2, dw = lane & 3;                 // luma: lane = (row, dword) of the 16x16 block
     const int crow = (lane >> 1) & 7, cdw = lane & 1, cp = (lane >> 4) & 1;   // chroma (lanes 0..31): (plane, row, dword)
     uint32_t outY = 0, outC = 0;
@@ -405,20 +408,26 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         // ---- all windows at once: luma 13 rows x 4 dwords per quadrant (lane: dword wl&3 of rows (wl>>2) + 4k),
         // chroma 5 rows x 2 dwords per quadrant and plane ----
         {
+            // (raw loads first, border fix-up afterwards: a fix-up inside the predicated load would make every load wait for
+            // its own data before the next one is issued)
             uint32_t yv[4], cv[2];
-            const int xa = (wx0 & ~3) + (wl & 3) * 4;
+            const int xa = (wx0 & ~3) + (wl & 3) * 4, xc = clip3i(xa, 0, g.w - 4);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int r = (wl >> 2) + 4 * k;
                 yv[k] = 0;
-                if (fastW && r < 13) yv[k] = luma_dword(refW, g, xa, wy0 + r);
+                if (fastW && r < 13) yv[k] = WLOAD(refW + luma_off(g, xc, clip3i(wy0 + r, 0, g.h - 1)));
             }
             const int cr = wl >> 1, cxa = (cx0 & ~3) + (wl & 1) * 4;
+            const uint32_t coff = chroma_off(g, 0, clip3i(cxa, 0, g.cw - 4), clip3i(cy0 + cr, 0, g.ch - 1));
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 cv[p] = 0;
-                if (fastW && wl < 10) cv[p] = chroma_dword(refW, g, p, cxa, cy0 + cr);
+                if (fastW && wl < 10) cv[p] = WLOAD(refW + coff + p * 64);
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++) yv[k] = edge_fix(yv[k], xa, g.w);
+            cv[0] = edge_fix(cv[0], cxa, g.cw); cv[1] = edge_fix(cv[1], cxa, g.cw);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int r = (wl >> 2) + 4 * k;
@@ -467,7 +476,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
             }
         }
         if (cbp >> 4) {                                       // chroma: DC (core/dct.c:55-68, core/quant.c:138-159) + AC
-            const int qpc = chroma_qp(clip3i(qp + pd->chroma_qp_offset, 0, 51));
+            const int qpc = chroma_qp(clip3i(qp + ph.chroma_qp_offset, 0, 51));
             const DqParams dq = dq_params(qpc);
             int cb = 16 + (lane >> 3), i2 = lane & 7;
 #pragma unroll
@@ -498,7 +507,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     if (EXP_NOSTORE && outY != 0x12345678u) return;
     // (tiled frame: luma dword (row, dw) sits at lane*4, chroma dword (plane, row, dw) at 256 + lane*4 - the
     // macroblock goes out as three whole cache lines)
-    uint8_t *tile = pd->dst + (size_t)mbi * MB_TILE;
+    uint8_t *tile = ph.dst + (size_t)mbi * MB_TILE;
     gstore1(tile + lane * 4, outY);
     if (lane < 32) gstore1(tile + MB_TILE_U + lane * 4, outC);
 }

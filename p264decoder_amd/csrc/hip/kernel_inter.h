@@ -408,23 +408,19 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         // ---- all windows at once: luma 13 rows x 4 dwords per quadrant (lane: dword wl&3 of rows (wl>>2) + 4k),
         // chroma 5 rows x 2 dwords per quadrant and plane ----
         {
-            // (raw loads first, border fix-up afterwards: a fix-up inside the predicated load would make every load wait for
-            // its own data before the next one is issued)
+            // Every lane loads, unconditionally: lanes past the end of a window repeat its last row, quadrants that will take
+            // the per-sample path fetch a window they do not use.  Predicated loads would cost exec-mask bookkeeping and, worse,
+            // make every load wait for the previous one (the wait for the reference pointer would sit inside the predicate).
             uint32_t yv[4], cv[2];
             const int xa = (wx0 & ~3) + (wl & 3) * 4, xc = clip3i(xa, 0, g.w - 4);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int r = (wl >> 2) + 4 * k;
-                yv[k] = 0;
-                if (fastW && r < 13) yv[k] = WLOAD(refW + luma_off(g, xc, clip3i(wy0 + r, 0, g.h - 1)));
+                const int r = min((wl >> 2) + 4 * k, 12);
+                yv[k] = WLOAD(refW + luma_off(g, xc, clip3i(wy0 + r, 0, g.h - 1)));
             }
-            const int cr = wl >> 1, cxa = (cx0 & ~3) + (wl & 1) * 4;
+            const int cr = min(wl, 9) >> 1, cxa = (cx0 & ~3) + (wl & 1) * 4;
             const uint32_t coff = chroma_off(g, 0, clip3i(cxa, 0, g.cw - 4), clip3i(cy0 + cr, 0, g.ch - 1));
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                cv[p] = 0;
-                if (fastW && wl < 10) cv[p] = WLOAD(refW + coff + p * 64);
-            }
+            cv[0] = WLOAD(refW + coff); cv[1] = WLOAD(refW + coff + 64);
 #pragma unroll
             for (int k = 0; k < 4; k++) yv[k] = edge_fix(yv[k], xa, g.w);
             cv[0] = edge_fix(cv[0], cxa, g.cw); cv[1] = edge_fix(cv[1], cxa, g.cw);

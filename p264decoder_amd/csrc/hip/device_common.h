@@ -154,7 +154,8 @@ __device__ __forceinline__ int chroma_qp(int qi)
 __device__ __forceinline__ int dequant_coef(int c, int pos, const DqParams &d)
 {   // core/quant.c:66-99; position class (pos&1) + ((pos>>2)&1); int16 store wrap = A-Q8
     int cls = (pos & 1) + ((pos >> 2) & 1);
-    int mf = cls == 0 ? d.mf0 : cls == 1 ? d.mf1 : d.mf2;
+    const int m1 = -(int)(cls == 1), m2 = -(int)(cls == 2);            // lane-varying class: masks, not branches
+    int mf = (d.mf0 & ~(m1 | m2)) | (d.mf1 & m1) | (d.mf2 & m2);
     int v = c * mf;
     v = d.qbits >= 0 ? (int)((unsigned)v << d.qbits) : (v + (1 << (-d.qbits - 1))) >> (-d.qbits);
     return (int)(int16_t)v;
@@ -182,6 +183,23 @@ __device__ __forceinline__ int dequant_coef(int c, int pos, int qp)
     return (int)(int16_t)v;
 }
 
+// a + b or a - b, with the pair picked by lane-varying flags (all-ones masks), branch-free
+__device__ __forceinline__ int pick_addsub(int a0, int a1, int b0, int b1, bool second, bool minus)
+{
+    const int ms = -(int)second, neg = -(int)minus;
+    const int a = (a1 & ms) | (a0 & ~ms), b = (b1 & ms) | (b0 & ~ms);
+    return a + ((b ^ neg) - neg);
+}
+
+// Output k (0..3) of the transform's butterfly {s02+s13, d02+d13, d02-d13, s02-s13} with k varying per lane, without
+// branches: nested ?: on a lane-varying index compiles to nested exec-mask regions (~16 scalar instructions per use).
+__device__ __forceinline__ int butterfly_pick(int s02, int d02, int s13, int d13, int k)
+{
+    const int outer = -(int)(k == 0 || k == 3), neg = -(int)(k >= 2);     // all-ones masks
+    const int a = (s02 & outer) | (d02 & ~outer), b = (s13 & outer) | (d13 & ~outer);
+    return a + ((b ^ neg) - neg);
+}
+
 // One output sample of the 4x4 inverse transform (core/dct.c:205-247): c = 16 dequantised
 // coefficients in raster order, (x,y) the sample.  Row pass then column pass with the
 // reference's int16 intermediates.
@@ -191,11 +209,8 @@ __device__ __forceinline__ int idct4x4_sample(const int16_t *c, int x, int y)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int c0 = c[i*4], c1 = c[i*4+1], c2 = c[i*4+2], c3 = c[i*4+3];
-        int s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
-        int v = x == 0 ? s02 + s13 : x == 1 ? d02 + d13 : x == 2 ? d02 - d13 : s02 - s13;
-        t[i] = (int)(int16_t)v;
+        t[i] = (int)(int16_t)butterfly_pick(c0 + c2, c0 - c2, c1 + (c3 >> 1), (c1 >> 1) - c3, x);
     }
-    int s02 = t[0] + t[2], d02 = t[0] - t[2], s13 = t[1] + (t[3] >> 1), d13 = (t[1] >> 1) - t[3];
-    int v = y == 0 ? s02 + s13 : y == 1 ? d02 + d13 : y == 2 ? d02 - d13 : s02 - s13;
+    int v = butterfly_pick(t[0] + t[2], t[0] - t[2], t[1] + (t[3] >> 1), (t[1] >> 1) - t[3], y);
     return (int)(int16_t)((v + 32) >> 6);
 }

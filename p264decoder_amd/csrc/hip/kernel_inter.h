@@ -243,8 +243,7 @@ __device__ __forceinline__ void idct4x4_row(const int16_t *c, int y, int r[4])
 #pragma unroll
     for (int x = 0; x < 4; x++) {
         int s02 = t[0][x] + t[2][x], d02 = t[0][x] - t[2][x], s13 = t[1][x] + (t[3][x] >> 1), d13 = (t[1][x] >> 1) - t[3][x];
-        int v = y == 0 ? s02 + s13 : y == 1 ? d02 + d13 : y == 2 ? d02 - d13 : s02 - s13;
-        r[x] = (int)(int16_t)((v + 32) >> 6);
+        r[x] = (int)(int16_t)((butterfly_pick(s02, d02, s13, d13, y) + 32) >> 6);
     }
 }
 __device__ __forceinline__ uint32_t add_residual4(uint32_t pred, const int16_t *c, int y)
@@ -334,13 +333,13 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 
     // coded coefficients are fetched now, whatever path the prediction takes:
     // luma block lane>>2, levels 4*(lane&3)..+3 ; chroma block 16+(lane>>3), levels 2*(lane&7)..+1
-    uint2 lc = make_uint2(0, 0); uint32_t cc = 0; int cdc = 0;
+    uint2 lc = make_uint2(0, 0); uint32_t cc = 0, cdc_raw = 0;
     if (mask) {
         int lb = lane >> 2;
         if ((mask >> lb) & 1) lc = gload2(cf + coef_slot(mask, lb) * 16 + (lane & 3) * 4);
         int cb = 16 + (lane >> 3);
         if ((mask >> cb) & 1) cc = gload1(cf + coef_slot(mask, cb) * 16 + (lane & 7) * 2);
-        if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdc = glob(cf)[((mask >> 24) & 1) * 16 + lane];
+        if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdc_raw = glob((const uint16_t *)cf)[((mask >> 24) & 1) * 16 + lane];
     }
 
     if (EXP_HDRONLY) { if (mvreg == 0x7fffffff) ph.dst[0] = 1; return; }
@@ -387,8 +386,6 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         // ======== general case: four 8x8 quadrants with their own vectors ========
         // Everything per quadrant stays in vector registers: a lane acts as (a) window loader of quadrant
         // wq = lane>>4, (b) producer of a luma dword in quadrant lq, (c) producer of a chroma dword in quadrant cq.
-        const int mvl = __shfl(mvreg, (row >> 2) * 4 + dw);
-        const int mvA = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2), mvB = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2 + 1);
         const int lq = (row >> 3) * 2 + (dw >> 1), cq = (crow >> 2) * 2 + cdw;
         const int wq = lane >> 4, wl = lane & 15;
         // quadrant q covers the 4x4 blocks b0, b0+1, b0+4, b0+5 (raster), b0 = (q>>1)*8 + (q&1)*2; lanes 0..15 hold the vectors
@@ -452,6 +449,9 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
                     outC = chroma4<2>(L.cwin[cp][cq] + (crow & 3) * 2, (X0 / 2 + (lx >> 3)) & 3, lx & 7, ly & 7);
             } else {
                 // sub-8x8 partitions with differing vectors: every lane samples the clamped plane with its own vectors
+                // (the branch is wave-uniform, so every lane takes part in these shuffles)
+                const int mvl = __shfl(mvreg, (row >> 2) * 4 + dw);
+                const int mvA = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2), mvB = __shfl(mvreg, (crow >> 1) * 4 + cdw * 2 + 1);
                 const uint8_t *rf = pd->ref[kri];
                 if ((group >> lq) & 1) outY = slow_luma4(rf, g.w, g.h, g.mb_w, X0 + dw * 4, Y0 + row, mvl);
                 if (lane < 32 && ((group >> cq) & 1)) outC = slow_chroma4(rf, g.cw, g.ch, g.mb_w, cp, X0 / 2 + cdw * 4, Y0 / 2 + crow, mvA, mvB);
@@ -481,12 +481,13 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
                 if (k < 16) { int pos = zigzag_pos(k); L.coef[cb * 16 + pos] = (int16_t)dequant_coef((int)(int16_t)(cc >> (16 * kk)), pos, dq); }
             }
             // DC of chroma block j of plane p: lanes 0..7 hold the parsed DC levels of (p = lane>>2, index lane&3)
+            const int cdc = (int)(int16_t)cdc_raw;
             int d0 = __shfl(cdc, (lane >> 5) * 4 + 0), d1 = __shfl(cdc, (lane >> 5) * 4 + 1);
             int d2 = __shfl(cdc, (lane >> 5) * 4 + 2), d3 = __shfl(cdc, (lane >> 5) * 4 + 3);
             if ((lane & 7) == 0) {
                 int j = (lane >> 3) & 3;
                 int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
-                int f = j == 0 ? t0 + t2 : j == 1 ? t1 + t3 : j == 2 ? t0 - t2 : t1 - t3;
+                int f = pick_addsub(t0, t1, t2, t3, j & 1, j & 2);            // {t0+t2, t1+t3, t0-t2, t1-t3}[j]
                 f = (int)(int16_t)f;
                 int qbits = dq.qbits - 1;                     // qpc/6 - 5
                 int v = qbits >= 0 ? f * (int)((unsigned)dq.mf0 << qbits) : (f * dq.mf0) >> (-qbits);

@@ -175,11 +175,11 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
             for (int c = 0; c < 4; c++) {                                       // column pass for tmp[i][c]
                 int d0 = L.dc[c], d1 = L.dc[4 + c], d2 = L.dc[8 + c], d3 = L.dc[12 + c];
                 int s01 = d0 + d1, d01 = d0 - d1, s23 = d2 + d3, d23 = d2 - d3;
-                int v = i == 0 ? s01 + s23 : i == 1 ? s01 - s23 : i == 2 ? d01 - d23 : d01 + d23;
+                int v = pick_addsub(s01, d01, s23, d23, i >= 2, i == 1 || i == 2);   // {s01+s23, s01-s23, d01-d23, d01+d23}[i]
                 tcol[c] = (int)(int16_t)v;
             }
             int s01 = tcol[0] + tcol[1], d01 = tcol[0] - tcol[1], s23 = tcol[2] + tcol[3], d23 = tcol[2] - tcol[3];
-            int v = j == 0 ? s01 + s23 : j == 1 ? s01 - s23 : j == 2 ? d01 - d23 : d01 + d23;
+            int v = pick_addsub(s01, d01, s23, d23, j >= 2, j == 1 || j == 2);
             v = (int)(int16_t)v;
             int qbits = m.qp / 6 - 6, mf = dq_scale(0, m.qp % 6);
             v = qbits >= 0 ? v * (int)((unsigned)mf << qbits) : (v * mf + (1 << (-qbits - 1))) >> (-qbits);
@@ -276,7 +276,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
                 int cv;
                 if (k == 0) {
                     int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
-                    int f = j == 0 ? t0 + t2 : j == 1 ? t1 + t3 : j == 2 ? t0 - t2 : t1 - t3;
+                    int f = pick_addsub(t0, t1, t2, t3, j & 1, j & 2);            // {t0+t2, t1+t3, t0-t2, t1-t3}[j]
                     f = (int)(int16_t)f;
                     int qbits = qpc / 6 - 5, mf = dq_scale(0, qpc % 6);
                     cv = qbits >= 0 ? f * (int)((unsigned)mf << qbits) : (f * mf) >> (-qbits);

@@ -285,7 +285,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         ScopedStamp t(c, 1);
         // one workgroup per picture: 16 wavefronts while every picture can have a CU to itself, else 8 so that two
         // pictures share a CU (the kernel is dependency/latency bound: measured +19 % at 512 pictures)
-        const int intra_waves = n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
+        int intra_waves = n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
+        if (const char *e = getenv("P264AMD_INTRA_WAVES")) { int v = atoi(e); if (v >= 1 && v <= INTRA_ROW_WAVES) intra_waves = v; }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(intra_waves * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
     }
     {

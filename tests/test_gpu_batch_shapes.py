@@ -1,0 +1,58 @@
+"""The two row-wavefront kernels pick their workgroup shape from the batch size (pictures vs compute units):
+k_deblock walks bands of 8 / 4 / 2 macroblock rows with 1 / 2 / 4 pictures per workgroup, k_intra uses 16 or 8
+wavefronts per picture.  A test batch is far smaller than an MI355X, so every shape is forced through the
+P264AMD_* knobs (read at each launch) and checked against the CPU oracle, picture by picture, on every stream."""
+import os
+
+import numpy as np
+import pytest
+
+from p264decoder_amd import HipReconstructor, Parser
+from tests import oracle_bind, synth_cases
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (P264AMD_DEBLOCK_RB_LOG2, P264AMD_DEBLOCK_PICS_PER_WG, P264AMD_INTRA_WAVES)
+    ("3", "1", "16"), ("2", "2", "8"), ("2", "1", "4"), ("1", "4", "8"), ("1", "3", "1"), ("1", "1", "16"),
+]
+
+
+@pytest.mark.parametrize("rb,per_wg,intra_waves", SHAPES)
+@pytest.mark.parametrize("case", ["cif_ip", "col_Nx1", "wide_70"])
+def test_workgroup_shapes(lib, oracle, case, rb, per_wg, intra_waves, monkeypatch):
+    monkeypatch.setenv("P264AMD_DEBLOCK_RB_LOG2", rb)
+    monkeypatch.setenv("P264AMD_DEBLOCK_PICS_PER_WG", per_wg)
+    monkeypatch.setenv("P264AMD_INTRA_WAVES", intra_waves)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes(case))[:8]
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    S = 7                                                      # odd on purpose: the last workgroup is partly empty
+    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=parser.slots, max_pictures=len(pics), lib=lib)
+    hip.upload(0, pics)
+    for i, p in enumerate(pics):
+        want = oracle_bind.reconstruct(oracle, store, p)
+        hip.reconstruct([i] * S, list(range(S)))
+        for s in range(S):
+            got = hip.read_frame(s, p.desc.dst_slot)
+            for plane, (a, b) in enumerate(zip(got, want)):
+                assert np.array_equal(a, b), "%s shape (%s,%s,%s): picture %d stream %d plane %d differs" % (case, rb, per_wg, intra_waves, i, s, plane)
+    hip.close()
+
+
+def test_vectors_far_outside_the_picture(lib, oracle):
+    """Windows that lie entirely outside the picture (vectors of +-100 pixels on a 160x128 picture): beyond the
+    reference's 32-pixel pads its behaviour is undefined (SURVEY A-Q9), so this is HIP against the oracle's clamped
+    coordinates only - it exercises the replicated-border dwords of k_inter on all four sides."""
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(open(synth_cases.generate("--mbw 10 --mbh 8 --frames 6 --gop 6 --seed 29 --mvmax 400 --coded 5 --maxlevel 6"), "rb").read())
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=1, slots=parser.slots, max_pictures=1, lib=lib)
+    for i, p in enumerate(pics):
+        want = oracle_bind.reconstruct(oracle, store, p)
+        hip.submit(0, p)
+        got = hip.read_frame(0, p.desc.dst_slot)
+        for plane, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), "picture %d plane %d differs" % (i, plane)
+    hip.close()

@@ -24,48 +24,33 @@ struct IntraLds {                  // per wavefront
     uint8_t  c[2][9 * CT_STRIDE];
     int16_t  coef[16 * 16];
     int16_t  dc[16];
+    uint8_t  edge[16];             // Intra4x4: l3 l3 l2 l1 l0 lt t0..t7 t7 of the current block
 };
 
 __device__ __forceinline__ int f3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
 __device__ __forceinline__ int f2(int a, int b) { return (a + b + 1) >> 1; }
 
-// One sample (x,y) of a 4x4 intra prediction (core/predict.c:366-638).  l[4] left, t[8] top and
-// top-right, lt corner - already substituted for missing neighbours.
-__device__ __forceinline__ int pred4x4_sample(int mode, int x, int y, const int *l, const int *t, int lt)
+// Intra 4x4 prediction (core/predict.c:366-638) over an EDGE ARRAY: S[0..14] = l3 l3 l2 l1 l0 lt t0 .. t7 t7 (left
+// column bottom-up, corner, top and top-right row; the ends replicated).  Every directional mode is then one of
+//   copy S[c],  (S[c] + S[c+1] + 1) >> 1,  (S[c-1] + 2 S[c] + S[c+1] + 2) >> 2
+// with an index c that is linear in (x,y) per mode - the mode is wave-uniform, so this is a small scalar switch and
+// no per-mode sample code (checked against the per-mode formulas for all modes and positions).
+enum { P4_COPY = 0, P4_F2 = 1, P4_F3 = 2 };
+__device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, int &kind)
 {
     switch (mode) {
-    case 0: return t[x];
-    case 1: return l[y];
-    case 2: return (l[0] + l[1] + l[2] + l[3] + t[0] + t[1] + t[2] + t[3] + 4) >> 3;
-    case 9: return (l[0] + l[1] + l[2] + l[3] + 2) >> 2;
-    case 10: return (t[0] + t[1] + t[2] + t[3] + 2) >> 2;
-    case 11: return 128;
-    case 3: { int k = x + y; return k == 6 ? (t[6] + 3 * t[7] + 2) >> 2 : f3(t[k], t[k+1], t[k+2]); }
-    case 4: {                                   // edge e = l3 l2 l1 l0 lt t0 t1 t2 t3, index 4 = lt
-        int k = 4 + x - y;
-        auto e = [&](int i) { return i < 4 ? l[3 - i] : i == 4 ? lt : t[i - 5]; };
-        return f3(e(k - 1), e(k), e(k + 1)); }
-    case 5: {                                   // vertical-right: zVR = 2x - y
-        int z = 2 * x - y;
-        auto e = [&](int i) { return i < 0 ? (i == -1 ? lt : l[-2 - i]) : t[i]; };   // e(-1)=lt, e(-2)=l0, e(-3)=l1 ...
-        if (z >= 0) { int i = x - (y >> 1); return (z & 1) ? f3(e(i - 2), e(i - 1), e(i)) : f2(e(i - 1), e(i)); }
-        if (z == -1) return f3(l[0], lt, t[0]);
-        return f3(l[y - 1], l[y - 2], y - 3 >= 0 ? l[y - 3] : lt); }
-    case 6: {                                   // horizontal-down: zHD = 2y - x
-        int z = 2 * y - x;
-        auto e = [&](int i) { return i < 0 ? (i == -1 ? lt : t[-2 - i]) : l[i]; };   // e(-1)=lt, e(-2)=t0 ...
-        if (z >= 0) { int i = y - (x >> 1); return (z & 1) ? f3(e(i - 2), e(i - 1), e(i)) : f2(e(i - 1), e(i)); }
-        if (z == -1) return f3(l[0], lt, t[0]);
-        return f3(t[x - 1], t[x - 2], x - 3 >= 0 ? t[x - 3] : lt); }
-    case 7: { int i = x + (y >> 1); return (y & 1) ? f3(t[i], t[i+1], t[i+2]) : f2(t[i], t[i+1]); }
-    case 8: {                                   // horizontal-up: zHU = x + 2y
-        int z = x + 2 * y;
-        if (z > 5) return l[3];
-        if (z == 5) return f3(l[2], l[3], l[3]);
-        int i = y + (x >> 1);
-        return (z & 1) ? f3(l[i], l[i+1], l[i+2]) : f2(l[i], l[i+1]); }
+    case 0: c = 6 + x; kind = P4_COPY; break;                                                   // vertical
+    case 1: c = 4 - y; kind = P4_COPY; break;                                                   // horizontal
+    case 3: c = 7 + x + y; kind = P4_F3; break;                                                 // diagonal down-left
+    case 4: c = 5 + x - y; kind = P4_F3; break;                                                 // diagonal down-right
+    case 5: { int z = 2 * x - y;                                                                // vertical-right
+              c = z >= 0 ? 5 + x - (y >> 1) : z == -1 ? 5 : 6 - y; kind = (z >= 0 && !(z & 1)) ? P4_F2 : P4_F3; break; }
+    case 6: { int z = 2 * y - x, i = y - (x >> 1);                                              // horizontal-down
+              c = z >= 0 ? ((z & 1) ? 5 - i : 4 - i) : z == -1 ? 5 : 4 + x; kind = (z >= 0 && !(z & 1)) ? P4_F2 : P4_F3; break; }
+    case 7: { int i = x + (y >> 1); c = (y & 1) ? 7 + i : 6 + i; kind = (y & 1) ? P4_F3 : P4_F2; break; }   // vertical-left
+    default: { int z = x + 2 * y;                                                               // 8: horizontal-up
+              c = z >= 5 ? 1 : 3 - y - (x >> 1); kind = z > 5 ? P4_COPY : (z == 5 || (z & 1)) ? P4_F3 : P4_F2; break; }
     }
-    return 128;
 }
 
 // Reconstruct one intra macroblock with one wavefront.  Every global load the macroblock needs (neighbour samples,
@@ -221,20 +206,37 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         }
         wave_lds_fence();
         const int x = lane & 3, y = (lane >> 2) & 3;
+        // the lane's slot of the edge array: offset from the block origin inside the tile and the neighbour it belongs to
+        // (0 left, 1 top-left, 2 top, 3 top-right)
+        const int es = min(lane, 14);
+        const int eoff = es <= 4 ? (es == 0 ? 3 : 4 - es) * IT_STRIDE - 1 : es == 5 ? -IT_STRIDE - 1 : -IT_STRIDE + min(es - 6, 7);
+        const int eflag = es <= 4 ? 0 : es == 5 ? 1 : es <= 9 ? 2 : 3;
         for (int i = 0; i < 16; i++) {
             const int bx = blk_x(i), by = blk_y(i);
             const bool left = bx > 0 || aL, top = by > 0 || aT;
             const bool topleft = (bx > 0 && by > 0) ? true : bx > 0 ? aT : by > 0 ? aL : aTL;
             const bool topright = by == 0 ? (bx < 3 ? aT : aTR) : (0x5744 >> i) & 1;   // core/macroblock.c:1210-1231
             int mode = __builtin_amdgcn_readlane(modebyte, i);
-            if (mode == 2) mode = (left && top) ? 2 : left ? 9 : top ? 10 : 11;       // :677-695
             const uint8_t *o = L.y + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
-            int l[4], t[8], lt;
-            for (int k = 0; k < 4; k++) l[k] = left ? o[k * IT_STRIDE - 1] : 128;
-            for (int k = 0; k < 4; k++) t[k] = top ? o[-IT_STRIDE + k] : 128;
-            for (int k = 4; k < 8; k++) t[k] = topright ? o[-IT_STRIDE + k] : t[3];
-            lt = topleft ? o[-IT_STRIDE - 1] : 128;
-            int v = pred4x4_sample(mode, x, y, l, t, lt);
+            // ---- edge array, missing neighbours substituted (decoder/macroblock.c:697-713): 128, or t3 for the top-right ----
+            {
+                const unsigned avail = (unsigned)left | (unsigned)topleft << 1 | (unsigned)top << 2 | (unsigned)topright << 3;
+                const int own = o[eoff], t3 = o[-IT_STRIDE + 3];
+                const int alt = (eflag == 3 && top) ? t3 : 128;
+                if (lane < 15) L.edge[lane] = (uint8_t)(((avail >> eflag) & 1) ? own : alt);
+            }
+            wave_lds_fence();
+            int v;
+            if (mode == 2) {                                                           // DC and its fall-backs, :677-695
+                const uint8_t *S = L.edge;
+                const int sl = S[1] + S[2] + S[3] + S[4], st = S[6] + S[7] + S[8] + S[9];
+                v = (left && top) ? (sl + st + 4) >> 3 : left ? (sl + 2) >> 2 : top ? (st + 2) >> 2 : 128;
+            } else {
+                int c, kind;
+                pred4x4_where(mode, x, y, c, kind);
+                const int a = L.edge[c - 1], b = L.edge[c], d = L.edge[c + 1];
+                v = kind == P4_COPY ? b : kind == P4_F2 ? (b + d + 1) >> 1 : (a + 2 * b + d + 2) >> 2;
+            }
             if ((mask >> i) & 1) v = clip255(v + idct4x4_sample(L.coef + i * 16, x, y));
             if (lane < 16) L.y[(by * 4 + y + 1) * IT_STRIDE + 4 + bx * 4 + x] = (uint8_t)v;
             wave_lds_fence();

@@ -360,16 +360,28 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         const int lx = mv_x(mv0), ly = mv_y(mv0);
         // (lanes past the end of a window repeat its last dword and write it to unused LDS words: cheaper than masking them off)
         uint32_t yv[2], cvv = 0;
+        const int wy0 = Y0 + (ly >> 2) - 2, wcy0 = Y0 / 2 + (ly >> 3);
+        // windows that lie inside the picture (nearly all) need neither coordinate clamps nor border replication
+        const bool inside = ux0 >= 0 && (ux0 & ~3) + 24 <= g.w && wy0 >= 0 && wy0 + 21 <= g.h &&
+                            ucx0 >= 0 && (ucx0 & ~3) + 12 <= g.cw && wcy0 >= 0 && wcy0 + 9 <= g.ch;
+        const int cl = min(lane, 53);
+        const int cpl = cl >= 27, l2 = cl - 27 * cpl, cr = (l2 * 11) >> 5, cd = l2 - 3 * cr;   // l2 / 3 for l2 < 27
+        if (inside) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = min(lane + 64 * k, 125), r = (i * 43) >> 8, d = i - r * 6;       // i / 6 for i < 128
-            yv[k] = 0;
-            if (!EXP_NOLOAD) yv[k] = luma_dword(rf, g, (ux0 & ~3) + d * 4, Y0 + (ly >> 2) - 2 + r);
-        }
-        if (!EXP_NOLOAD) {
-            const int cl = min(lane, 53);
-            int p = cl >= 27, l2 = cl - 27 * p, r = (l2 * 11) >> 5, d = l2 - 3 * r;   // l2 / 3 for l2 < 27
-            cvv = chroma_dword(rf, g, p, (ucx0 & ~3) + d * 4, Y0 / 2 + (ly >> 3) + r);
+            for (int k = 0; k < 2; k++) {
+                const int i = min(lane + 64 * k, 125), r = (i * 43) >> 8, d = i - r * 6;       // i / 6 for i < 128
+                yv[k] = 0;
+                if (!EXP_NOLOAD) yv[k] = WLOAD(rf + luma_off(g, (ux0 & ~3) + d * 4, wy0 + r));
+            }
+            if (!EXP_NOLOAD) cvv = WLOAD(rf + chroma_off(g, cpl, (ucx0 & ~3) + cd * 4, wcy0 + cr));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int i = min(lane + 64 * k, 125), r = (i * 43) >> 8, d = i - r * 6;
+                yv[k] = 0;
+                if (!EXP_NOLOAD) yv[k] = luma_dword(rf, g, (ux0 & ~3) + d * 4, wy0 + r);
+            }
+            if (!EXP_NOLOAD) cvv = chroma_dword(rf, g, cpl, (ucx0 & ~3) + cd * 4, wcy0 + cr);
         }
         uint32_t *yw = &L.ywin[0][0], *cw = &L.cwin[0][0][0];
         yw[lane] = yv[0];

@@ -113,6 +113,18 @@ int  p264hip_device_count(void);
 
 /* Copy parsed pictures host->HBM into resident input slots [first, first+n). Asynchronous. */
 int  p264hip_upload(p264hip_ctx *ctx, int first, const p264hip_picture_t *pics, int n);
+/* The same without the final wait: the copies are only enqueued.  The picture's arrays must stay untouched until
+ * a marker taken after this call has been reached (p264hip_marker / p264hip_marker_wait) or p264hip_sync returns;
+ * they should live in pinned memory (p264hip_host_alloc) for the copies to be real DMA transfers. */
+int  p264hip_upload_async(p264hip_ctx *ctx, int slot, const p264hip_picture_t *pic);
+/* Pinned host memory for picture inputs (hipHostMalloc); usable without a context. */
+void *p264hip_host_alloc(size_t bytes);
+void  p264hip_host_free(void *p);
+/* A marker is a point in the context's stream; marker_wait blocks the calling host thread until everything
+ * enqueued before the marker has completed.  Markers are small integers >= 0 (a ring of P264HIP_MARKERS). */
+#define P264HIP_MARKERS 8
+int  p264hip_marker(p264hip_ctx *ctx);
+int  p264hip_marker_wait(p264hip_ctx *ctx, int marker);
 /* Device-side copy of resident picture `src` into slot `dst` (private HBM copy; bench set-up). */
 int  p264hip_clone_picture(p264hip_ctx *ctx, int dst, int src);
 

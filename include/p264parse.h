@@ -13,6 +13,7 @@
 #ifndef P264PARSE_H
 #define P264PARSE_H
 #include <stdint.h>
+#include <stddef.h>
 #include "p264hip.h"
 
 #ifdef __cplusplus
@@ -28,6 +29,9 @@ enum {
 };
 
 p264parse *p264parse_open(int options);
+/* Where the arrays of the picture descriptors live (default: malloc/free).  A pipeline passes pinned-memory
+ * functions so that the parser writes straight into DMA-able staging.  Call before the first slice NAL. */
+void       p264parse_set_allocator(p264parse *p, void *(*alloc)(size_t bytes), void (*release)(void *ptr));
 void       p264parse_close(p264parse *p);
 
 /* Feed one NAL unit (header byte already split off, emulation-prevention bytes already

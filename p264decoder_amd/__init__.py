@@ -12,6 +12,7 @@ shared library is missing, `_native.load()` raises.
 from . import _native
 from .recon import HipReconstructor, ParsedPicture, Parser, P264Error, device_count
 from .decoder import Decoder, param_default
+from .pipeline import Pipeline
 
-__all__ = ["Decoder", "param_default", "Parser", "ParsedPicture", "HipReconstructor", "P264Error",
+__all__ = ["Decoder", "param_default", "Pipeline", "Parser", "ParsedPicture", "HipReconstructor", "P264Error",
            "device_count", "_native"]

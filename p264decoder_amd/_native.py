@@ -46,6 +46,12 @@ class Picture(C.Structure):
 
 assert C.sizeof(MbInfo) == 16
 
+
+class PipeStats(C.Structure):
+    """p264pipe_stats_t"""
+    _fields_ = [("pictures", C.c_int64), ("bytes", C.c_int64), ("seconds", C.c_double), ("parse_seconds", C.c_double),
+                ("submit_seconds", C.c_double), ("rounds", C.c_int), ("streams", C.c_int), ("threads", C.c_int)]
+
 _lib = None
 
 
@@ -94,6 +100,30 @@ def load(path=None):
         lib.p264hip_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.p264hip_timing_reset.restype = C.c_int
         lib.p264hip_timing_reset.argtypes = [C.c_void_p]
+        lib.p264hip_upload_async.restype = C.c_int
+        lib.p264hip_upload_async.argtypes = [C.c_void_p, C.c_int, C.POINTER(Picture)]
+        lib.p264hip_host_alloc.restype = C.c_void_p
+        lib.p264hip_host_alloc.argtypes = [C.c_size_t]
+        lib.p264hip_host_free.argtypes = [C.c_void_p]
+        lib.p264hip_marker.restype = C.c_int
+        lib.p264hip_marker.argtypes = [C.c_void_p]
+        lib.p264hip_marker_wait.restype = C.c_int
+        lib.p264hip_marker_wait.argtypes = [C.c_void_p, C.c_int]
+    # ---- p264pipe.h
+    if hasattr(lib, "p264pipe_open"):
+        lib.p264pipe_open.restype = C.c_void_p
+        lib.p264pipe_open.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.p264pipe_set_input.restype = C.c_int
+        lib.p264pipe_set_input.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+        lib.p264pipe_run.restype = C.c_int
+        lib.p264pipe_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(PipeStats)]
+        lib.p264pipe_frame_size.restype = C.c_int
+        lib.p264pipe_frame_size.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.p264pipe_read_frame.restype = C.c_int
+        lib.p264pipe_read_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        lib.p264pipe_stream_pictures.restype = C.c_int64
+        lib.p264pipe_stream_pictures.argtypes = [C.c_void_p, C.c_int]
+        lib.p264pipe_close.argtypes = [C.c_void_p]
     if path is None:
         _lib = lib
     return lib

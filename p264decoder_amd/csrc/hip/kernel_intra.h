@@ -337,8 +337,8 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                 intra = P264_MB_IS_INTRA(rec.x & 255);
                 if (row > 0) {
                     const AS1 p264hip_mb_t *up = recs - g.mb_w;
-                    dep = P264_MB_IS_INTRA(up[x].mb_type) | P264_MB_IS_INTRA(up[max(x - 1, 0)].mb_type) |
-                          P264_MB_IS_INTRA(up[min(x + 1, g.mb_w - 1)].mb_type);
+                    dep = (int)P264_MB_IS_INTRA(up[x].mb_type) | (int)P264_MB_IS_INTRA(up[max(x - 1, 0)].mb_type) |
+                          (int)P264_MB_IS_INTRA(up[min(x + 1, g.mb_w - 1)].mb_type);
                 }
             }
             unsigned long long todo = __ballot(intra);

@@ -75,6 +75,8 @@ struct p264hip_ctx {
     int *d_status = nullptr;
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
+    hipEvent_t markers[P264HIP_MARKERS] = {};
+    int next_marker = 0;
     bool timing = false;
     struct Stamp { hipEvent_t a, b; int k; };
     std::vector<Stamp> stamps;
@@ -137,6 +139,7 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     if (c->frames) (void)hipFree(c->frames);
     if (c->d_edge) (void)hipFree(c->d_edge);
     if (c->d_planar) (void)hipFree(c->d_planar);
+    for (auto &m : c->markers) if (m) (void)hipEventDestroy(m);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -193,6 +196,40 @@ extern "C" int p264hip_upload(p264hip_ctx *c, int first, const p264hip_picture_t
     for (int i = 0; i < n; i++) { int rc = upload_one(c, first + i, &pics[i]); if (rc) return rc; }
     // sources are pageable host memory owned by the caller: make sure they are consumed before returning
     HIPCHK(hipStreamSynchronize(c->stream));
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_upload_async(p264hip_ctx *c, int slot, const p264hip_picture_t *pic)
+{
+    if (!c || !pic || slot < 0 || slot >= c->max_pictures) return fail(P264HIP_EINVAL, "p264hip_upload_async: bad slot %d", slot);
+    HIPCHK(hipSetDevice(c->device));
+    return upload_one(c, slot, pic);
+}
+
+extern "C" void *p264hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void p264hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int p264hip_marker(p264hip_ctx *c)
+{
+    if (!c) return fail(P264HIP_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    const int m = c->next_marker; c->next_marker = (c->next_marker + 1) % P264HIP_MARKERS;
+    if (!c->markers[m]) HIPCHK(hipEventCreateWithFlags(&c->markers[m], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->markers[m], c->stream));
+    return m;
+}
+
+extern "C" int p264hip_marker_wait(p264hip_ctx *c, int marker)
+{
+    if (!c || marker < 0 || marker >= P264HIP_MARKERS || !c->markers[marker]) return fail(P264HIP_EINVAL, "p264hip_marker_wait: bad marker %d", marker);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->markers[marker]));
     return P264HIP_OK;
 }
 

@@ -52,6 +52,7 @@ typedef struct { int used, frame_num, pic_num; } dpb_frame_t;
 typedef struct {
     p264hip_mb_t *mb; int16_t *mv; int8_t *ref; uint8_t *i4; int16_t *coef;
     size_t coef_cap, coef_n;
+    void *(*alloc)(size_t); void (*release)(void *);   /* where the arrays live (p264parse_set_allocator) */
 } picbuf_t;
 
 struct p264parse {
@@ -62,6 +63,7 @@ struct p264parse {
     int mb_w, mb_h, n_mb, slots;
 
     picbuf_t buf[2]; int cur;                 /* cur: being built; 1-cur: last completed */
+    void *(*alloc)(size_t); void (*release)(void *);
     p264hip_picture_t desc[2];
     uint8_t  *nnz;                            /* [n_mb][24] total_coeff per 4x4 block */
     uint16_t *slice_of;                       /* [n_mb] slice number inside the picture, 0xffff = not decoded */
@@ -170,8 +172,9 @@ static int parse_pps(p264parse *p, bitrd_t *b)
 static void free_context(p264parse *p)
 {
     for (int i = 0; i < 2; i++) {
-        free(p->buf[i].mb); free(p->buf[i].mv); free(p->buf[i].ref); free(p->buf[i].i4); free(p->buf[i].coef);
-        memset(&p->buf[i], 0, sizeof p->buf[i]);
+        picbuf_t *q = &p->buf[i];
+        if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); }
+        memset(q, 0, sizeof *q);
     }
     free(p->nnz); p->nnz = NULL;
     free(p->slice_of); p->slice_of = NULL;
@@ -188,13 +191,16 @@ static int init_context(p264parse *p, int sps_id, int pps_id)
     size_t n = (size_t)p->n_mb;
     for (int i = 0; i < 2; i++) {
         picbuf_t *q = &p->buf[i];
-        q->mb  = (p264hip_mb_t *)calloc(n, sizeof(p264hip_mb_t));
-        q->mv  = (int16_t *)calloc(n * 32, sizeof(int16_t));
-        q->ref = (int8_t *)calloc(n * 4, 1);
-        q->i4  = (uint8_t *)calloc(n * 16, 1);
+        q->alloc = p->alloc ? p->alloc : malloc; q->release = p->release ? p->release : free;
+        q->mb  = (p264hip_mb_t *)q->alloc(n * sizeof(p264hip_mb_t));
+        q->mv  = (int16_t *)q->alloc(n * 32 * sizeof(int16_t));
+        q->ref = (int8_t *)q->alloc(n * 4);
+        q->i4  = (uint8_t *)q->alloc(n * 16);
         q->coef_cap = n * 4 + 64;
-        q->coef = (int16_t *)malloc(q->coef_cap * 16 * sizeof(int16_t));
+        q->coef = (int16_t *)q->alloc(q->coef_cap * 16 * sizeof(int16_t));
         if (!q->mb || !q->mv || !q->ref || !q->i4 || !q->coef) return -1;
+        memset(q->mb, 0, n * sizeof(p264hip_mb_t)); memset(q->mv, 0, n * 32 * sizeof(int16_t));
+        memset(q->ref, 0, n * 4); memset(q->i4, 0, n * 16);
     }
     p->nnz = (uint8_t *)calloc(n, 24);
     p->slice_of = (uint16_t *)malloc(n * sizeof(uint16_t));
@@ -436,8 +442,10 @@ static int coef_reserve(picbuf_t *q, size_t more)
 {
     if (q->coef_n + more <= q->coef_cap) return 0;
     size_t cap = q->coef_cap * 2 + more;
-    int16_t *n = (int16_t *)realloc(q->coef, cap * 16 * sizeof(int16_t));
+    int16_t *n = (int16_t *)q->alloc(cap * 16 * sizeof(int16_t));
     if (!n) return -1;
+    memcpy(n, q->coef, q->coef_n * 16 * sizeof(int16_t));
+    q->release(q->coef);
     q->coef = n; q->coef_cap = cap;
     return 0;
 }
@@ -749,6 +757,12 @@ p264parse *p264parse_open(int options)
     p->opts = options;
     p->active_sps = p->active_pps = -1;
     return p;
+}
+
+void p264parse_set_allocator(p264parse *p, void *(*alloc)(size_t bytes), void (*release)(void *ptr))
+{
+    if (!p || p->n_mb) return;                              /* only before the first context is built */
+    p->alloc = alloc; p->release = release;
 }
 
 void p264parse_close(p264parse *p)

@@ -1,0 +1,224 @@
+/* pipeline.c - multi-stream, multi-threaded decode pipeline on top of the two C ABIs
+ * (p264parse.h: host bitstream layer, p264hip.h: MI355X reconstruction).  See include/p264pipe.h.
+ *
+ * Round r: every stream that still has data gets its next picture parsed (threads pull streams from a shared
+ * counter); when all are done the main thread hands the picture descriptors to the GPU - asynchronous uploads
+ * out of the parsers' pinned double buffers, one batched reconstruct - and immediately releases the threads
+ * into round r+1.  A parser reuses the buffers of round r-1 in round r+1, so before releasing the threads
+ * the main thread waits for the marker taken after round r-1's uploads: the only host-side wait on the device.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "p264pipe.h"
+#include "p264parse.h"
+#include "p264hip.h"
+#include "p264_dropin.h"
+
+typedef struct {
+    p264parse *parser;
+    const uint8_t *in; int64_t size, pos;
+    uint8_t *rbsp; int64_t rbsp_cap;
+    const p264hip_picture_t *pic;        /* picture completed in the current round, or NULL */
+    int done, failed, last_slot;
+    int64_t pictures;
+} pstream_t;
+
+struct p264pipe {
+    int device, n_streams, n_threads;
+    pstream_t *st;
+    p264hip_ctx *ctx; int mb_w, mb_h, slots;
+    /* thread pool: generation counter + two condition variables */
+    pthread_t *threads; int started;
+    pthread_mutex_t mu; pthread_cond_t go, idle;
+    int generation, busy, quit, next_stream, max_pictures;
+    double parse_seconds;
+};
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* feed NAL units of one stream until a picture completes or the stream ends */
+static void parse_one(p264pipe *p, pstream_t *s)
+{
+    s->pic = NULL;
+    if (s->done || (p->max_pictures > 0 && s->pictures >= p->max_pictures)) { s->done = 1; return; }
+    int64_t off, len;
+    while (p264_annexb_next(s->in, s->size, &s->pos, &off, &len)) {
+        if (len < 1) continue;
+        if (len + 8 > s->rbsp_cap) {
+            free(s->rbsp); s->rbsp_cap = len * 2 + 64; s->rbsp = (uint8_t *)malloc((size_t)s->rbsp_cap);
+            if (!s->rbsp) { s->failed = 1; s->done = 1; return; }
+        }
+        p264_nal_t nal; nal.p_payload = s->rbsp;
+        p264_nal_decode(&nal, (void *)(s->in + off), (int)len);
+        const p264hip_picture_t *pic = NULL;
+        int rc = p264parse_nal(s->parser, nal.i_type, nal.i_ref_idc, nal.p_payload, nal.i_payload, &pic);
+        if (rc < 0) { s->failed = 1; s->done = 1; return; }
+        if (rc == 1) { s->pic = pic; s->pictures++; return; }
+    }
+    s->done = 1;
+}
+
+static void *worker(void *arg)
+{
+    p264pipe *p = (p264pipe *)arg;
+    int seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        while (p->generation == seen && !p->quit) pthread_cond_wait(&p->go, &p->mu);
+        if (p->quit) { pthread_mutex_unlock(&p->mu); return NULL; }
+        seen = p->generation;
+        pthread_mutex_unlock(&p->mu);
+        double spent = 0;
+        for (;;) {
+            int i = __atomic_fetch_add(&p->next_stream, 1, __ATOMIC_RELAXED);
+            if (i >= p->n_streams) break;
+            double t0 = now_s();
+            parse_one(p, &p->st[i]);
+            spent += now_s() - t0;
+        }
+        pthread_mutex_lock(&p->mu);
+        p->parse_seconds += spent;
+        if (--p->busy == 0) pthread_cond_signal(&p->idle);
+        pthread_mutex_unlock(&p->mu);
+    }
+}
+
+static void start_round(p264pipe *p)
+{
+    pthread_mutex_lock(&p->mu);
+    p->next_stream = 0; p->busy = p->n_threads; p->generation++;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->mu);
+}
+static void finish_round(p264pipe *p)
+{
+    pthread_mutex_lock(&p->mu);
+    while (p->busy) pthread_cond_wait(&p->idle, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+
+p264pipe *p264pipe_open(int device, int n_streams, int n_threads)
+{
+    if (n_streams < 1 || n_threads < 1) return NULL;
+    if (device >= 0 && p264hip_device_count() <= device) {
+        fprintf(stderr, "p264pipe_open: no HIP device %d (there is no CPU fallback for the reconstruction; device -1 runs the parsers only)\n", device);
+        return NULL;
+    }
+    p264pipe *p = (p264pipe *)calloc(1, sizeof *p);
+    if (!p) return NULL;
+    p->device = device; p->n_streams = n_streams; p->n_threads = n_threads < n_streams ? n_threads : n_streams;
+    p->st = (pstream_t *)calloc((size_t)n_streams, sizeof *p->st);
+    p->threads = (pthread_t *)calloc((size_t)p->n_threads, sizeof *p->threads);
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->idle, NULL);
+    if (!p->st || !p->threads) { p264pipe_close(p); return NULL; }
+    for (int i = 0; i < n_streams; i++) {
+        p->st[i].parser = p264parse_open(P264PARSE_OPT_QUIET);
+        if (!p->st[i].parser) { p264pipe_close(p); return NULL; }
+        if (device >= 0) p264parse_set_allocator(p->st[i].parser, p264hip_host_alloc, p264hip_host_free);
+        p->st[i].last_slot = -1;
+    }
+    for (int i = 0; i < p->n_threads; i++) {
+        if (pthread_create(&p->threads[i], NULL, worker, p)) { p264pipe_close(p); return NULL; }
+        p->started++;
+    }
+    return p;
+}
+
+int p264pipe_set_input(p264pipe *p, int stream, const uint8_t *annexb, int64_t size)
+{
+    if (!p || stream < 0 || stream >= p->n_streams || !annexb || size < 0) return -1;
+    pstream_t *s = &p->st[stream];
+    s->in = annexb; s->size = size; s->pos = 0; s->done = 0; s->failed = 0; s->pictures = 0; s->pic = NULL;
+    return 0;
+}
+
+int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
+{
+    if (!p) return -1;
+    for (int i = 0; i < p->n_streams; i++) if (!p->st[i].in) { fprintf(stderr, "p264pipe_run: stream %d has no input\n", i); return -1; }
+    p->max_pictures = max_pictures; p->parse_seconds = 0;
+    int *ids = (int *)malloc(sizeof(int) * (size_t)p->n_streams), *sts = (int *)malloc(sizeof(int) * (size_t)p->n_streams);
+    const p264hip_picture_t **pics = (const p264hip_picture_t **)malloc(sizeof(void *) * (size_t)p->n_streams);
+    if (!ids || !sts || !pics) { free(ids); free(sts); free(pics); return -1; }
+    int markers[2] = { -1, -1 }, rounds = 0, rc = 0;
+    int64_t pictures = 0;
+    double submit = 0;
+    const double t0 = now_s();
+    start_round(p);                                          /* round 0 */
+    for (int r = 0;; r++) {
+        finish_round(p);
+        int n = 0;
+        for (int i = 0; i < p->n_streams; i++) {
+            pstream_t *s = &p->st[i];
+            if (s->failed) rc = -1;
+            if (s->pic) { pics[n] = s->pic; sts[n] = i; ids[n] = i * 2 + (r & 1); s->last_slot = s->pic->dst_slot; n++; }
+        }
+        if (n == 0 || rc) break;
+        rounds++; pictures += n;
+        if (p->device >= 0 && !p->ctx) {                     /* geometry is known after the first picture */
+            p->mb_w = pics[0]->mb_w; p->mb_h = pics[0]->mb_h; p->slots = p264parse_slots(p->st[sts[0]].parser);
+            if (p264hip_create(&p->ctx, p->device, p->mb_w, p->mb_h, p->n_streams, p->slots, p->n_streams * 2)) {
+                fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; break;
+            }
+        }
+        /* the parsers are about to overwrite the buffers of round r-1: its uploads must have been consumed */
+        if (p->ctx && markers[(r + 1) & 1] >= 0 && p264hip_marker_wait(p->ctx, markers[(r + 1) & 1])) { rc = -1; break; }
+        start_round(p);                                      /* round r+1 parses while round r is submitted and runs */
+        if (p->ctx) {
+            const double s0 = now_s();
+            for (int k = 0; k < n && !rc; k++) {
+                if (pics[k]->mb_w != p->mb_w || pics[k]->mb_h != p->mb_h) { fprintf(stderr, "p264pipe_run: stream %d has a different picture size\n", sts[k]); rc = -1; }
+                else if (p264hip_upload_async(p->ctx, ids[k], pics[k])) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
+            }
+            if (!rc && p264hip_reconstruct(p->ctx, ids, sts, n)) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
+            if (!rc) { markers[r & 1] = p264hip_marker(p->ctx); if (markers[r & 1] < 0) rc = -1; }
+            submit += now_s() - s0;
+            if (rc) { finish_round(p); break; }
+        }
+    }
+    if (p->ctx && p264hip_sync(p->ctx)) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
+    const double t1 = now_s();
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->pictures = pictures; stats->seconds = t1 - t0; stats->parse_seconds = p->parse_seconds; stats->submit_seconds = submit;
+        stats->rounds = rounds; stats->streams = p->n_streams; stats->threads = p->n_threads;
+        for (int i = 0; i < p->n_streams; i++) stats->bytes += p->st[i].pos;
+    }
+    free(ids); free(sts); free(pics);
+    return rc;
+}
+
+int p264pipe_frame_size(p264pipe *p, int *width, int *height)
+{
+    if (!p || !p->mb_w) return -1;
+    if (width) *width = p->mb_w * 16;
+    if (height) *height = p->mb_h * 16;
+    return 0;
+}
+
+int p264pipe_read_frame(p264pipe *p, int stream, uint8_t *y, int y_stride, uint8_t *u, uint8_t *v, int c_stride)
+{
+    if (!p || !p->ctx || stream < 0 || stream >= p->n_streams || p->st[stream].last_slot < 0) return -1;
+    return p264hip_read_frame(p->ctx, stream, p->st[stream].last_slot, y, y_stride, u, v, c_stride) ? -1 : 0;
+}
+
+int64_t p264pipe_stream_pictures(p264pipe *p, int stream)
+{
+    return (p && stream >= 0 && stream < p->n_streams) ? p->st[stream].pictures : -1;
+}
+
+void p264pipe_close(p264pipe *p)
+{
+    if (!p) return;
+    pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->go); pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->started; i++) pthread_join(p->threads[i], NULL);
+    if (p->ctx) { (void)p264hip_sync(p->ctx); }
+    if (p->st) for (int i = 0; i < p->n_streams; i++) { if (p->st[i].parser) p264parse_close(p->st[i].parser); free(p->st[i].rbsp); }
+    if (p->ctx) p264hip_destroy(p->ctx);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->idle);
+    free(p->st); free(p->threads); free(p);
+}

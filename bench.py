@@ -88,12 +88,33 @@ def cpu_baseline(stream_path, n_pictures):
             "sample": "%d 1920x1088 pictures through the scalar oracle (reconstruction only, parse excluded)" % n}
 
 
+def measured_copy_bandwidth(torch):
+    """Achievable HBM ceiling on this box next to the 8 TB/s vendor peak: device-to-device copy of 1 GiB,
+    bytes read + bytes written per second."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    a.fill_(1)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbps = 2.0 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    return round(gbps, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=512, help="independent 1080p streams per GPU")
+    ap.add_argument("--streams", type=int, default=1024, help="independent 1080p streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -159,6 +180,7 @@ def main():
         a, b = hip.read_frame(0, last_slot), hip.read_frame(DISTINCT, last_slot)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), "stream copies diverged"
 
+    copy_gbps = measured_copy_bandwidth(torch) if rank == 0 else None
     if rank == 0:
         frames = S * K * world
         fps = frames / elapsed
@@ -188,7 +210,8 @@ def main():
             "macroblocks_per_s": round(fps * N_MB, 0),
             "roofline": {"kernel": "k_" + dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"]},
+                         "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
+                         "measured_copy_GBps": copy_gbps},
             "kernels": kernels,
             "reconstruct_call_ms": round(timing["reconstruct"][0] / max(timing["reconstruct"][1], 1), 4),
         }

@@ -320,9 +320,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     }
     {
         ScopedStamp t(c, 1);
-        // one workgroup per picture: 16 wavefronts while every picture can have a CU to itself, else 8 so that two
-        // pictures share a CU (the kernel is dependency/latency bound: measured +19 % at 512 pictures)
-        int intra_waves = n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
+        // one workgroup per picture: 16 wavefronts while every picture can have a CU to itself, else 8 or 4 so that two or
+        // four pictures share a CU (the kernel is dependency/latency bound: measured +19 % at 512 and +9 % at 1024 pictures)
+        int intra_waves = n > 2 * c->n_cu ? INTRA_ROW_WAVES / 4 : n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
         if (const char *e = getenv("P264AMD_INTRA_WAVES")) { int v = atoi(e); if (v >= 1 && v <= INTRA_ROW_WAVES) intra_waves = v; }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(intra_waves * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
     }
@@ -331,10 +331,15 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         hipLaunchKernelGGL(k_deblock_bs, dim3(g.mb_h, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge);
         // a wavefront filters 8 macroblock rows at a time: 8 rows of one picture while there are no more
         // pictures than compute units, else 4 rows of two pictures (or 2 of four) per workgroup
-        int rb_log2 = n > 3 * c->n_cu ? 1 : n > c->n_cu ? 2 : 3;
-        if (const char *e = getenv("P264AMD_DEBLOCK_RB_LOG2")) { int v = atoi(e); if (v >= 1 && v <= 3) rb_log2 = v; }
-        int per_wg = 8 >> rb_log2;
-        if (const char *e = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) { int v = atoi(e); if (v >= 1 && v <= per_wg) per_wg = v; }
+        // pictures per workgroup = as many as it takes to cover the batch with one workgroup per CU (at most 4; a
+        // second half-empty round of workgroups costs more than thinner bands), band height = 8 / pictures, rounded down
+        // to a power of two
+        int per_wg = (n + c->n_cu - 1) / c->n_cu;
+        if (per_wg < 1) per_wg = 1;
+        if (per_wg > 4) per_wg = 4;
+        int rb_log2 = per_wg == 1 ? 3 : per_wg == 2 ? 2 : 1;
+        if (const char *e = getenv("P264AMD_DEBLOCK_RB_LOG2")) { int v = atoi(e); if (v >= 1 && v <= 3) { rb_log2 = v; per_wg = 8 >> v; } }
+        if (const char *e = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) { int v = atoi(e); if (v >= 1 && v <= (8 >> rb_log2)) per_wg = v; }
         const int n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
         const int waves = n_bands < ROW_WAVES ? n_bands : ROW_WAVES;
         hipLaunchKernelGGL(k_deblock, dim3((n + per_wg - 1) / per_wg), dim3(waves * 64), 0, c->stream, c->d_batch[r], g,

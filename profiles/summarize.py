@@ -37,7 +37,7 @@ for k, ctrs in agg.items():
         pmc[k][c] = round(sum(vals) / len(vals))
     pmc[k]["launches_averaged"] = len(vals)
 note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline` "
-        "(512 1080p pictures per launch), separate rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as reported")
+        "(1024 1080p pictures per launch), separate rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as reported")
 json.dump({"note": note, **pmc}, open(os.path.join(here, tag + "_pmc.json"), "w"), indent=1)
 
 def hbm(k):

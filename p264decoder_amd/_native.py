@@ -20,6 +20,7 @@ COEF_LUMA_DC = 1 << 24
 COEF_CHROMA_DC = 1 << 25
 AVAIL_LEFT, AVAIL_TOP, AVAIL_TOPRIGHT, AVAIL_TOPLEFT = 1, 2, 4, 8
 EDGE_LEFT, EDGE_TOP, EDGE_INNER = 1, 2, 4
+MBF_QUADS = 1
 
 
 class MbInfo(C.Structure):
@@ -27,7 +28,7 @@ class MbInfo(C.Structure):
     _fields_ = [
         ("mb_type", C.c_uint8), ("qp", C.c_uint8), ("cbp", C.c_uint8), ("intra_modes", C.c_uint8),
         ("coef_mask", C.c_uint32), ("coef_index", C.c_uint32),
-        ("avail", C.c_uint8), ("edges", C.c_uint8), ("reserved", C.c_uint16),
+        ("avail", C.c_uint8), ("edges", C.c_uint8), ("flags", C.c_uint16),
     ]
 
 
@@ -41,6 +42,7 @@ class Picture(C.Structure):
         ("n_coef_blocks", C.c_uint32), ("frame_num", C.c_uint32),
         ("mb", C.POINTER(MbInfo)), ("mv", C.POINTER(C.c_int16)), ("ref_idx", C.POINTER(C.c_int8)),
         ("i4modes", C.POINTER(C.c_uint8)), ("coefs", C.POINTER(C.c_int16)),
+        ("quads", C.POINTER(C.c_uint32)), ("n_quads", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

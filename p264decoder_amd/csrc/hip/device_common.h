@@ -20,7 +20,8 @@ struct PicDev {
     uint8_t            *dst;       // frame base (macroblock-tiled, see MB_TILE)
     const uint8_t      *ref[P264HIP_MAX_REFS];
     int32_t n_ref, slice_type, chroma_qp_offset, deblock, alpha_off, beta_off;
-    int32_t pad[2];
+    int32_t n_quads, pad;
+    const uint32_t     *quads;     // quadrant list (p264hip.h), n_quads entries incl. padding
 };
 
 // The fields of a PicDev a kernel needs, fetched with TWO loads issued together (the descriptor address is
@@ -35,7 +36,7 @@ struct PicHead {
 };
 __device__ __forceinline__ PicHead load_pic_head(const PicDev *pd)
 {
-    static_assert(offsetof(PicDev, ref) == 48 && offsetof(PicDev, n_ref) == 176 && sizeof(PicDev) == 208, "PicDev layout");
+    static_assert(offsetof(PicDev, ref) == 48 && offsetof(PicDev, n_ref) == 176 && offsetof(PicDev, quads) == 208 && sizeof(PicDev) == 216, "PicDev layout");
     const u32x16 a = *(const u32x16 *)pd;
     const u32x4v b = *(const u32x4v *)((const char *)pd + 176);
     auto p64 = [&](int i) { return ((uint64_t)a[2 * i + 1] << 32) | a[2 * i]; };
@@ -86,6 +87,7 @@ __device__ __forceinline__ uint4 gload4(const void *p) { u32x4 v = *(const AS1 u
 __device__ __forceinline__ uint2 gload2(const void *p) { u32x2 v = *(const AS1 u32x2 *)p; return make_uint2(v.x, v.y); }
 __device__ __forceinline__ uint2 gload2(const AS1 void *p) { u32x2 v = *(const AS1 u32x2 *)p; return make_uint2(v.x, v.y); }
 __device__ __forceinline__ uint32_t gload1(const void *p) { return *(const AS1 uint32_t *)p; }
+__device__ __forceinline__ uint32_t gload1(const AS1 void *p) { return *(const AS1 uint32_t *)p; }
 __device__ __forceinline__ void gstore4(void *p, uint4 v) { u32x4 t = { v.x, v.y, v.z, v.w }; *(AS1 u32x4 *)p = t; }
 __device__ __forceinline__ void gstore2(void *p, uint2 v) { u32x2 t = { v.x, v.y }; *(AS1 u32x2 *)p = t; }
 __device__ __forceinline__ void gstore1(void *p, uint32_t v) { *(AS1 uint32_t *)p = v; }

@@ -319,7 +319,8 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     const int mb_type = w0 & 255, qp = (w0 >> 8) & 255, cbp = (w0 >> 16) & 255;
     // (the second term is never true; it makes the vector and the reference indices part of this branch, so that their
     // loads are issued with the record's instead of being sunk below it - one round trip instead of two)
-    if (P264_MB_IS_INTRA(mb_type) | ((ph.n_ref < 0) & (__ballot(mvreg_raw == 0x7fffffff) != 0) & (refs4_raw == 0x7fffffff))) return;
+    // macroblocks flagged P264_MBF_QUADS are motion-compensated by k_inter_quads
+    if (P264_MB_IS_INTRA(mb_type) | (int)((rfl((int)rec.w) >> 16) & P264_MBF_QUADS) | ((ph.n_ref < 0) & (__ballot(mvreg_raw == 0x7fffffff) != 0) & (refs4_raw == 0x7fffffff))) return;
     const int16_t *cf = ph.coefs + (size_t)(unsigned)rfl((int)rec.z) * 16;
     const int mvreg = lane < 16 ? mvreg_raw : 0;
     const int refs4 = rfl(refs4_raw);
@@ -519,4 +520,139 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
     uint8_t *tile = ph.dst + (size_t)mbi * MB_TILE;
     gstore1(tile + lane * 4, outY);
     if (lane < 32) gstore1(tile + MB_TILE_U + lane * 4, outC);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// K1b k_inter_quads - macroblocks with one vector per 8x8 quadrant (16x8, 8x16, P_8x8), quadrant by quadrant.
+//
+// In k_inter such a macroblock costs 2.5x a single-vector one: one interpolation pass per distinct vector with most lanes
+// idle.  Here the work item is the QUADRANT (8x8 luma + two 4x4 chroma blocks with their residuals), and the host parser
+// hands the quadrants over sorted by quarter-pel phase (p264hip_picture_t.quads): a wavefront takes four list entries -
+// four quadrants of the same phase from whatever macroblocks - so the phase is wave-uniform again, every lane works in
+// the one interpolation pass, and nothing is sorted on the device.  16 lanes per quadrant: lane l produces luma dword
+// (row l>>1, dword l&1) and, for l < 8, chroma row l&3 of plane l>>2.
+// Same arithmetic and the same helpers as k_inter; only the bookkeeping is per 16-lane group instead of per wavefront.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 8)
+void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw)
+{
+    __shared__ InterLds lds[4];
+    const PicDev *pd = pics + blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_quads = pd->n_quads;
+    const int item0 = (blockIdx.x * 4 + wave) * 4;
+    if (item0 >= n_quads) return;
+    const PicHead ph = load_pic_head(pd);
+    const int grp = lane >> 4, l = lane & 15;
+    InterLds &L = lds[wave];
+
+    // ---- the group's work item; padding entries repeat the wave's first (always real) entry and store nothing ----
+    const uint32_t item_raw = glob(pd->quads)[item0 + grp];
+    const bool valid = item_raw != 0xffffffffu;
+    const uint32_t item = valid ? item_raw : glob(pd->quads)[item0];     // (a uniform load: the wave's first entry)
+    const int mbi = (int)(item >> 2), q = (int)(item & 3);
+    const uint4 rec = gload4(ph.mb + mbi);
+    const int b0 = (q >> 1) * 8 + (q & 1) * 2;
+    const int mv = glob(ph.mv)[mbi * 16 + b0];
+    int ri = glob(ph.ref_idx)[mbi * 4 + q];
+    if (ri < 0 || ri >= ph.n_ref) ri = 0;
+    const uint8_t *ref = (const uint8_t *)glob((const uint64_t *)pd->ref)[ri];
+    const unsigned mask = rec.y;
+    const int qp = (rec.x >> 8) & 255, cbp = (rec.x >> 16) & 255;
+    const AS1 int16_t *cf = glob(ph.coefs) + (size_t)rec.z * 16;
+    int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+    const int mbx = mbi - mby * g.mb_w;
+    const int X0 = mbx * 16 + (q & 1) * 8, Y0 = mby * 16 + (q >> 1) * 8;        // quadrant origin (luma)
+
+    // ---- coded coefficients of the quadrant: luma blocks 4q .. 4q+3 (lane: block l>>2, levels 4*(l&3)..+3), chroma blocks
+    //      16+q and 20+q (lane: plane l>>3, levels 2*(l&7)..+1), the macroblock's 8 chroma DC levels in lanes 0..7 ----
+    uint2 lc = make_uint2(0, 0); uint32_t cc = 0, cdc_raw = 0;
+    const int lb = q * 4 + (l >> 2), cb = 16 + q + 4 * (l >> 3);
+    if (mask) {
+        if ((mask >> lb) & 1) lc = gload2(cf + coef_slot(mask, lb) * 16 + (l & 3) * 4);
+        if ((mask >> cb) & 1) cc = gload1(cf + coef_slot(mask, cb) * 16 + (l & 7) * 2);
+        if ((mask & P264_COEF_CHROMA_DC) && l < 8) cdc_raw = glob((const uint16_t *)cf)[((mask >> 24) & 1) * 16 + l];
+    }
+
+    // ---- reference windows: luma 13 rows x 4 dwords (lane: dword l&3 of rows (l>>2) + 4k), chroma 5 rows x 2 dwords per
+    //      plane (lanes 0..9); every lane loads, lanes past the end repeat the last row ----
+    const int wx0 = X0 + (mv_x(mv) >> 2) - 2, wy0 = Y0 + (mv_y(mv) >> 2) - 2;
+    const int cx0 = X0 / 2 + (mv_x(mv) >> 3), cy0 = Y0 / 2 + (mv_y(mv) >> 3);
+    {
+        uint32_t yv[4], cv[2];
+        const int xa = (wx0 & ~3) + (l & 3) * 4, xc = clip3i(xa, 0, g.w - 4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = min((l >> 2) + 4 * k, 12);
+            yv[k] = WLOAD(ref + luma_off(g, xc, clip3i(wy0 + r, 0, g.h - 1)));
+        }
+        const int cr = min(l, 9) >> 1, cxa = (cx0 & ~3) + (l & 1) * 4;
+        const uint32_t coff = chroma_off(g, 0, clip3i(cxa, 0, g.cw - 4), clip3i(cy0 + cr, 0, g.ch - 1));
+        cv[0] = WLOAD(ref + coff); cv[1] = WLOAD(ref + coff + 64);
+#pragma unroll
+        for (int k = 0; k < 4; k++) yv[k] = edge_fix(yv[k], xa, g.w);
+        cv[0] = edge_fix(cv[0], cxa, g.cw); cv[1] = edge_fix(cv[1], cxa, g.cw);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = (l >> 2) + 4 * k;
+            if (r < 13) L.ywin[grp][r * 4 + (l & 3)] = yv[k];
+        }
+        if (l < 10) { L.cwin[0][grp][l] = cv[0]; L.cwin[1][grp][l] = cv[1]; }
+    }
+    wave_lds_fence();
+
+    // ---- prediction: the quarter-pel phase is the same for all four quadrants of the wave (the list is sorted by it) ----
+    const int fx = rfl(mv_x(mv) & 3), fy = rfl(mv_y(mv) & 3);
+    const int row = l >> 1, dw = l & 1;                         // luma: (row, dword) inside the 8x8 quadrant
+    const int cp = (l >> 2) & 1, crow = l & 3;                  // chroma (lanes 0..7): plane, row of the 4x4 block
+    uint32_t outY = qpel4<4>(L.ywin[grp], row + 2, (wx0 & 3) + 2 + dw * 4, fx, fy), outC = 0;
+    if (l < 8) outC = chroma4<2>(L.cwin[cp][grp] + crow * 2, cx0 & 3, mv_x(mv) & 7, mv_y(mv) & 7);
+
+    // ---- residual (decoder/macroblock.c:832-890): six blocks per quadrant, L.coef[(6*grp + block)*16 + raster position] ----
+    if (__ballot(mask != 0)) {
+        int16_t *co = L.coef + grp * 96;
+        {
+            const DqParams dq = dq_params(qp);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int pos = zigzag_pos((l & 3) * 4 + kk);
+                const int c = (int)(int16_t)((kk & 2 ? lc.y : lc.x) >> (16 * (kk & 1)));
+                co[(l >> 2) * 16 + pos] = (int16_t)dequant_coef(c, pos, dq);
+            }
+        }
+        {   // chroma: DC (core/dct.c:55-68, core/quant.c:138-159) + AC of block q of both planes
+            const int qpc = chroma_qp(clip3i(qp + ph.chroma_qp_offset, 0, 51));
+            const DqParams dq = dq_params(qpc);
+            const int pl = l >> 3, i2 = l & 7;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {                  // level index 2*i2+kk sits at scan position 2*i2+kk+1
+                const int k = 2 * i2 + kk + 1;
+                if (k < 16) { const int pos = zigzag_pos(k); co[(4 + pl) * 16 + pos] = (int16_t)dequant_coef((int)(int16_t)(cc >> (16 * kk)), pos, dq); }
+            }
+            // lanes 0..7 of the group hold the DC levels of (plane = lane>>2, index lane&3); all shuffles before any use
+            const int cdc = (int)(int16_t)cdc_raw, base = (lane & 48) + pl * 4;
+            const int d0 = __shfl(cdc, base), d1 = __shfl(cdc, base + 1), d2 = __shfl(cdc, base + 2), d3 = __shfl(cdc, base + 3);
+            if (i2 == 0) {
+                const int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
+                int f = pick_addsub(t0, t1, t2, t3, q & 1, q & 2);            // {t0+t2, t1+t3, t0-t2, t1-t3}[q]
+                f = (int)(int16_t)f;
+                const int qbits = dq.qbits - 1;               // qpc/6 - 5
+                const int v = qbits >= 0 ? f * (int)((unsigned)dq.mf0 << qbits) : (f * dq.mf0) >> (-qbits);
+                co[(4 + pl) * 16] = (int16_t)((cbp >> 4) ? v : 0);
+            }
+        }
+        wave_lds_fence();
+        const int blk = (row >> 2) * 2 + dw;                  // block inside the quadrant, decode order
+        if ((mask >> (q * 4 + blk)) & 1) outY = add_residual4(outY, co + blk * 16, row & 3);
+        if (l < 8 && (cbp >> 4)) outC = add_residual4(outC, co + (4 + cp) * 16, crow);
+    }
+
+    // ---- store into the macroblock's tile ----
+    if (valid) {
+        uint8_t *tile = ph.dst + (size_t)mbi * MB_TILE;
+        gstore1(tile + ((q >> 1) * 8 + row) * 16 + (q & 1) * 8 + dw * 4, outY);
+        if (l < 8) gstore1(tile + MB_TILE_U + cp * 64 + ((q >> 1) * 4 + crow) * 8 + (q & 1) * 4, outC);
+    }
 }

@@ -37,7 +37,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct PicSlot {                       // one device-resident parsed picture
     uint8_t *dev = nullptr;
     size_t   cap = 0;                  // bytes allocated
-    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_coef = 0;
+    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_quads = 0, off_coef = 0;
     p264hip_picture_t meta;            // scalar fields only; pointers unused
     bool     valid = false;
 };
@@ -155,6 +155,8 @@ static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
         if (p->ref_slot[i] < 0 || p->ref_slot[i] >= c->slots) return fail(P264HIP_EINVAL, "ref_slot[%d]=%d out of range", i, p->ref_slot[i]);
     if (p->slice_type == P264_SLICE_P && p->n_ref < 1) return fail(P264HIP_EINVAL, "P picture without reference");
     if (!p->mb || !p->mv || !p->ref_idx || !p->i4modes || (p->n_coef_blocks && !p->coefs)) return fail(P264HIP_EINVAL, "null picture array");
+    if (p->n_quads && (!p->quads || (p->n_quads & 3) || p->n_quads > (uint32_t)c->g.n_mb * 4 + 48))
+        return fail(P264HIP_EINVAL, "bad quadrant list (%u entries)", p->n_quads);
     return 0;
 }
 
@@ -167,7 +169,8 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
     size_t off_mv = align_up(n * sizeof(p264hip_mb_t), 256);
     size_t off_ref = off_mv + align_up(n * 64, 256);
     size_t off_i4 = off_ref + align_up(n * 4, 256);
-    size_t off_coef = off_i4 + align_up(n * 16, 256);
+    size_t off_quads = off_i4 + align_up(n * 16, 256);
+    size_t off_coef = off_quads + align_up((n * 4 + 48) * sizeof(uint32_t), 256);
     size_t need = off_coef + align_up((size_t)p->n_coef_blocks * 32, 256) + 256;
     if (need > s.cap) {
         if (s.dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(s.dev)); s.dev = nullptr; s.cap = 0; }
@@ -176,7 +179,8 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
         if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for picture input: %s", cap, hipGetErrorString(e));
         s.cap = cap;
     }
-    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_coef = off_coef;
+    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_quads = off_quads; s.off_coef = off_coef;
+    if (p->n_quads) HIPCHK(hipMemcpyAsync(s.dev + off_quads, p->quads, (size_t)p->n_quads * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(s.dev + off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(s.dev + off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -184,7 +188,7 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
     if (p->n_coef_blocks)
         HIPCHK(hipMemcpyAsync(s.dev + off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
     s.meta = *p;
-    s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr;
+    s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr; s.meta.quads = nullptr;
     s.valid = true;
     return 0;
 }
@@ -247,7 +251,7 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
         d.cap = need;
     }
     HIPCHK(hipMemcpyAsync(d.dev, s.dev, need, hipMemcpyDeviceToDevice, c->stream));
-    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef;
+    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_quads = s.off_quads; d.off_coef = s.off_coef;
     d.meta = s.meta; d.valid = true;
     return P264HIP_OK;
 }
@@ -288,6 +292,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     HIPCHK(hipEventSynchronize(c->batch_free[r]));            // the copy that last used this staging buffer is done
     PicDev *hb = c->h_batch[r];
     bool any_p = false;
+    int max_quads = 0;
     for (int i = 0; i < n; i++) {
         int id = pic_ids[i], st = streams[i];
         if (id < 0 || id >= c->max_pictures || !c->pics[(size_t)id].valid) return fail(P264HIP_EINVAL, "picture slot %d is empty", id);
@@ -306,6 +311,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         d.n_ref = s.meta.n_ref; d.slice_type = s.meta.slice_type;
         d.chroma_qp_offset = s.meta.chroma_qp_offset; d.deblock = s.meta.deblock;
         d.alpha_off = s.meta.alpha_c0_offset; d.beta_off = s.meta.beta_offset;
+        d.quads = (const uint32_t *)(s.dev + s.off_quads); d.n_quads = (int32_t)s.meta.n_quads;
+        if (d.n_quads > max_quads) max_quads = d.n_quads;
         any_p |= s.meta.slice_type == P264_SLICE_P;
     }
     ScopedStamp whole(c, 3);
@@ -317,6 +324,10 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         int per_pic = (g.n_mb + 3) / 4, n_blocks = per_pic * n, grid = (n_blocks + 7) / 8 * 8;
         hipLaunchKernelGGL(k_inter, dim3(grid), dim3(256), 0, c->stream, c->d_batch[r], g, per_pic, n_blocks,
                            (uint32_t)(((1ull << 32) - 1) / (unsigned)per_pic), (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w));
+        // multi-vector macroblocks, quadrant by quadrant: a wavefront takes four list entries, a workgroup sixteen
+        if (max_quads)
+            hipLaunchKernelGGL(k_inter_quads, dim3((max_quads + 15) / 16, n), dim3(256), 0, c->stream, c->d_batch[r], g,
+                               (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w));
     }
     {
         ScopedStamp t(c, 1);

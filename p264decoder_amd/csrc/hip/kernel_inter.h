@@ -582,18 +582,24 @@ void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw)
     const int cx0 = X0 / 2 + (mv_x(mv) >> 3), cy0 = Y0 / 2 + (mv_y(mv) >> 3);
     {
         uint32_t yv[4], cv[2];
-        const int xa = (wx0 & ~3) + (l & 3) * 4, xc = clip3i(xa, 0, g.w - 4);
+        const int xa = (wx0 & ~3) + (l & 3) * 4, cxa = (cx0 & ~3) + (l & 1) * 4, cr = min(l, 9) >> 1;
+        const bool inside = wx0 >= 0 && (wx0 & ~3) + 16 <= g.w && wy0 >= 0 && wy0 + 13 <= g.h &&
+                            cx0 >= 0 && (cx0 & ~3) + 8 <= g.cw && cy0 >= 0 && cy0 + 5 <= g.ch;
+        if (__ballot(!inside) == 0) {                           // all four windows inside the picture: no clamps, no border fix-up
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int r = min((l >> 2) + 4 * k, 12);
-            yv[k] = WLOAD(ref + luma_off(g, xc, clip3i(wy0 + r, 0, g.h - 1)));
+            for (int k = 0; k < 4; k++) yv[k] = WLOAD(ref + luma_off(g, xa, wy0 + min((l >> 2) + 4 * k, 12)));
+            const uint32_t coff = chroma_off(g, 0, cxa, cy0 + cr);
+            cv[0] = WLOAD(ref + coff); cv[1] = WLOAD(ref + coff + 64);
+        } else {
+            const int xc = clip3i(xa, 0, g.w - 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) yv[k] = WLOAD(ref + luma_off(g, xc, clip3i(wy0 + min((l >> 2) + 4 * k, 12), 0, g.h - 1)));
+            const uint32_t coff = chroma_off(g, 0, clip3i(cxa, 0, g.cw - 4), clip3i(cy0 + cr, 0, g.ch - 1));
+            cv[0] = WLOAD(ref + coff); cv[1] = WLOAD(ref + coff + 64);
+#pragma unroll
+            for (int k = 0; k < 4; k++) yv[k] = edge_fix(yv[k], xa, g.w);
+            cv[0] = edge_fix(cv[0], cxa, g.cw); cv[1] = edge_fix(cv[1], cxa, g.cw);
         }
-        const int cr = min(l, 9) >> 1, cxa = (cx0 & ~3) + (l & 1) * 4;
-        const uint32_t coff = chroma_off(g, 0, clip3i(cxa, 0, g.cw - 4), clip3i(cy0 + cr, 0, g.ch - 1));
-        cv[0] = WLOAD(ref + coff); cv[1] = WLOAD(ref + coff + 64);
-#pragma unroll
-        for (int k = 0; k < 4; k++) yv[k] = edge_fix(yv[k], xa, g.w);
-        cv[0] = edge_fix(cv[0], cxa, g.cw); cv[1] = edge_fix(cv[1], cxa, g.cw);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = (l >> 2) + 4 * k;
@@ -613,8 +619,11 @@ void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw)
     // ---- residual (decoder/macroblock.c:832-890): six blocks per quadrant, L.coef[(6*grp + block)*16 + raster position] ----
     if (__ballot(mask != 0)) {
         int16_t *co = L.coef + grp * 96;
+        // the four macroblocks of a wave nearly always share their QP: then the dequantisation parameters are scalars
+        const int qp0 = rfl(qp);
+        const bool qp_uniform = __ballot(qp != qp0) == 0;
         {
-            const DqParams dq = dq_params(qp);
+            const DqParams dq = qp_uniform ? dq_params(qp0) : dq_params(qp);
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const int pos = zigzag_pos((l & 3) * 4 + kk);
@@ -623,8 +632,8 @@ void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw)
             }
         }
         {   // chroma: DC (core/dct.c:55-68, core/quant.c:138-159) + AC of block q of both planes
-            const int qpc = chroma_qp(clip3i(qp + ph.chroma_qp_offset, 0, 51));
-            const DqParams dq = dq_params(qpc);
+            const int qpc0 = chroma_qp(clip3i(qp0 + ph.chroma_qp_offset, 0, 51));
+            const DqParams dq = qp_uniform ? dq_params(qpc0) : dq_params(chroma_qp(clip3i(qp + ph.chroma_qp_offset, 0, 51)));
             const int pl = l >> 3, i2 = l & 7;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {                  // level index 2*i2+kk sits at scan position 2*i2+kk+1

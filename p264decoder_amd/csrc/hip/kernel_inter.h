@@ -535,13 +535,22 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 // Same arithmetic and the same helpers as k_inter; only the bookkeeping is per 16-lane group instead of per wavefront.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 8)
-void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw)
+void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw, int chunks_per_pic, int n_chunks, uint32_t inv_chunks)
 {
     __shared__ InterLds lds[4];
-    const PicDev *pd = pics + blockIdx.y;
+    // XCD-aware remap as in k_inter: every XCD gets a contiguous range of (picture, chunk) pairs, so that the quadrants of
+    // one picture - which reach the device sorted by phase, not by position - meet their reference tiles in ONE L2
+    // (a 1080p reference frame is 3.1 MB, an XCD's L2 4 MB).  Without it the same tiles were fetched by all eight XCDs.
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= n_chunks) return;
+    int pic = (int)__umulhi((unsigned)logical, inv_chunks);
+    if (logical - pic * chunks_per_pic >= chunks_per_pic) pic++;
+    const int chunk = logical - pic * chunks_per_pic;
+    const PicDev *pd = pics + pic;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_quads = pd->n_quads;
-    const int item0 = (blockIdx.x * 4 + wave) * 4;
+    const int item0 = (chunk * 4 + wave) * 4;
     if (item0 >= n_quads) return;
     const PicHead ph = load_pic_head(pd);
     const int grp = lane >> 4, l = lane & 15;

@@ -325,9 +325,11 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         hipLaunchKernelGGL(k_inter, dim3(grid), dim3(256), 0, c->stream, c->d_batch[r], g, per_pic, n_blocks,
                            (uint32_t)(((1ull << 32) - 1) / (unsigned)per_pic), (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w));
         // multi-vector macroblocks, quadrant by quadrant: a wavefront takes four list entries, a workgroup sixteen
-        if (max_quads)
-            hipLaunchKernelGGL(k_inter_quads, dim3((max_quads + 15) / 16, n), dim3(256), 0, c->stream, c->d_batch[r], g,
-                               (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w));
+        if (max_quads) {
+            const int chunks = (max_quads + 15) / 16, total = chunks * n;
+            hipLaunchKernelGGL(k_inter_quads, dim3((total + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], g,
+                               (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w), chunks, total, (uint32_t)(((1ull << 32) - 1) / (unsigned)chunks));
+        }
     }
     {
         ScopedStamp t(c, 1);

@@ -36,13 +36,13 @@ for k, ctrs in agg.items():
         vals = v[1:] if k != "k_inter" and len(v) > 1 else v
         pmc[k][c] = round(sum(vals) / len(vals))
     pmc[k]["launches_averaged"] = len(vals)
-note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline` "
+note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
         "(1024 1080p pictures per launch), separate rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as reported")
 json.dump({"note": note, **pmc}, open(os.path.join(here, tag + "_pmc.json"), "w"), indent=1)
 
 def hbm(k):
     return int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
-traffic = {"inter": hbm("k_inter"), "intra": hbm("k_intra"), "deblock": hbm("k_deblock") + hbm("k_deblock_bs"),
+traffic = {"inter": hbm("k_inter") + (hbm("k_inter_quads") if "k_inter_quads" in pmc else 0), "intra": hbm("k_intra"), "deblock": hbm("k_deblock") + hbm("k_deblock_bs"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
 json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(traffic))

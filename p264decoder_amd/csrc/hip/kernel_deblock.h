@@ -34,6 +34,9 @@
 #define EXPD_NOWAIT 0
 #endif
 #include "wavefront_sync.h"
+#ifndef DEBLOCK_WAIT_SLEEP
+#define DEBLOCK_WAIT_SLEEP 16
+#endif
 
 #define DY_DW 5                    // luma tile row: 5 dwords = cols -4..15
 #define DC_DW 3                    // chroma tile row: 3 dwords = cols -4..7
@@ -312,7 +315,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 const int want = x + 1;
                 int spins = 0;
                 while (__ballot(need && __hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)) {
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(DEBLOCK_WAIT_SLEEP);
                     if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(status, 1); ok = false; break; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

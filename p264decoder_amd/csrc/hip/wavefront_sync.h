@@ -14,6 +14,9 @@
 #define ROW_WAVES      16            // wavefronts per picture workgroup (1024 threads)
 #define MAX_MB_ROWS    512
 #define SPIN_LIMIT     (1 << 22)
+#ifndef WAIT_SLEEP
+#define WAIT_SLEEP     32            // x64 cycles between polls: a polling wave must not eat the CU's scalar issue slots
+#endif
 
 struct RowSync {
     int progress[MAX_MB_ROWS];
@@ -36,7 +39,7 @@ __device__ __forceinline__ bool row_wait(RowSync &s, int row, int need, int *sta
 {
     int spins = 0;
     while (__hip_atomic_load(&s.progress[row], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(WAIT_SLEEP);
         if (++spins > SPIN_LIMIT) {
             if ((threadIdx.x & 63) == 0) atomicOr(status, 1);
             return false;

@@ -229,27 +229,33 @@ __device__ __forceinline__ uint32_t chroma_dword(const uint8_t *ref, const Geom 
 __device__ __forceinline__ int mv_x(int packed) { return (int)(int16_t)(packed & 0xffff); }
 __device__ __forceinline__ int mv_y(int packed) { return packed >> 16; }
 
-// four residual samples of row y of a 4x4 block (core/dct.c:205-247), c = 16 dequantised coefficients
-__device__ __forceinline__ void idct4x4_row(const int16_t *c, int y, int r[4])
+// The 4x4 inverse transform (core/dct.c:205-247), shared between the four lanes that own the four rows of a block: lane y
+// runs the horizontal pass on ROW y only and puts it back in place (int16, as the reference stores its tmp), then - after
+// a fence - every lane reads the 16 intermediate values and evaluates the vertical pass for its own output row.  (Each
+// lane doing the whole horizontal pass for itself cost 4x the work of that pass.)
+__device__ __forceinline__ void idct4x4_rowpass(int16_t *c, int y)
 {
-    int t[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int c0 = c[i*4], c1 = c[i*4+1], c2 = c[i*4+2], c3 = c[i*4+3];
-        int s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
-        t[i][0] = (int)(int16_t)(s02 + s13); t[i][1] = (int)(int16_t)(d02 + d13);
-        t[i][2] = (int)(int16_t)(d02 - d13); t[i][3] = (int)(int16_t)(s02 - s13);
-    }
+    uint2 *r = (uint2 *)(c + y * 4);
+    const uint2 v = *r;
+    const int c0 = (int)(int16_t)(v.x & 0xffff), c1 = (int)v.x >> 16, c2 = (int)(int16_t)(v.y & 0xffff), c3 = (int)v.y >> 16;
+    const int s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
+    const uint32_t t0 = (uint32_t)(s02 + s13) & 0xffffu, t1 = (uint32_t)(d02 + d13) << 16;
+    const uint32_t t2 = (uint32_t)(d02 - d13) & 0xffffu, t3 = (uint32_t)(s02 - s13) << 16;
+    *r = make_uint2(t0 | t1, t2 | t3);
+}
+__device__ __forceinline__ uint32_t idct4x4_colpass_add(uint32_t pred, const int16_t *c, int y)
+{
+    const uint4 a = *(const uint4 *)c, b = *(const uint4 *)(c + 8);     // rows 0,1 | rows 2,3 of the intermediate
+    const uint32_t row[4][2] = { { a.x, a.y }, { a.z, a.w }, { b.x, b.y }, { b.z, b.w } };
+    int r[4];
 #pragma unroll
     for (int x = 0; x < 4; x++) {
-        int s02 = t[0][x] + t[2][x], d02 = t[0][x] - t[2][x], s13 = t[1][x] + (t[3][x] >> 1), d13 = (t[1][x] >> 1) - t[3][x];
+        int t[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = (x & 1) ? (int)row[i][x >> 1] >> 16 : (int)(int16_t)(row[i][x >> 1] & 0xffff);
+        const int s02 = t[0] + t[2], d02 = t[0] - t[2], s13 = t[1] + (t[3] >> 1), d13 = (t[1] >> 1) - t[3];
         r[x] = (int)(int16_t)((butterfly_pick(s02, d02, s13, d13, y) + 32) >> 6);
     }
-}
-__device__ __forceinline__ uint32_t add_residual4(uint32_t pred, const int16_t *c, int y)
-{
-    int r[4];
-    idct4x4_row(c, y, r);
     return pack4(clip255((int)(pred & 255) + r[0]), clip255((int)((pred >> 8) & 255) + r[1]),
                  clip255((int)((pred >> 16) & 255) + r[2]), clip255((int)(pred >> 24) + r[3]));
 }
@@ -509,8 +515,13 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         }
         wave_lds_fence();
         const int blk = blk_at(dw, row >> 2);
-        if ((mask >> blk) & 1) outY = add_residual4(outY, L.coef + blk * 16, row & 3);
-        if (lane < 32 && (cbp >> 4)) outC = add_residual4(outC, L.coef + (16 + cp * 4 + (crow >> 2) * 2 + cdw) * 16, crow & 3);
+        const bool resY = (mask >> blk) & 1, resC = lane < 32 && (cbp >> 4);
+        int16_t *coefY = L.coef + blk * 16, *coefC = L.coef + (16 + cp * 4 + (crow >> 2) * 2 + cdw) * 16;
+        if (resY) idct4x4_rowpass(coefY, row & 3);
+        if (resC) idct4x4_rowpass(coefC, crow & 3);
+        wave_lds_fence();
+        if (resY) outY = idct4x4_colpass_add(outY, coefY, row & 3);
+        if (resC) outC = idct4x4_colpass_add(outC, coefC, crow & 3);
     }
 
     // ---------------- the lane stores its own dword ----------------
@@ -663,8 +674,12 @@ void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw, in
         }
         wave_lds_fence();
         const int blk = (row >> 2) * 2 + dw;                  // block inside the quadrant, decode order
-        if ((mask >> (q * 4 + blk)) & 1) outY = add_residual4(outY, co + blk * 16, row & 3);
-        if (l < 8 && (cbp >> 4)) outC = add_residual4(outC, co + (4 + cp) * 16, crow);
+        const bool resY = (mask >> (q * 4 + blk)) & 1, resC = l < 8 && (cbp >> 4);
+        if (resY) idct4x4_rowpass(co + blk * 16, row & 3);
+        if (resC) idct4x4_rowpass(co + (4 + cp) * 16, crow);
+        wave_lds_fence();
+        if (resY) outY = idct4x4_colpass_add(outY, co + blk * 16, row & 3);
+        if (resC) outC = idct4x4_colpass_add(outC, co + (4 + cp) * 16, crow);
     }
 
     // ---- store into the macroblock's tile ----

@@ -202,17 +202,24 @@ __device__ __forceinline__ int butterfly_pick(int s02, int d02, int s13, int d13
     return a + ((b ^ neg) - neg);
 }
 
-// One output sample of the 4x4 inverse transform (core/dct.c:205-247): c = 16 dequantised
-// coefficients in raster order, (x,y) the sample.  Row pass then column pass with the
-// reference's int16 intermediates.
-__device__ __forceinline__ int idct4x4_sample(const int16_t *c, int x, int y)
+// The 4x4 inverse transform (core/dct.c:205-247), shared between the four lanes that own the four rows of a block: lane y
+// runs the horizontal pass on ROW y only and puts it back in place (int16, as the reference stores its tmp), then - after
+// a fence - every lane reads the 16 intermediate values and evaluates the vertical pass for its own output row.  (Each
+// lane doing the whole horizontal pass for itself cost 4x the work of that pass.)
+__device__ __forceinline__ void idct4x4_rowpass(int16_t *c, int y)
 {
-    int t[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int c0 = c[i*4], c1 = c[i*4+1], c2 = c[i*4+2], c3 = c[i*4+3];
-        t[i] = (int)(int16_t)butterfly_pick(c0 + c2, c0 - c2, c1 + (c3 >> 1), (c1 >> 1) - c3, x);
-    }
-    int v = butterfly_pick(t[0] + t[2], t[0] - t[2], t[1] + (t[3] >> 1), (t[1] >> 1) - t[3], y);
-    return (int)(int16_t)((v + 32) >> 6);
+    uint2 *r = (uint2 *)(c + y * 4);
+    const uint2 v = *r;
+    const int c0 = (int)(int16_t)(v.x & 0xffff), c1 = (int)v.x >> 16, c2 = (int)(int16_t)(v.y & 0xffff), c3 = (int)v.y >> 16;
+    const int s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
+    const uint32_t t0 = (uint32_t)(s02 + s13) & 0xffffu, t1 = (uint32_t)(d02 + d13) << 16;
+    const uint32_t t2 = (uint32_t)(d02 - d13) & 0xffffu, t3 = (uint32_t)(s02 - s13) << 16;
+    *r = make_uint2(t0 | t1, t2 | t3);
 }
+// one output sample (x,y) of the vertical pass over the intermediate left by idct4x4_rowpass
+__device__ __forceinline__ int idct4x4_col_sample(const int16_t *t, int x, int y)
+{
+    const int t0 = t[x], t1 = t[4 + x], t2 = t[8 + x], t3 = t[12 + x];
+    return (int)(int16_t)((butterfly_pick(t0 + t2, t0 - t2, t1 + (t3 >> 1), (t1 >> 1) - t3, y) + 32) >> 6);
+}
+

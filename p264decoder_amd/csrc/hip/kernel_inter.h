@@ -229,20 +229,6 @@ __device__ __forceinline__ uint32_t chroma_dword(const uint8_t *ref, const Geom 
 __device__ __forceinline__ int mv_x(int packed) { return (int)(int16_t)(packed & 0xffff); }
 __device__ __forceinline__ int mv_y(int packed) { return packed >> 16; }
 
-// The 4x4 inverse transform (core/dct.c:205-247), shared between the four lanes that own the four rows of a block: lane y
-// runs the horizontal pass on ROW y only and puts it back in place (int16, as the reference stores its tmp), then - after
-// a fence - every lane reads the 16 intermediate values and evaluates the vertical pass for its own output row.  (Each
-// lane doing the whole horizontal pass for itself cost 4x the work of that pass.)
-__device__ __forceinline__ void idct4x4_rowpass(int16_t *c, int y)
-{
-    uint2 *r = (uint2 *)(c + y * 4);
-    const uint2 v = *r;
-    const int c0 = (int)(int16_t)(v.x & 0xffff), c1 = (int)v.x >> 16, c2 = (int)(int16_t)(v.y & 0xffff), c3 = (int)v.y >> 16;
-    const int s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
-    const uint32_t t0 = (uint32_t)(s02 + s13) & 0xffffu, t1 = (uint32_t)(d02 + d13) << 16;
-    const uint32_t t2 = (uint32_t)(d02 - d13) & 0xffffu, t3 = (uint32_t)(s02 - s13) << 16;
-    *r = make_uint2(t0 | t1, t2 | t3);
-}
 __device__ __forceinline__ uint32_t idct4x4_colpass_add(uint32_t pred, const int16_t *c, int y)
 {
     const uint4 a = *(const uint4 *)c, b = *(const uint4 *)(c + 8);     // rows 0,1 | rows 2,3 of the intermediate

@@ -189,8 +189,10 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         wave_lds_fence();
         {
             int b = blk_at(lane & 3, row >> 2), yy = row & 3;
+            idct4x4_rowpass(L.coef + b * 16, yy);                                // horizontal pass of this lane's row, in place
+            wave_lds_fence();
             for (int i = 0; i < 4; i++)
-                L.y[(row + 1) * IT_STRIDE + 4 + c0 + i] = (uint8_t)clip255(pv[i] + idct4x4_sample(L.coef + b * 16, i, yy));
+                L.y[(row + 1) * IT_STRIDE + 4 + c0 + i] = (uint8_t)clip255(pv[i] + idct4x4_col_sample(L.coef + b * 16, i, yy));
         }
         wave_lds_fence();
     } else {
@@ -205,17 +207,22 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
             }
         }
         wave_lds_fence();
+        idct4x4_rowpass(L.coef + lb * 16, lane & 3);                              // horizontal pass of all 16 blocks: lane = (block, row)
+        wave_lds_fence();
         const int x = lane & 3, y = (lane >> 2) & 3;
         // the lane's slot of the edge array: offset from the block origin inside the tile and the neighbour it belongs to
         // (0 left, 1 top-left, 2 top, 3 top-right)
         const int es = min(lane, 14);
         const int eoff = es <= 4 ? (es == 0 ? 3 : 4 - es) * IT_STRIDE - 1 : es == 5 ? -IT_STRIDE - 1 : -IT_STRIDE + min(es - 6, 7);
         const int eflag = es <= 4 ? 0 : es == 5 ? 1 : es <= 9 ? 2 : 3;
+        // which of the 16 blocks (decode order) have their left / top / top-left / top-right neighbour: one bit per block,
+        // from the macroblock's availability (inside the MB: fixed pattern, top-right per core/macroblock.c:1210-1231)
+        const unsigned left_m = 0xFAFAu | (aL ? 0x0505u : 0u), top_m = 0xFFCCu | (aT ? 0x0033u : 0u);
+        const unsigned tl_m = 0xFAC8u | (aT ? 0x0032u : 0u) | (aL ? 0x0504u : 0u) | (aTL ? 0x0001u : 0u);
+        const unsigned tr_m = 0x5744u | (aT ? 0x0013u : 0u) | (aTR ? 0x0020u : 0u);
         for (int i = 0; i < 16; i++) {
             const int bx = blk_x(i), by = blk_y(i);
-            const bool left = bx > 0 || aL, top = by > 0 || aT;
-            const bool topleft = (bx > 0 && by > 0) ? true : bx > 0 ? aT : by > 0 ? aL : aTL;
-            const bool topright = by == 0 ? (bx < 3 ? aT : aTR) : (0x5744 >> i) & 1;   // core/macroblock.c:1210-1231
+            const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1, topleft = (tl_m >> i) & 1, topright = (tr_m >> i) & 1;
             int mode = __builtin_amdgcn_readlane(modebyte, i);
             const uint8_t *o = L.y + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
             // ---- edge array, missing neighbours substituted (decoder/macroblock.c:697-713): 128, or t3 for the top-right ----
@@ -237,7 +244,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
                 const int a = L.edge[c - 1], b = L.edge[c], d = L.edge[c + 1];
                 v = kind == P4_COPY ? b : kind == P4_F2 ? (b + d + 1) >> 1 : (a + 2 * b + d + 2) >> 2;
             }
-            if ((mask >> i) & 1) v = clip255(v + idct4x4_sample(L.coef + i * 16, x, y));
+            if ((mask >> i) & 1) v = clip255(v + idct4x4_col_sample(L.coef + i * 16, x, y));
             if (lane < 16) L.y[(by * 4 + y + 1) * IT_STRIDE + 4 + bx * 4 + x] = (uint8_t)v;
             wave_lds_fence();
         }
@@ -286,8 +293,10 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
                 } else cv = dequant_coef(cac[p], pos, qpc);
                 L.coef[j * 16 + pos] = (int16_t)cv;
                 wave_lds_fence();
+                if (lane < 16) idct4x4_rowpass(L.coef + (lane >> 2) * 16, lane & 3);     // 4 blocks x 4 rows
+                wave_lds_fence();
                 int jj = ((py >> 2) << 1) | (px >> 2);
-                v = clip255(v + idct4x4_sample(L.coef + jj * 16, px & 3, py & 3));
+                v = clip255(v + idct4x4_col_sample(L.coef + jj * 16, px & 3, py & 3));
             }
             wave_lds_fence();
             L.c[p][(py + 1) * CT_STRIDE + 4 + px] = (uint8_t)v;

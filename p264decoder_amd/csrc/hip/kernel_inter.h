@@ -60,6 +60,7 @@ struct InterLds {                 // per wavefront
     uint32_t ywin[4][YWIN_DW];    // whole-MB path: 21 rows x 6 dwords (+2 pad); quadrant path: 13 x 4 luma + 20 chroma dwords
     uint32_t cwin[2][4][16];      // whole-MB path: 2 planes x 9 rows x 3 dwords (+pad)
     int16_t  coef[24 * 16];       // dequantised coefficients, raster order per block
+    uint32_t hrow[224];           // unrounded horizontal 6-tap sums for the centre half-pel position, 4 x int16 per (row, dword column)
 };
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -138,21 +139,48 @@ template <int P> __device__ __forceinline__ uint32_t hv4(const uint32_t *w, int 
     }
     return pack4(clip255(no_fuse(acc[0] >> 10)), clip255(no_fuse(acc[1] >> 10)), clip255(no_fuse(acc[2] >> 10)), clip255(no_fuse(acc[3] >> 10)));
 }
-// four samples at half-pel coordinate (2x + hx, 2y + hy); plane choice as in core/mc.c:244-257
-template <int P> __device__ __forceinline__ uint32_t half4(const uint32_t *w, int r, int b, int hx, int hy)
+// The centre position shared between lanes: hv4 above runs the horizontal filter on six rows per lane, and vertically
+// adjacent lanes repeat five of them.  When a whole wavefront needs the centre position (the phase is wave-uniform) the
+// lanes first fill a table of horizontal sums, one (row, dword column) each - h4_raw - and then every lane runs only the
+// vertical filter over six table rows - hv4_from_rows.  Same arithmetic: unrounded 16-bit sums, (sum + 512) >> 10.
+template <int P> __device__ __forceinline__ uint2 h4_raw(const uint32_t *w, int r, int b)
+{
+    uint32_t n0, n1, n2; int t[4];
+    row12<P>(w, r, b - 2, n0, n1, n2);
+    tap_h4(n0, n1, n2, t);
+    return make_uint2(((uint32_t)t[0] & 0xffffu) | ((uint32_t)t[1] << 16), ((uint32_t)t[2] & 0xffffu) | ((uint32_t)t[3] << 16));
+}
+__device__ __forceinline__ uint32_t hv4_from_rows(const uint32_t *h, int pitch)
+{
+    int acc[4] = { 512, 512, 512, 512 };
+    const int cv[6] = { 1, -5, 20, 20, -5, 1 };
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint2 v = *(const uint2 *)(h + k * pitch);
+        acc[0] += cv[k] * (int)(int16_t)(v.x & 0xffff); acc[1] += cv[k] * ((int)v.x >> 16);
+        acc[2] += cv[k] * (int)(int16_t)(v.y & 0xffff); acc[3] += cv[k] * ((int)v.y >> 16);
+    }
+    return pack4(clip255(no_fuse(acc[0] >> 10)), clip255(no_fuse(acc[1] >> 10)), clip255(no_fuse(acc[2] >> 10)), clip255(no_fuse(acc[3] >> 10)));
+}
+// the phases that use the centre position (core/mc.c:244-257): always at half-pel offset (1,1) of the lane's own samples
+__device__ __forceinline__ bool phase_uses_centre(int fx, int fy) { return (fx == 2 && fy != 0) || (fy == 2 && fx != 0); }
+
+// four samples at half-pel coordinate (2x + hx, 2y + hy); plane choice as in core/mc.c:244-257.  hrows: this lane's six rows
+// of the shared table (pitch hp dwords), or null
+template <int P> __device__ __forceinline__ uint32_t half4(const uint32_t *w, int r, int b, int hx, int hy, const uint32_t *hrows = nullptr, int hp = 0)
 {
     r += hy >> 1; b += hx >> 1;
     int which = (hx & 1) | ((hy & 1) << 1);
     if (which == 0) return row4<P>(w, r, b);
     if (which == 1) return h4<P>(w, r, b);
     if (which == 2) return v4<P>(w, r, b);
-    return hv4<P>(w, r, b);
+    return hrows ? hv4_from_rows(hrows, hp) : hv4<P>(w, r, b);
 }
-template <int P> __device__ __forceinline__ uint32_t qpel4(const uint32_t *w, int r, int b, int fx, int fy)
+template <int P> __device__ __forceinline__ uint32_t qpel4(const uint32_t *w, int r, int b, int fx, int fy, const uint32_t *hrows = nullptr, int hp = 0)
 {
     int corr = (fx & 1) && (fy & 1) && ((fx & 2) ^ (fy & 2));
-    uint32_t a = half4<P>(w, r, b, fx >> 1, (fy + 1 - corr) >> 1);
-    if ((fx | fy) & 1) a = avg4(a, half4<P>(w, r, b, (fx + 1) >> 1, (fy + corr) >> 1));
+    uint32_t a = half4<P>(w, r, b, fx >> 1, (fy + 1 - corr) >> 1, hrows, hp);
+    if ((fx | fy) & 1) a = avg4(a, half4<P>(w, r, b, (fx + 1) >> 1, (fy + corr) >> 1, hrows, hp));
     return a;
 }
 
@@ -384,7 +412,17 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 #if EXP_NOCOMPUTE
         outY = yw[lane]; outC = cw[lane & 31];
 #else
-        outY = qpel4<6>(yw, row + 2, (ux0 & 3) + 2 + dw * 4, lx & 3, ly & 3);
+        if (phase_uses_centre(lx & 3, ly & 3)) {
+            // 21 window rows x 4 dword columns of horizontal sums: lane t takes entry t, lanes 0..19 also entry 64 + t
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int t = lane + 64 * k;
+                if (t < 84) *(uint2 *)(L.hrow + t * 2) = h4_raw<6>(yw, t >> 2, (ux0 & 3) + 2 + (t & 3) * 4);
+            }
+            wave_lds_fence();
+            outY = qpel4<6>(yw, row + 2, (ux0 & 3) + 2 + dw * 4, lx & 3, ly & 3, L.hrow + lane * 2, 8);
+        } else
+            outY = qpel4<6>(yw, row + 2, (ux0 & 3) + 2 + dw * 4, lx & 3, ly & 3);
         if (lane < 32) outC = chroma4<3>(cw + cp * 27 + crow * 3, (ucx0 & 3) + cdw * 4, lx & 7, ly & 7);
 #endif
     } else {
@@ -619,7 +657,19 @@ void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw, in
     const int fx = rfl(mv_x(mv) & 3), fy = rfl(mv_y(mv) & 3);
     const int row = l >> 1, dw = l & 1;                         // luma: (row, dword) inside the 8x8 quadrant
     const int cp = (l >> 2) & 1, crow = l & 3;                  // chroma (lanes 0..7): plane, row of the 4x4 block
-    uint32_t outY = qpel4<4>(L.ywin[grp], row + 2, (wx0 & 3) + 2 + dw * 4, fx, fy), outC = 0;
+    uint32_t outY, outC = 0;
+    if (phase_uses_centre(fx, fy)) {
+        // per quadrant 13 window rows x 2 dword columns of horizontal sums: lane l takes entry l, lanes 0..9 also entry 16 + l
+        uint32_t *hq = L.hrow + grp * 52;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int t = l + 16 * k;
+            if (t < 26) *(uint2 *)(hq + t * 2) = h4_raw<4>(L.ywin[grp], t >> 1, (wx0 & 3) + 2 + (t & 1) * 4);
+        }
+        wave_lds_fence();
+        outY = qpel4<4>(L.ywin[grp], row + 2, (wx0 & 3) + 2 + dw * 4, fx, fy, hq + l * 2, 4);
+    } else
+        outY = qpel4<4>(L.ywin[grp], row + 2, (wx0 & 3) + 2 + dw * 4, fx, fy);
     if (l < 8) outC = chroma4<2>(L.cwin[cp][grp] + crow * 2, cx0 & 3, mv_x(mv) & 7, mv_y(mv) & 7);
 
     // ---- residual (decoder/macroblock.c:832-890): six blocks per quadrant, L.coef[(6*grp + block)*16 + raster position] ----

@@ -55,89 +55,104 @@ struct EdgeInfo {                  // 64 bytes per macroblock, written by k_debl
 // ------------------------------------------------------------------------------------------
 // K4a
 // ------------------------------------------------------------------------------------------
-struct BsLoads { uint4 rec; int rp, rq, vp, vq; };
+// One LANE per macroblock.  (The first versions spent 32 lanes per macroblock, one per edge segment: the arithmetic per
+// segment is a handful of compares, so shuffling records around and packing nibbles across lanes dominated, ~57 vector
+// instructions per macroblock.  With the whole macroblock in one lane's registers - its 16 vectors, the left column and
+// the bottom row of the neighbours - everything unrolls at compile time to ~8 per macroblock, and the loads and the
+// 64-byte store of neighbouring lanes still cover whole cache lines.)
+__device__ __forceinline__ int bs_motion(int vp, int vq, int rp, int rq)
+{   // core/frame.c:565-577: different reference or a vector component differing by >= 4 quarter-pels
+    const int dx = (int)(int16_t)vp - (int)(int16_t)vq, dy = (vp >> 16) - (vq >> 16);
+    return (rp != rq) | (abs(dx) >= 4) | (abs(dy) >= 4);
+}
 
 __global__ __launch_bounds__(256)
-void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info)
+void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info, uint32_t inv_mbw)
 {
-    // grid = (mb_h, pictures): a workgroup walks one macroblock row, 32 lanes per macroblock (one per edge
-    // segment), 8 macroblocks at a time.  The picture is uniform per workgroup, so its descriptor comes through
-    // scalar loads, and the loads of the next 8 macroblocks are in flight while these 8 are worked out.
+    // alpha / tc0 (one dword per index) and beta tables in LDS: lane-varying indices, no constant-memory gathers
+    __shared__ uint32_t t_alpha_tc[52];
+    __shared__ uint8_t  t_beta[52];
+    if (threadIdx.x < 52) {
+        const int i = threadIdx.x;
+        t_alpha_tc[i] = (uint32_t)c_alpha[i] | ((uint32_t)c_tc0[i][0] << 8) | ((uint32_t)c_tc0[i][1] << 16) | ((uint32_t)c_tc0[i][2] << 24);
+        t_beta[i] = c_beta[i];
+    }
+    __syncthreads();
     const PicDev *pd = pics + blockIdx.y;
     if (!pd->deblock) return;
-    const int mby = blockIdx.x, grp = threadIdx.x >> 5;
-    const int lane = threadIdx.x & 31;
-    const int dir = lane >> 4, e = (lane >> 2) & 3, i = lane & 3;
-    const bool outer = e == 0;
-    // the two 4x4 blocks either side of this lane's edge segment: p in the neighbour (or this MB), q in this MB
-    const int x = dir == 0 ? e : i, y = dir == 0 ? i : e;
-    const int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
-    const AS1 int8_t *refs = glob(pd->ref_idx);
-    const AS1 int *mvs = glob(pd->mv);
+    const int mbi = blockIdx.x * 256 + threadIdx.x;
+    if (mbi >= g.n_mb) return;
+    int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+    const int mbx = mbi - mby * g.mb_w;
+    const int li = mbx > 0 ? mbi - 1 : mbi, ti = mby > 0 ? mbi - g.mb_w : mbi;       // neighbours (self where there is none: unused)
+
+    // ---- all loads ----
     const uint4 *recs = (const uint4 *)pd->mb;
-    const int chroma_qp_offset = pd->chroma_qp_offset, alpha_off = pd->alpha_off, beta_off = pd->beta_off;
+    const uint4 rec = gload4(recs + mbi), recL = gload4(recs + li), recT = gload4(recs + ti);
+    const int *mvs = pd->mv;
+    const uint4 m0 = gload4(mvs + mbi * 16), m1 = gload4(mvs + mbi * 16 + 4), m2 = gload4(mvs + mbi * 16 + 8), m3 = gload4(mvs + mbi * 16 + 12);
+    const uint4 mT = gload4(mvs + ti * 16 + 12);                                       // bottom row of the macroblock above
+    const AS1 int *mvg = glob(mvs);
+    const int mL[4] = { mvg[li * 16 + 3], mvg[li * 16 + 7], mvg[li * 16 + 11], mvg[li * 16 + 15] };   // right column of the left one
+    const uint32_t refs = gload1(pd->ref_idx + mbi * 4), refsL = gload1(pd->ref_idx + li * 4), refsT = gload1(pd->ref_idx + ti * 4);
+    const int mv[16] = { (int)m0.x, (int)m0.y, (int)m0.z, (int)m0.w, (int)m1.x, (int)m1.y, (int)m1.z, (int)m1.w,
+                         (int)m2.x, (int)m2.y, (int)m2.z, (int)m2.w, (int)m3.x, (int)m3.y, (int)m3.z, (int)m3.w };
+    const int mvTop[4] = { (int)mT.x, (int)mT.y, (int)mT.z, (int)mT.w };
 
-    // every load of a macroblock is issued together, before anything depends on one: a single round trip
-    auto fetch = [&](int mbx) {
-        BsLoads f;
-        const int mbi = mby * g.mb_w + min(mbx, g.mb_w - 1);
-        const bool has_nb = dir == 0 ? mbx > 0 : mby > 0;
-        const int nbi = !outer ? mbi : !has_nb ? mbi : dir == 0 ? mbi - 1 : mbi - g.mb_w;
-        int src = mbi;
-        if (lane == 1) src = mbx > 0 ? mbi - 1 : mbi;
-        if (lane == 2) src = mby > 0 ? mbi - g.mb_w : mbi;
-        f.rec = make_uint4(0, 0, 0, 0);
-        if (lane < 3) f.rec = gload4(recs + src);
-        f.rp = refs[mbi * 4 + (y >> 1) * 2 + (x >> 1)]; f.rq = refs[nbi * 4 + (yn >> 1) * 2 + (xn >> 1)];
-        f.vp = mvs[mbi * 16 + y * 4 + x];               f.vq = mvs[nbi * 16 + yn * 4 + xn];
-        return f;
-    };
+    const int m_type = rec.x & 255, m_qp = (rec.x >> 8) & 255, m_edges = (rec.w >> 8) & 255;
+    const unsigned mmask = rec.y, lmask = recL.y, tmask = recT.y;
+    const bool m_intra = P264_MB_IS_INTRA(m_type), l_intra = P264_MB_IS_INTRA(recL.x & 255), t_intra = P264_MB_IS_INTRA(recT.x & 255);
+    const bool fL = m_edges & P264_EDGE_LEFT, fT = m_edges & P264_EDGE_TOP;
+    auto ref_of = [](uint32_t r4, int x, int y) { return (int)((r4 >> (8 * ((y >> 1) * 2 + (x >> 1)))) & 255); };
 
-    BsLoads nxt = fetch(grp);
-    for (int mbx = grp; mbx < g.mb_w; mbx += 8) {
-        const BsLoads f = nxt;
-        if (mbx + 8 < g.mb_w) nxt = fetch(mbx + 8);
-        const int mbi = mby * g.mb_w + mbx;
-        const unsigned m0 = __shfl((int)f.rec.x, 0, 32), mmask = __shfl((int)f.rec.y, 0, 32), mflags = __shfl((int)f.rec.w, 0, 32);
-        const unsigned l0 = __shfl((int)f.rec.x, 1, 32), lmask = __shfl((int)f.rec.y, 1, 32);
-        const unsigned t0 = __shfl((int)f.rec.x, 2, 32), tmask = __shfl((int)f.rec.y, 2, 32);
-        const int m_type = m0 & 255, m_qp = (m0 >> 8) & 255, m_edges = (mflags >> 8) & 255;
-        const bool fL = m_edges & P264_EDGE_LEFT, fT = m_edges & P264_EDGE_TOP;
-        EdgeInfo *out = info + (size_t)blockIdx.y * g.n_mb + mbi;
-
-        // ---- boundary strengths, core/frame.c:535-581; lane = dir*16 + edge*4 + segment ----
-        int bS = 0;
-        {
-            const bool enabled = m_edges && (outer ? (dir == 0 ? fL : fT) : true);
-            const int n_type = outer ? ((dir == 0 ? l0 : t0) & 255) : m_type;
-            const unsigned n_mask = outer ? (dir == 0 ? lmask : tmask) : mmask;
-            if (enabled) {
-                if (P264_MB_IS_INTRA(m_type) || P264_MB_IS_INTRA(n_type)) bS = outer ? 4 : 3;
-                else if (((mmask >> blk_at(x, y)) & 1) || ((n_mask >> blk_at(xn, yn)) & 1)) bS = 2;
-                else bS = (f.rp != f.rq || abs((int)(int16_t)f.vp - (int)(int16_t)f.vq) >= 4 || abs((f.vp >> 16) - (f.vq >> 16)) >= 4) ? 1 : 0;
+    // ---- boundary strengths, core/frame.c:535-581: word = dir*2 + (edge>>1), nibble = (edge&1)*4 + segment ----
+    uint32_t word[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = dir == 0 ? e : i, y = dir == 0 ? i : e;
+                const int xn = dir == 0 ? (x + 3) & 3 : x, yn = dir == 0 ? y : (y + 3) & 3;
+                const bool outer = e == 0;
+                const bool enabled = m_edges && (outer ? (dir == 0 ? fL : fT) : true);
+                const bool n_intra = outer ? (dir == 0 ? l_intra : t_intra) : m_intra;
+                const unsigned n_mask = outer ? (dir == 0 ? lmask : tmask) : mmask;
+                const int vq = mv[y * 4 + x], vp = !outer ? mv[yn * 4 + xn] : dir == 0 ? mL[y] : mvTop[x];
+                const int rq = ref_of(refs, x, y), rp = ref_of(!outer ? refs : dir == 0 ? refsL : refsT, xn, yn);
+                int bS = bs_motion(vp, vq, rp, rq);
+                if (((mmask >> blk_at(x, y)) | (n_mask >> blk_at(xn, yn))) & 1) bS = 2;
+                if (m_intra | n_intra) bS = outer ? 4 : 3;
+                if (!enabled) bS = 0;
+                word[dir * 2 + (e >> 1)] |= (uint32_t)bS << (4 * ((e & 1) * 4 + i));
             }
-        }
-        // pack 8 nibbles per word: lanes 8w .. 8w+7 -> word w; lane 0 writes all four
-        uint32_t word = (uint32_t)bS << (4 * (lane & 7));
-        word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
-        const uint32_t w1 = __shfl((int)word, 8, 32), w2 = __shfl((int)word, 16, 32), w3 = __shfl((int)word, 24, 32);
-        if (lane == 0) gstore4(out->bs, make_uint4(word, w1, w2, w3));
-        const bool any = (word | w1 | w2 | w3) != 0;
+    const bool any = (word[0] | word[1] | word[2] | word[3]) != 0;
 
-        // ---- per edge class: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted: A-Q3) ----
-        if (lane < 6) {
-            const int cls = lane % 3, chroma = lane / 3;
-            const int qp = m_qp, qpn = cls == EC_LEFT ? (int)((l0 >> 8) & 255) : cls == EC_TOP ? (int)((t0 >> 8) & 255) : m_qp;
-            int q;
-            if (!chroma) q = (qp + qpn + 1) >> 1;                                     // :593-595
-            else q = (chroma_qp(clip3i(qp + chroma_qp_offset, 0, 51)) + chroma_qp(clip3i(qpn + chroma_qp_offset, 0, 51)) + 1) >> 1;   // :600-601
-            const int ia = clip3i(q + alpha_off, 0, 51);
-            uint32_t lo = (uint32_t)c_alpha[ia] | ((uint32_t)c_beta[clip3i(q + beta_off, 0, 51)] << 8) |
-                          ((uint32_t)(c_tc0[ia][0] + chroma) << 16) | ((uint32_t)(c_tc0[ia][1] + chroma) << 24);
-            uint32_t hi = (uint32_t)(c_tc0[ia][2] + chroma) | ((uint32_t)(any ? 1 : 0) << 8);
-            gstore2(&out->cls[lane], make_uint2(lo, hi));
-        }
+    // ---- per edge class: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted: A-Q3) ----
+    const int cqo = pd->chroma_qp_offset, alpha_off = pd->alpha_off, beta_off = pd->beta_off;
+    const int qps[3] = { (int)((recL.x >> 8) & 255), (int)((recT.x >> 8) & 255), m_qp };          // EC_LEFT, EC_TOP, EC_INNER neighbours
+    const int cq_own = chroma_qp(clip3i(m_qp + cqo, 0, 51));
+    uint32_t cls[12];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int c = k % 3, chroma = k / 3;
+        const int q = !chroma ? (m_qp + qps[c] + 1) >> 1                                           // :593-595
+                              : (cq_own + chroma_qp(clip3i(qps[c] + cqo, 0, 51)) + 1) >> 1;       // :600-601
+        const uint32_t at = t_alpha_tc[clip3i(q + alpha_off, 0, 51)];
+        const uint32_t be = t_beta[clip3i(q + beta_off, 0, 51)];
+        const uint32_t add = chroma ? 0x01010100u : 0u;                                            // chroma: tc0 + 1
+        const uint32_t v = at + add;                                                               // alpha | tc0[0..2] (+1), no carries: tc0 <= 25
+        cls[2 * k] = (v & 0xffu) | (be << 8) | ((v & 0x00ffff00u) << 8);
+        cls[2 * k + 1] = (v >> 24) | ((uint32_t)(any ? 1 : 0) << 8);
     }
+    EdgeInfo *out = info + (size_t)blockIdx.y * g.n_mb + mbi;
+    uint32_t *o = (uint32_t *)out;
+    gstore4(o, make_uint4(word[0], word[1], word[2], word[3]));
+    gstore4(o + 4, make_uint4(cls[0], cls[1], cls[2], cls[3]));
+    gstore4(o + 8, make_uint4(cls[4], cls[5], cls[6], cls[7]));
+    gstore4(o + 12, make_uint4(cls[8], cls[9], cls[10], cls[11]));
 }
 
 // A macroblock's EdgeInfo as its eight lanes see it: the four boundary-strength words in registers, the class

@@ -341,7 +341,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     }
     {
         ScopedStamp t(c, 2);
-        hipLaunchKernelGGL(k_deblock_bs, dim3(g.mb_h, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge);
+        hipLaunchKernelGGL(k_deblock_bs, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge,
+                           (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w));
         // a wavefront filters 8 macroblock rows at a time: 8 rows of one picture while there are no more
         // pictures than compute units, else 4 rows of two pictures (or 2 of four) per workgroup
         // pictures per workgroup = as many as it takes to cover the batch with one workgroup per CU (at most 4; a

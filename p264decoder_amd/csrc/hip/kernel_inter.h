@@ -370,7 +370,7 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
 
     const int mv0 = __builtin_amdgcn_readfirstlane(mvreg);
     int r0i = (int)(int8_t)refs4;
-    if (r0i < 0 || r0i >= n_ref) r0i = 0;
+    if ((unsigned)r0i >= (unsigned)n_ref) r0i = 0;             // negative or past the list: entry 0, as the reference's flat lists
     const bool same_mv = __ballot(lane < 16 && mvreg != mv0) == 0 && (unsigned)refs4 == ((unsigned)(refs4 & 255) * 0x01010101u);
     const int ux0 = X0 + (mv_x(mv0) >> 2) - 2, ucx0 = X0 / 2 + (mv_x(mv0) >> 3);
 
@@ -383,8 +383,10 @@ void k_inter(const PicDev *__restrict__ pics, Geom g, int blocks_per_pic, int n_
         uint32_t yv[2], cvv = 0;
         const int wy0 = Y0 + (ly >> 2) - 2, wcy0 = Y0 / 2 + (ly >> 3);
         // windows that lie inside the picture (nearly all) need neither coordinate clamps nor border replication
-        const bool inside = ux0 >= 0 && (ux0 & ~3) + 24 <= g.w && wy0 >= 0 && wy0 + 21 <= g.h &&
-                            ucx0 >= 0 && (ucx0 & ~3) + 12 <= g.cw && wcy0 >= 0 && wcy0 + 9 <= g.ch;
+        // (0 <= v <= limit for four values at once: v | (limit - v) keeps its sign bit clear exactly then - one test instead of
+        // eight short-circuit branches; the coordinates are far below 2^30)
+        const int uxa = ux0 & ~3, ucxa = ucx0 & ~3;
+        const bool inside = ((uxa | (g.w - 24 - uxa)) | (wy0 | (g.h - 21 - wy0)) | (ucxa | (g.cw - 12 - ucxa)) | (wcy0 | (g.ch - 9 - wcy0))) >= 0;
         const int cl = min(lane, 53);
         const int cpl = cl >= 27, l2 = cl - 27 * cpl, cr = (l2 * 11) >> 5, cd = l2 - 3 * cr;   // l2 / 3 for l2 < 27
         if (inside) {
@@ -627,8 +629,8 @@ void k_inter_quads(const PicDev *__restrict__ pics, Geom g, uint32_t inv_mbw, in
     {
         uint32_t yv[4], cv[2];
         const int xa = (wx0 & ~3) + (l & 3) * 4, cxa = (cx0 & ~3) + (l & 1) * 4, cr = min(l, 9) >> 1;
-        const bool inside = wx0 >= 0 && (wx0 & ~3) + 16 <= g.w && wy0 >= 0 && wy0 + 13 <= g.h &&
-                            cx0 >= 0 && (cx0 & ~3) + 8 <= g.cw && cy0 >= 0 && cy0 + 5 <= g.ch;
+        const int wxa = wx0 & ~3, cxa4 = cx0 & ~3;
+        const bool inside = ((wxa | (g.w - 16 - wxa)) | (wy0 | (g.h - 13 - wy0)) | (cxa4 | (g.cw - 8 - cxa4)) | (cy0 | (g.ch - 5 - cy0))) >= 0;
         if (__ballot(!inside) == 0) {                           // all four windows inside the picture: no clamps, no border fix-up
 #pragma unroll
             for (int k = 0; k < 4; k++) yv[k] = WLOAD(ref + luma_off(g, xa, wy0 + min((l >> 2) + 4 * k, 12)));

@@ -215,7 +215,7 @@ def main():
             "kernels": kernels,
             "reconstruct_call_ms": round(timing["reconstruct"][0] / max(timing["reconstruct"][1], 1), 4),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: a reported baseline, not part of the scaling runs
             out["cpu_baseline"] = cpu_baseline(paths[0], T)
         print(json.dumps(out), flush=True)
     hip.close()

@@ -7,22 +7,26 @@
 // (decoder/macroblock.c:895-934) and the inter half of p264_macroblock_decode
 // (decoder/macroblock.c:832-890: unscan, dequant_4x4, add4x4_idct, chroma DC).
 //
-// Shape: one 64-lane wavefront per macroblock, four macroblocks (256 threads) per workgroup,
-// all inter MBs of all pictures of the batch in one launch (they are independent).
+// Two kernels (both instruction-issue bound, see DESIGN.md section 4 - the structure is about instructions and round
+// trips per macroblock, the frames are macroblock-tiled so every access covers whole cache lines):
 //
-// v2 structure (latency first, then instruction count):
-//   1. header: MB record, 16 motion vectors, 4 reference indices;
-//   2. ALL global loads of the macroblock are issued back to back - four 13x13 luma windows
-//      (one per 8x8 quadrant, aligned dwords, rows clamped per lane), eight 5x5 chroma windows,
-//      the coded coefficients (8 bytes per lane) - and land in LDS in one go;
-//   3. every lane produces FOUR horizontally adjacent samples (one output dword): rows come out
-//      of LDS as dwords, horizontal 6-tap = v_alignbyte + v_dot4_i32_i8 on sign-flipped bytes,
-//      vertical 6-tap = packed 16-bit math, quarter-pel mean = byte-parallel rounding average;
-//   4. residual added in registers; the lane stores its own dword (coalesced, no staging).
-// Windows that cross the left/right picture edge, or quadrants whose four vectors differ
-// (sub-8x8 partitions), take a per-lane clamped-read path.  Border padding
-// (core/frame.c:183-222) is replaced by coordinate clamping, which is equivalent inside the
-// reference's pads (SURVEY A-Q9).
+// k_inter        one 64-lane wavefront per macroblock, four macroblocks per workgroup, all pictures of the batch in
+//                one launch.  Macroblocks with ONE vector (16x16, P_SKIP) take the whole-MB path:
+//   1. descriptor (one scalar load), then MB record + 16 vectors + 4 reference indices in one round trip;
+//   2. coded coefficients (8 bytes per lane) and the reference window - 21x24 luma + 2 x 9x12 chroma bytes as aligned
+//      dwords, three load instructions - issued back to back, landing in LDS; rows are clamped through y, a dword
+//      outside the picture is the replicated border byte (core/frame.c:183-222 without storing the pads, SURVEY A-Q9);
+//   3. every lane produces FOUR horizontally adjacent samples (one dword of the tile): horizontal 6-tap =
+//      v_alignbyte + v_dot4_i32_i8 on sign-flipped bytes, vertical 6-tap and chroma bilinear = packed 16-bit math,
+//      the centre position from a table of horizontal sums shared by the wavefront, quarter-pel mean = byte-parallel
+//      rounding average;
+//   4. residual: levels dequantised into LDS, inverse transform shared between the four lanes of a block, added in
+//      registers; the macroblock leaves as three whole cache lines.
+//                Macroblocks flagged P264_MBF_QUADS are skipped (k_inter_quads); other multi-vector macroblocks
+//                (no quadrant list, or sub-8x8 partitions with differing vectors) take the quadrant path below with
+//                one interpolation pass per distinct vector, and a rolled per-sample path for non-uniform quadrants.
+// k_inter_quads  at the end of this file: the quadrants of multi-vector macroblocks, four of one quarter-pel phase
+//                per wavefront, from the parser's phase-sorted list.
 #pragma once
 #include "device_common.h"
 #ifndef EXP_NOCOMPUTE

@@ -13,6 +13,8 @@
  *
  *   synth264 out.264 --mbw 120 --mbh 68 --frames 60 --gop 30 --seed 3 [--intra-only]
  *            [--qp 26] [--coded 12] [--maxlevel 32] [--mvmax 64] [--cqo 0] [--nodeblock]
+ *            [--refs 2]      two reference frames, reference index per partition (outside the reference's safe subset, A-Q5)
+ *            [--dump-mv f]   per picture: the intended vectors int16[mb][16][2] and reference indices int8[mb][16]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -73,7 +75,10 @@ static void write_nal(FILE *f, int ref_idc, int type, const bw_t *b)
 /* ---------------------------------------------------------------- stream state ---------- */
 enum { T_I4 = 0, T_I16 = 1, T_P = 3, T_P8 = 4, T_SKIP = 5 };
 static int W, H, NMB;                       /* in macroblocks */
-static int opt_qp = 26, opt_coded = 12, opt_maxlevel = 32, opt_mvmax = 64, opt_cqo = 0, opt_deblock = 1;
+static int opt_qp = 26, opt_coded = 12, opt_maxlevel = 32, opt_mvmax = 64, opt_cqo = 0, opt_deblock = 1, opt_refs = 1;
+static int n_active = 1;                    /* num_ref_idx_l0_active of the current slice */
+static int8_t *refs;                        /* [mb][16] reference index per 4x4 block (-1 intra) */
+static FILE *dump_mv;                       /* --dump-mv: intended vectors and reference indices, for checking a parser */
 static uint8_t *mb_type;                    /* per MB of the current picture */
 static int16_t *mvs;                        /* [mb][16][2] */
 static uint8_t *nnz;                        /* [mb][24] */
@@ -82,7 +87,7 @@ static int cur;                             /* current MB index */
 
 static int avail(int mbx, int mby) { return mbx >= 0 && mby >= 0 && mbx < W && mby < H && mby * W + mbx < cur; }
 
-typedef struct { int ref, x, y; } nb_t;     /* ref -2 unavailable, -1 intra, 0 inter */
+typedef struct { int ref, x, y; } nb_t;     /* ref -2 unavailable, -1 intra, >= 0 reference index */
 static unsigned mv_done;
 static nb_t nb_motion(int x4, int y4)
 {
@@ -92,29 +97,34 @@ static nb_t nb_motion(int x4, int y4)
     if (i == cur) { if (!((mv_done >> sub) & 1)) return r; }
     else if (i > cur) return r;
     if (i != cur && mb_type[i] <= T_I16) { r.ref = -1; return r; }
-    r.ref = 0; r.x = mvs[(i * 16 + sub) * 2]; r.y = mvs[(i * 16 + sub) * 2 + 1];
+    r.ref = refs[i * 16 + sub]; r.x = mvs[(i * 16 + sub) * 2]; r.y = mvs[(i * 16 + sub) * 2 + 1];
     return r;
 }
 static int med3(int a, int b, int c) { int lo = a < b ? a : b, hi = a < b ? b : a; return c < lo ? lo : c > hi ? hi : c; }
-/* H.264 8.4.1.3, single reference: dir 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right */
-static void predict_mv(int mbx, int mby, int bx, int by, int bw, int dir, int *px, int *py)
+/* H.264 8.4.1.3: dir 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right; ref = reference index of the partition */
+static void predict_mv(int mbx, int mby, int bx, int by, int bw, int dir, int ref, int *px, int *py)
 {
     int x0 = mbx * 4 + bx, y0 = mby * 4 + by;
     nb_t a = nb_motion(x0 - 1, y0), b = nb_motion(x0, y0 - 1), c = nb_motion(x0 + bw, y0 - 1);
     if (c.ref == -2) c = nb_motion(x0 - 1, y0 - 1);
-    if (dir == 1 && b.ref == 0) { *px = b.x; *py = b.y; return; }
-    if (dir == 2 && a.ref == 0) { *px = a.x; *py = a.y; return; }
-    if (dir == 3 && a.ref == 0) { *px = a.x; *py = a.y; return; }
-    if (dir == 4 && c.ref == 0) { *px = c.x; *py = c.y; return; }
-    int hits = (a.ref == 0) + (b.ref == 0) + (c.ref == 0);
-    if (hits == 1) { nb_t *s = a.ref == 0 ? &a : b.ref == 0 ? &b : &c; *px = s->x; *py = s->y; return; }
+    if (dir == 1 && b.ref == ref) { *px = b.x; *py = b.y; return; }
+    if (dir == 2 && a.ref == ref) { *px = a.x; *py = a.y; return; }
+    if (dir == 3 && a.ref == ref) { *px = a.x; *py = a.y; return; }
+    if (dir == 4 && c.ref == ref) { *px = c.x; *py = c.y; return; }
+    int hits = (a.ref == ref) + (b.ref == ref) + (c.ref == ref);
+    if (hits == 1) { nb_t *s = a.ref == ref ? &a : b.ref == ref ? &b : &c; *px = s->x; *py = s->y; return; }
     if (hits == 0 && b.ref == -2 && c.ref == -2 && a.ref != -2) { *px = a.x; *py = a.y; return; }
+    /* neighbours that are intra or unavailable count as zero vectors in the median */
+    if (a.ref < 0) a.x = a.y = 0;
+    if (b.ref < 0) b.x = b.y = 0;
+    if (c.ref < 0) c.x = c.y = 0;
     *px = med3(a.x, b.x, c.x); *py = med3(a.y, b.y, c.y);
 }
-static void set_mv(int bx, int by, int bw, int bh, int mx, int my)
+static void set_mv(int bx, int by, int bw, int bh, int mx, int my, int ref)
 {
     for (int y = by; y < by + bh; y++)
         for (int x = bx; x < bx + bw; x++) {
+            refs[cur * 16 + y * 4 + x] = (int8_t)ref;
             mvs[(cur * 16 + y * 4 + x) * 2] = (int16_t)mx; mvs[(cur * 16 + y * 4 + x) * 2 + 1] = (int16_t)my;
             mv_done |= 1u << (y * 4 + x);
         }
@@ -286,6 +296,7 @@ static void put_intra(bw_t *b, int mbx, int mby, int type_offset)
     resid_t r; int i16_ac = 0;
     int cbp = rand_residual(&r, is16, &i16_ac);
     memset(mvs + cur * 32, 0, 64);
+    memset(refs + cur * 16, -1, 16);
     if (is16) {
         int legal[4], nl = 0;
         if (T) legal[nl++] = 0;
@@ -342,24 +353,28 @@ static void put_inter(bw_t *b, int mbx, int mby)
     mb_type[cur] = t == 3 ? T_P8 : T_P;
     memset(i4m + cur * 16, 2, 16);
     bw_ue(b, (uint32_t)t);
+    /* te(v) with two active references: one bit, inverted */
+    int pref[4] = { 0, 0, 0, 0 };
     if (t < 3) {
         int np = t == 0 ? 1 : 2;
+        for (int k = 0; k < np; k++) if (n_active > 1) { pref[k] = pct(35); bw_put(b, 1, !pref[k]); }
         for (int k = 0; k < np; k++) {
             int mx, my, px, py, dir = t == 0 ? 0 : t == 1 ? 1 + k : 3 + k;
-            predict_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], dir, &px, &py);
+            predict_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], dir, pref[k], &px, &py);
             if (pct(25) && mv_ok(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], px, py)) { mx = px; my = py; }
             else random_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], &mx, &my);
             bw_se(b, mx - px); bw_se(b, my - py);
-            set_mv(geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], mx, my);
+            set_mv(geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], mx, my, pref[k]);
         }
     } else {
         for (int k = 0; k < 4; k++) bw_ue(b, 0);                       /* sub_mb_type 8x8 (A-Q4) */
+        for (int k = 0; k < 4; k++) if (n_active > 1) { pref[k] = pct(35); bw_put(b, 1, !pref[k]); }
         for (int k = 0; k < 4; k++) {
             int ox = (k & 1) * 2, oy = (k >> 1) * 2, mx, my, px, py;
-            predict_mv(mbx, mby, ox, oy, 2, 0, &px, &py);
+            predict_mv(mbx, mby, ox, oy, 2, 0, pref[k], &px, &py);
             random_mv(mbx, mby, ox, oy, 2, 2, &mx, &my);
             bw_se(b, mx - px); bw_se(b, my - py);
-            set_mv(ox, oy, 2, 2, mx, my);
+            set_mv(ox, oy, 2, 2, mx, my, pref[k]);
         }
     }
     resid_t r; int dummy;
@@ -376,17 +391,17 @@ static int try_skip(int mbx, int mby)
     int mx = 0, my = 0;
     nb_t a = nb_motion(mbx * 4 - 1, mby * 4), b = nb_motion(mbx * 4, mby * 4 - 1);
     if (!(a.ref == -2 || b.ref == -2 || (a.ref == 0 && !a.x && !a.y) || (b.ref == 0 && !b.x && !b.y)))
-        predict_mv(mbx, mby, 0, 0, 4, 0, &mx, &my);
+        predict_mv(mbx, mby, 0, 0, 4, 0, 0, &mx, &my);
     if (!mv_ok(mbx, mby, 0, 0, 4, 4, mx, my)) return 0;
     mb_type[cur] = T_SKIP;
     memset(i4m + cur * 16, 2, 16);
     memset(nnz + (size_t)cur * 24, 0, 24);
-    set_mv(0, 0, 4, 4, mx, my);
+    set_mv(0, 0, 4, 4, mx, my, 0);
     return 1;
 }
 
 /* ---------------------------------------------------------------- pictures -------------- */
-static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn)
+static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn, int refs_available)
 {
     bw_t b = { 0 };
     bw_ue(&b, 0);                               /* first_mb_in_slice */
@@ -394,7 +409,12 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
     bw_ue(&b, 0);                               /* pps id */
     bw_put(&b, log2_fn, (uint32_t)frame_num);
     if (idr) bw_ue(&b, (uint32_t)idr_id);
-    if (is_p) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }   /* no num_ref_idx override, no reordering */
+    n_active = is_p && opt_refs > 1 && refs_available > 1 ? 2 : 1;
+    if (is_p) {
+        if (opt_refs > 1) { bw_put(&b, 1, 1); bw_ue(&b, (uint32_t)(n_active - 1)); }   /* num_ref_idx_active_override */
+        else bw_put(&b, 1, 0);
+        bw_put(&b, 1, 0);                               /* no reordering */
+    }
     if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }    /* no_output_of_prior_pics, long_term_reference */
     else bw_put(&b, 1, 0);                              /* sliding-window marking */
     bw_se(&b, 0);                               /* slice_qp_delta */
@@ -411,6 +431,7 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         if (k >= 96) put_intra(&b, mbx, mby, 5); else put_inter(&b, mbx, mby);
     }
     if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+    if (dump_mv) { fwrite(mvs, 2, (size_t)NMB * 32, dump_mv); fwrite(refs, 1, (size_t)NMB * 16, dump_mv); }
     bw_trailing(&b);
     write_nal(f, 3, idr ? 5 : 1, &b);
     free(b.buf);
@@ -438,12 +459,14 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--crop-bottom")) { crop_bottom = v; i++; }
         else if (!strcmp(a, "--intra-only")) intra_only = 1;
         else if (!strcmp(a, "--nodeblock")) opt_deblock = 0;
+        else if (!strcmp(a, "--refs")) { opt_refs = v; i++; }
+        else if (!strcmp(a, "--dump-mv")) { dump_mv = fopen(argv[i + 1], "wb"); i++; }
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
-    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51) { fprintf(stderr, "bad geometry\n"); return 2; }
+    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > 2) { fprintf(stderr, "bad geometry\n"); return 2; }
     NMB = W * H;
     g_rng = seed * 0x9e3779b97f4a7c15ull + 264;
-    mb_type = calloc((size_t)NMB, 1); mvs = calloc((size_t)NMB * 32, 2); nnz = calloc((size_t)NMB, 24); i4m = calloc((size_t)NMB, 16);
+    mb_type = calloc((size_t)NMB, 1); mvs = calloc((size_t)NMB * 32, 2); nnz = calloc((size_t)NMB, 24); i4m = calloc((size_t)NMB, 16); refs = calloc((size_t)NMB, 16);
     FILE *f = fopen(argv[1], "wb");
     if (!f) { perror(argv[1]); return 2; }
     const int log2_fn = 8;
@@ -451,7 +474,7 @@ int main(int argc, char **argv)
         bw_t b = { 0 };
         bw_put(&b, 8, 66); bw_put(&b, 8, 0xc0); bw_put(&b, 8, 40);
         bw_ue(&b, 0); bw_ue(&b, log2_fn - 4); bw_ue(&b, 2);
-        bw_ue(&b, 1); bw_put(&b, 1, 0);
+        bw_ue(&b, (uint32_t)opt_refs); bw_put(&b, 1, 0);    /* num_ref_frames */
         bw_ue(&b, (uint32_t)(W - 1)); bw_ue(&b, (uint32_t)(H - 1));
         bw_put(&b, 1, 1); bw_put(&b, 1, 1);
         if (crop_bottom) { bw_put(&b, 1, 1); bw_ue(&b, 0); bw_ue(&b, 0); bw_ue(&b, 0); bw_ue(&b, (uint32_t)crop_bottom); }
@@ -469,14 +492,16 @@ int main(int argc, char **argv)
         bw_trailing(&b);
         write_nal(f, 3, 8, &b); free(b.buf);
     }
-    int frame_num = 0, idr_id = 0;
+    int frame_num = 0, idr_id = 0, since_idr = 0;
     for (int n = 0; n < frames; n++) {
         int idr = intra_only || n == 0 || (gop > 0 && n % gop == 0);
-        if (idr) frame_num = 0;
-        put_slice(f, idr, !idr, frame_num, idr_id, log2_fn);
+        if (idr) { frame_num = 0; since_idr = 0; }
+        put_slice(f, idr, !idr, frame_num, idr_id, log2_fn, since_idr);   /* since_idr = reference pictures available (sliding window) */
+        since_idr++;
         if (idr) idr_id = (idr_id + 1) & 0xffff;
         frame_num = (frame_num + 1) & ((1 << log2_fn) - 1);
     }
     fclose(f);
+    if (dump_mv) fclose(dump_mv);
     return 0;
 }

@@ -1,0 +1,65 @@
+"""Two reference frames with a reference index per partition.  The reference decoder is broken
+here (Appendix A-Q5: out-of-bounds scan8 index), so nothing can be pinned against it; instead
+  * CPU: the parser's motion vectors and reference indices are checked against the stream writer's own record of what it
+    coded (tools/synth264 --dump-mv): two independent implementations of the H.264 8.4.1.3 predictor and the list-0
+    construction (sliding window, PicNum order) have to agree;
+  * GPU: the HIP path against the CPU oracle, picture by picture - both take reference slots per 8x8 quadrant, which
+    exercises the per-quadrant reference pointers of k_inter / k_inter_quads and the reference test of the boundary strengths."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from p264decoder_amd import Parser, _native as N
+from tests import synth_cases
+
+ARGS = "--mbw 11 --mbh 9 --frames 10 --gop 0 --seed 41 --refs 2 --coded 8 --maxlevel 6"
+
+
+def make(tmp_path):
+    synth_cases.ensure_tool()
+    stream, dump = str(tmp_path / "mr.264"), str(tmp_path / "mr.mv")
+    subprocess.run([synth_cases.TOOL, stream] + ARGS.split() + ["--dump-mv", dump], check=True)
+    return open(stream, "rb").read(), np.fromfile(dump, dtype=np.uint8)
+
+
+def test_parser_against_writer(lib, tmp_path):
+    data, dump = make(tmp_path)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(data)
+    n = pics[0].n_mb
+    per = n * 64 + n * 16
+    assert len(pics) == 10 and parser.slots == 3 and len(dump) == per * len(pics)
+    both = 0
+    for i, p in enumerate(pics):
+        blob = dump[i * per:(i + 1) * per]
+        mv = blob[:n * 64].view(np.int16).reshape(n, 16, 2)
+        rf = blob[n * 64:].view(np.int8).reshape(n, 16)
+        assert p.desc.n_ref == min(i, 2)
+        if i >= 2:                                            # list 0 = the two previous pictures, most recent first
+            assert p.desc.ref_slot[0] == pics[i - 1].desc.dst_slot and p.desc.ref_slot[1] == pics[i - 2].desc.dst_slot
+        inter = p.mb_records()["mb_type"] > N.MB_IPCM
+        assert np.array_equal(p.mv.reshape(n, 16, 2)[inter], mv[inter]), "picture %d: vectors" % i
+        assert np.array_equal(p.ref_idx.reshape(n, 4)[inter], rf[:, [0, 2, 8, 10]][inter]), "picture %d: reference indices" % i
+        both += int(((rf == 1).any(axis=1) & (rf == 0).any(axis=1)).sum())
+    assert both > 20                                          # macroblocks mixing both references exist
+
+
+@pytest.mark.gpu
+def test_two_references_hip_vs_oracle(lib, oracle, tmp_path):
+    from p264decoder_amd import HipReconstructor
+    from tests import oracle_bind
+    data, _ = make(tmp_path)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(data)
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=1, slots=parser.slots, max_pictures=1, lib=lib)
+    for i, p in enumerate(pics):
+        want = oracle_bind.reconstruct(oracle, store, p)
+        hip.submit(0, p)
+        got = hip.read_frame(0, p.desc.dst_slot)
+        for plane, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), "picture %d plane %d differs" % (i, plane)
+    hip.close()

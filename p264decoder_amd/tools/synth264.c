@@ -14,6 +14,7 @@
  *   synth264 out.264 --mbw 120 --mbh 68 --frames 60 --gop 30 --seed 3 [--intra-only]
  *            [--qp 26] [--coded 12] [--maxlevel 32] [--mvmax 64] [--cqo 0] [--nodeblock]
  *            [--refs 2]      two reference frames, reference index per partition (outside the reference's safe subset, A-Q5)
+ *            [--slices N]    N slices per picture (equal runs of macroblocks; the reference handles one, decoder/decoder.c:516-523)
  *            [--dump-mv f]   per picture: the intended vectors int16[mb][16][2] and reference indices int8[mb][16]
  */
 #include <stdio.h>
@@ -85,7 +86,9 @@ static uint8_t *nnz;                        /* [mb][24] */
 static int8_t  *i4m;                        /* [mb][16], 2 for non-I4x4 */
 static int cur;                             /* current MB index */
 
-static int avail(int mbx, int mby) { return mbx >= 0 && mby >= 0 && mbx < W && mby < H && mby * W + mbx < cur; }
+static int opt_slices = 1, slice_first;     /* --slices: equal runs of macroblocks; slice_first = first MB of the current slice */
+/* a neighbour is usable for prediction when it was coded earlier IN THE SAME SLICE (H.264 6.4.x) */
+static int avail(int mbx, int mby) { return mbx >= 0 && mby >= 0 && mbx < W && mby < H && mby * W + mbx < cur && mby * W + mbx >= slice_first; }
 
 typedef struct { int ref, x, y; } nb_t;     /* ref -2 unavailable, -1 intra, >= 0 reference index */
 static unsigned mv_done;
@@ -95,7 +98,7 @@ static nb_t nb_motion(int x4, int y4)
     if (x4 < 0 || y4 < 0 || (x4 >> 2) >= W || (y4 >> 2) >= H) return r;
     int i = (y4 >> 2) * W + (x4 >> 2), sub = (y4 & 3) * 4 + (x4 & 3);
     if (i == cur) { if (!((mv_done >> sub) & 1)) return r; }
-    else if (i > cur) return r;
+    else if (i > cur || i < slice_first) return r;
     if (i != cur && mb_type[i] <= T_I16) { r.ref = -1; return r; }
     r.ref = refs[i * 16 + sub]; r.x = mvs[(i * 16 + sub) * 2]; r.y = mvs[(i * 16 + sub) * 2 + 1];
     return r;
@@ -403,38 +406,44 @@ static int try_skip(int mbx, int mby)
 /* ---------------------------------------------------------------- pictures -------------- */
 static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn, int refs_available)
 {
-    bw_t b = { 0 };
-    bw_ue(&b, 0);                               /* first_mb_in_slice */
-    bw_ue(&b, is_p ? 5 : 7);                    /* slice_type: all slices of the picture alike */
-    bw_ue(&b, 0);                               /* pps id */
-    bw_put(&b, log2_fn, (uint32_t)frame_num);
-    if (idr) bw_ue(&b, (uint32_t)idr_id);
     n_active = is_p && opt_refs > 1 && refs_available > 1 ? 2 : 1;
-    if (is_p) {
-        if (opt_refs > 1) { bw_put(&b, 1, 1); bw_ue(&b, (uint32_t)(n_active - 1)); }   /* num_ref_idx_active_override */
-        else bw_put(&b, 1, 0);
-        bw_put(&b, 1, 0);                               /* no reordering */
+    for (int sl = 0; sl < opt_slices; sl++) {
+        const int first = (int)((long)NMB * sl / opt_slices), end = (int)((long)NMB * (sl + 1) / opt_slices);
+        if (first == end) continue;
+        slice_first = first;
+        bw_t b = { 0 };
+        bw_ue(&b, (uint32_t)first);                 /* first_mb_in_slice */
+        bw_ue(&b, is_p ? 5 : 7);                    /* slice_type: all slices of the picture alike */
+        bw_ue(&b, 0);                               /* pps id */
+        bw_put(&b, log2_fn, (uint32_t)frame_num);
+        if (idr) bw_ue(&b, (uint32_t)idr_id);
+        if (is_p) {
+            if (opt_refs > 1) { bw_put(&b, 1, 1); bw_ue(&b, (uint32_t)(n_active - 1)); }   /* num_ref_idx_active_override */
+            else bw_put(&b, 1, 0);
+            bw_put(&b, 1, 0);                               /* no reordering */
+        }
+        if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }    /* no_output_of_prior_pics, long_term_reference */
+        else bw_put(&b, 1, 0);                              /* sliding-window marking */
+        bw_se(&b, 0);                               /* slice_qp_delta */
+        bw_ue(&b, opt_deblock ? 0 : 1);             /* disable_deblocking_filter_idc (0: also across slice boundaries) */
+        if (opt_deblock) { bw_se(&b, 0); bw_se(&b, 0); }
+        int skip_run = 0;
+        for (cur = first; cur < end; cur++) {
+            int mbx = cur % W, mby = cur / W;
+            mv_done = 0;
+            if (!is_p) { put_intra(&b, mbx, mby, 0); continue; }
+            int k = rnd(100);
+            if (k < 20 && try_skip(mbx, mby)) { skip_run++; continue; }
+            bw_ue(&b, (uint32_t)skip_run); skip_run = 0;
+            if (k >= 96) put_intra(&b, mbx, mby, 5); else put_inter(&b, mbx, mby);
+        }
+        if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+        bw_trailing(&b);
+        write_nal(f, 3, idr ? 5 : 1, &b);
+        free(b.buf);
     }
-    if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }    /* no_output_of_prior_pics, long_term_reference */
-    else bw_put(&b, 1, 0);                              /* sliding-window marking */
-    bw_se(&b, 0);                               /* slice_qp_delta */
-    bw_ue(&b, opt_deblock ? 0 : 1);             /* disable_deblocking_filter_idc */
-    if (opt_deblock) { bw_se(&b, 0); bw_se(&b, 0); }
-    int skip_run = 0;
-    for (cur = 0; cur < NMB; cur++) {
-        int mbx = cur % W, mby = cur / W;
-        mv_done = 0;
-        if (!is_p) { put_intra(&b, mbx, mby, 0); continue; }
-        int k = rnd(100);
-        if (k < 20 && try_skip(mbx, mby)) { skip_run++; continue; }
-        bw_ue(&b, (uint32_t)skip_run); skip_run = 0;
-        if (k >= 96) put_intra(&b, mbx, mby, 5); else put_inter(&b, mbx, mby);
-    }
-    if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+    slice_first = 0;
     if (dump_mv) { fwrite(mvs, 2, (size_t)NMB * 32, dump_mv); fwrite(refs, 1, (size_t)NMB * 16, dump_mv); }
-    bw_trailing(&b);
-    write_nal(f, 3, idr ? 5 : 1, &b);
-    free(b.buf);
 }
 
 int main(int argc, char **argv)
@@ -460,6 +469,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--intra-only")) intra_only = 1;
         else if (!strcmp(a, "--nodeblock")) opt_deblock = 0;
         else if (!strcmp(a, "--refs")) { opt_refs = v; i++; }
+        else if (!strcmp(a, "--slices")) { opt_slices = v < 1 ? 1 : v; i++; }
         else if (!strcmp(a, "--dump-mv")) { dump_mv = fopen(argv[i + 1], "wb"); i++; }
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }

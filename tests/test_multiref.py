@@ -1,4 +1,5 @@
-"""Two reference frames with a reference index per partition.  The reference decoder is broken
+"""Beyond the reference's safe subset: two reference frames with a reference index per partition
+and several slices per picture.  The reference decoder is broken
 here (Appendix A-Q5: out-of-bounds scan8 index), so nothing can be pinned against it; instead
   * CPU: the parser's motion vectors and reference indices are checked against the stream writer's own record of what it
     coded (tools/synth264 --dump-mv): two independent implementations of the H.264 8.4.1.3 predictor and the list-0
@@ -15,12 +16,16 @@ from p264decoder_amd import Parser, _native as N
 from tests import synth_cases
 
 ARGS = "--mbw 11 --mbh 9 --frames 10 --gop 0 --seed 41 --refs 2 --coded 8 --maxlevel 6"
+# several slices per picture (the reference handles one, decoder/decoder.c:516-523): slice boundaries in the middle of
+# macroblock rows change every neighbour-availability pattern of the intra predictors and the vector / nC / mode predictors
+SLICED = ["--mbw 11 --mbh 9 --frames 8 --gop 4 --seed 43 --slices 4 --coded 10 --maxlevel 6",
+          "--mbw 7 --mbh 6 --frames 9 --gop 0 --seed 44 --slices 5 --refs 2 --coded 12 --maxlevel 6"]
 
 
-def make(tmp_path):
+def make(tmp_path, args=ARGS):
     synth_cases.ensure_tool()
     stream, dump = str(tmp_path / "mr.264"), str(tmp_path / "mr.mv")
-    subprocess.run([synth_cases.TOOL, stream] + ARGS.split() + ["--dump-mv", dump], check=True)
+    subprocess.run([synth_cases.TOOL, stream] + args.split() + ["--dump-mv", dump], check=True)
     return open(stream, "rb").read(), np.fromfile(dump, dtype=np.uint8)
 
 
@@ -46,11 +51,32 @@ def test_parser_against_writer(lib, tmp_path):
     assert both > 20                                          # macroblocks mixing both references exist
 
 
+@pytest.mark.parametrize("args", SLICED)
+def test_sliced_pictures_parser_against_writer(lib, tmp_path, args):
+    data, dump = make(tmp_path, args)
+    pics = Parser(quiet=True, lib=lib).parse_stream(data)
+    n = pics[0].n_mb
+    per = n * 64 + n * 16
+    assert len(dump) == per * len(pics)
+    patterns = set()
+    for i, p in enumerate(pics):
+        blob = dump[i * per:(i + 1) * per]
+        mv = blob[:n * 64].view(np.int16).reshape(n, 16, 2)
+        rf = blob[n * 64:].view(np.int8).reshape(n, 16)
+        rec = p.mb_records()
+        inter = rec["mb_type"] > N.MB_IPCM
+        assert np.array_equal(p.mv.reshape(n, 16, 2)[inter], mv[inter]), "picture %d: vectors" % i
+        assert np.array_equal(p.ref_idx.reshape(n, 4)[inter], rf[:, [0, 2, 8, 10]][inter]), "picture %d: reference indices" % i
+        patterns |= set(rec["avail"].tolist())
+    assert len(patterns) >= 7                                 # far more neighbour patterns than a single slice produces
+
+
 @pytest.mark.gpu
-def test_two_references_hip_vs_oracle(lib, oracle, tmp_path):
+@pytest.mark.parametrize("args", [ARGS] + SLICED)
+def test_two_references_hip_vs_oracle(lib, oracle, tmp_path, args):
     from p264decoder_amd import HipReconstructor
     from tests import oracle_bind
-    data, _ = make(tmp_path)
+    data, _ = make(tmp_path, args)
     parser = Parser(quiet=True, lib=lib)
     pics = parser.parse_stream(data)
     mb_w, mb_h = pics[0].mb_w, pics[0].mb_h

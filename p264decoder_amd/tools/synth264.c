@@ -86,6 +86,7 @@ static uint8_t *nnz;                        /* [mb][24] */
 static int8_t  *i4m;                        /* [mb][16], 2 for non-I4x4 */
 static int cur;                             /* current MB index */
 
+static int opt_idc = 0;                     /* --deblock-idc 2: no filtering across slice boundaries */
 static int opt_slices = 1, slice_first;     /* --slices: equal runs of macroblocks; slice_first = first MB of the current slice */
 /* a neighbour is usable for prediction when it was coded earlier IN THE SAME SLICE (H.264 6.4.x) */
 static int avail(int mbx, int mby) { return mbx >= 0 && mby >= 0 && mbx < W && mby < H && mby * W + mbx < cur && mby * W + mbx >= slice_first; }
@@ -425,7 +426,7 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }    /* no_output_of_prior_pics, long_term_reference */
         else bw_put(&b, 1, 0);                              /* sliding-window marking */
         bw_se(&b, 0);                               /* slice_qp_delta */
-        bw_ue(&b, opt_deblock ? 0 : 1);             /* disable_deblocking_filter_idc (0: also across slice boundaries) */
+        bw_ue(&b, (uint32_t)(opt_deblock ? opt_idc : 1)); /* disable_deblocking_filter_idc: 0 also across slice boundaries, 2 not */
         if (opt_deblock) { bw_se(&b, 0); bw_se(&b, 0); }
         int skip_run = 0;
         for (cur = first; cur < end; cur++) {
@@ -470,6 +471,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--nodeblock")) opt_deblock = 0;
         else if (!strcmp(a, "--refs")) { opt_refs = v; i++; }
         else if (!strcmp(a, "--slices")) { opt_slices = v < 1 ? 1 : v; i++; }
+        else if (!strcmp(a, "--deblock-idc")) { opt_idc = v == 2 ? 2 : 0; i++; }
         else if (!strcmp(a, "--dump-mv")) { dump_mv = fopen(argv[i + 1], "wb"); i++; }
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }

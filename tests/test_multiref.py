@@ -19,7 +19,8 @@ ARGS = "--mbw 11 --mbh 9 --frames 10 --gop 0 --seed 41 --refs 2 --coded 8 --maxl
 # several slices per picture (the reference handles one, decoder/decoder.c:516-523): slice boundaries in the middle of
 # macroblock rows change every neighbour-availability pattern of the intra predictors and the vector / nC / mode predictors
 SLICED = ["--mbw 11 --mbh 9 --frames 8 --gop 4 --seed 43 --slices 4 --coded 10 --maxlevel 6",
-          "--mbw 7 --mbh 6 --frames 9 --gop 0 --seed 44 --slices 5 --refs 2 --coded 12 --maxlevel 6"]
+          "--mbw 7 --mbh 6 --frames 9 --gop 0 --seed 44 --slices 5 --refs 2 --coded 12 --maxlevel 6",
+          "--mbw 9 --mbh 7 --frames 8 --gop 4 --seed 45 --slices 3 --deblock-idc 2 --coded 14 --maxlevel 8"]   # no filtering across slices
 
 
 def make(tmp_path, args=ARGS):

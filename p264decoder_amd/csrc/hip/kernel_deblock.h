@@ -63,7 +63,7 @@ struct EdgeInfo {                  // 64 bytes per macroblock, written by k_debl
 __device__ __forceinline__ int bs_motion(int vp, int vq, int rp, int rq)
 {   // core/frame.c:565-577: different reference or a vector component differing by >= 4 quarter-pels
     const int dx = (int)(int16_t)vp - (int)(int16_t)vq, dy = (vp >> 16) - (vq >> 16);
-    return (rp != rq) | (abs(dx) >= 4) | (abs(dy) >= 4);
+    return (int)(rp != rq) | (int)(abs(dx) >= 4) | (int)(abs(dy) >= 4);
 }
 
 __global__ __launch_bounds__(256)

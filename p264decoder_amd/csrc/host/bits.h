@@ -62,8 +62,11 @@ static inline int  br_eof(const bitrd_t *b)       { return (b->consumed >> 3) >=
 
 static inline uint32_t br_ue(bitrd_t *b)
 {
-    int zeros = 0;
-    while (zeros < 32 && br_peek(b, 1) == 0 && !br_overrun(b)) { br_skip(b, 1); zeros++; }
+    /* leading zeros of the next 32 bits in one step (the window always holds at least 57 valid bits; past the end of the
+     * buffer it is zero-padded, so a truncated code reads as "32 zeros" and is rejected by the callers' range checks) */
+    const uint32_t w = br_peek(b, 32);
+    const int zeros = w ? __builtin_clz(w) : 32;
+    br_skip(b, zeros);
     br_skip(b, 1);                       /* the terminating 1 */
     if (zeros == 0) return 0;
     if (zeros >= 32) return 0xffffffffu;

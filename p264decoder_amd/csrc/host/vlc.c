@@ -120,8 +120,10 @@ int cavlc_read_block(bitrd_t *b, int nC, int max_coeff, int16_t *out)
     int suffix_len = (tc > 10 && t1 < 3) ? 1 : 0;
     for (int i = 0; i < t1; i++) level[i] = br_u1(b) ? -1 : 1;
     for (int i = t1; i < tc; i++) {
-        int prefix = 0;
-        while (prefix < 32 && br_peek(b, 1) == 0) { br_skip(b, 1); prefix++; if (br_overrun(b)) return -1; }
+        const uint32_t w = br_peek(b, 32);                  /* level_prefix: zeros up to the first 1, counted in one step */
+        const int prefix = w ? __builtin_clz(w) : 32;
+        br_skip(b, prefix);
+        if (br_overrun(b)) return -1;
         br_skip(b, 1);
         int sufbits = suffix_len;
         if (prefix == 14 && suffix_len == 0) sufbits = 4;

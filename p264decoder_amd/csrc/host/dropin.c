@@ -62,9 +62,15 @@ int p264_nal_decode(p264_nal_t *nal, void *buf, int size)
     nal->i_type = src[0] & 0x1f;
     nal->i_ref_idc = (src[0] >> 5) & 3;
     src++;
+    /* same result as the byte loop of core/core.c:318-334 (a 00 00 03 is only stripped while at least four bytes remain,
+     * A-Q10), but the payload moves in runs between zero bytes found by memchr */
     while (src < end) {
-        if (src < end - 3 && src[0] == 0 && src[1] == 0 && src[2] == 3) { *dst++ = 0; *dst++ = 0; src += 3; continue; }
-        *dst++ = *src++;
+        const uint8_t *z = (const uint8_t *)memchr(src, 0, (size_t)(end - src));
+        if (!z) z = end;
+        memcpy(dst, src, (size_t)(z - src)); dst += z - src; src = z;
+        if (src >= end) break;
+        if (src < end - 3 && src[1] == 0 && src[2] == 3) { *dst++ = 0; *dst++ = 0; src += 3; }
+        else *dst++ = *src++;
     }
     nal->i_payload = (int)(dst - nal->p_payload);
     return 0;

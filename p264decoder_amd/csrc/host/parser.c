@@ -849,13 +849,25 @@ int p264parse_mb_height(const p264parse *p)  { return p ? p->mb_h : 0; }
 int p264parse_slots(const p264parse *p)      { return p ? p->slots : 0; }
 int p264parse_generation(const p264parse *p) { return p ? p->generation : 0; }
 
+/* first index >= from with buf[i..i+2] == 00 00 01, or an index with i + 3 > size; the scan hops between zero bytes */
+static int64_t annexb_find(const uint8_t *buf, int64_t size, int64_t from)
+{
+    int64_t i = from;
+    while (i + 3 <= size) {
+        const uint8_t *z = (const uint8_t *)memchr(buf + i, 0, (size_t)(size - 2 - i));
+        if (!z) return size;
+        i = z - buf;
+        if (buf[i + 1] == 0 && buf[i + 2] == 1) return i;
+        i++;
+    }
+    return size;
+}
+
 int p264_annexb_next(const uint8_t *buf, int64_t size, int64_t *pos, int64_t *nal_off, int64_t *nal_len)
 {
-    int64_t i = *pos;
-    while (i + 3 <= size && !(buf[i] == 0 && buf[i+1] == 0 && buf[i+2] == 1)) i++;
+    int64_t i = annexb_find(buf, size, *pos);
     if (i + 3 > size) { *pos = size; return 0; }
-    int64_t start = i + 3, j = start;
-    while (j + 3 <= size && !(buf[j] == 0 && buf[j+1] == 0 && buf[j+2] == 1)) j++;
+    int64_t start = i + 3, j = annexb_find(buf, size, start);
     int64_t end = j + 3 <= size ? j : size;
     *pos = end;
     while (end > start && buf[end-1] == 0) end--;           /* zeros in front of a start code belong to it */

@@ -22,5 +22,21 @@ for trial in range(60):
     except Exception as e:
         pass
 print("fuzz ok")
+# the same kind of damage through the C start-code scanner and emulation-prevention strip (pipeline, parse only)
+for trial in range(40):
+    d = bytearray(synth_cases.stream_bytes("cif_ip"))
+    for _ in range(random.randrange(1, 30)):
+        d[random.randrange(0, len(d))] = random.choice([0, 0, 1, 3, random.randrange(256)])
+    d = bytes(d[:random.randrange(4, len(d))])
+    try:
+        pipe = Pipeline([d, d[: len(d) // 2]], threads=2, device=-1, lib=lib)
+        try:
+            pipe.run()
+        except RuntimeError:
+            pass
+        pipe.close()
+    except RuntimeError:
+        pass
+print("pipeline fuzz ok")
 pipe = Pipeline([data, synth_cases.stream_bytes("cif_ip")]*3, threads=4, device=-1, lib=lib)
 print(pipe.run()); pipe.close()

@@ -208,7 +208,7 @@ def main():
                                    "reconstruction hot path (MC + residual, intra, deblock), parsed inputs resident in HBM",
                        "streams_per_gpu": S, "pictures_per_step": S * world, "mb_per_picture": N_MB, "parallelism": "stream-parallel x%d" % world},
             "macroblocks_per_s": round(fps * N_MB, 0),
-            "roofline": {"kernel": "k_" + dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": {"inter": "k_inter + k_inter_quads", "intra": "k_intra", "deblock": "k_deblock_bs + k_deblock"}[dom], "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
                          "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
                          "measured_copy_GBps": copy_gbps},

@@ -16,6 +16,14 @@
  *            [--refs 2]      two reference frames, reference index per partition (outside the reference's safe subset, A-Q5)
  *            [--slices N]    N slices per picture (equal runs of macroblocks; the reference handles one, decoder/decoder.c:516-523)
  *            [--dump-mv f]   per picture: the intended vectors int16[mb][16][2] and reference indices int8[mb][16]
+ *            [--qp-delta N]  random mb_qp_delta in [-N, N] on every macroblock that carries one (the reference adds it to the
+ *                            SLICE QP instead of accumulating it, decoder/macroblock.c:568 = SURVEY A-Q2; so does this writer:
+ *                            the QP of the macroblock is slice QP + delta, kept inside 0..51)
+ *            [--deblock-offsets A B]  slice_alpha_c0_offset_div2 / slice_beta_offset_div2 (the reference uses them unshifted, A-Q3)
+ *            [--sub8x8]      P_8x8 with all four sub_mb_types (8x8, 8x4, 4x8, 4x4; mis-decoded by the reference, A-Q4)
+ *            [--reorder]     with --refs 2: some P slices swap the two entries of list 0 (ref_pic_list_reordering; ignored by
+ *                            the reference, decoder/lists.c:146-149)
+ *            [--dump-mv f]   additionally records, per picture, one byte: 1 when list 0 was reordered
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -86,6 +94,7 @@ static uint8_t *nnz;                        /* [mb][24] */
 static int8_t  *i4m;                        /* [mb][16], 2 for non-I4x4 */
 static int cur;                             /* current MB index */
 
+static int opt_qpdelta = 0, opt_alpha = 0, opt_beta = 0, opt_sub8x8 = 0, opt_reorder = 0, slice_reordered;
 static int opt_idc = 0;                     /* --deblock-idc 2: no filtering across slice boundaries */
 static int opt_slices = 1, slice_first;     /* --slices: equal runs of macroblocks; slice_first = first MB of the current slice */
 /* a neighbour is usable for prediction when it was coded earlier IN THE SAME SLICE (H.264 6.4.x) */
@@ -229,6 +238,14 @@ static void put_block(bw_t *b, const int16_t *lv, int n, int nC)
 }
 
 /* ---------------------------------------------------------------- macroblock writers ---- */
+static int rand_qp_delta(void)
+{
+    if (!opt_qpdelta) return 0;
+    int lo = -opt_qpdelta, hi = opt_qpdelta;
+    if (opt_qp + lo < 0) lo = -opt_qp;
+    if (opt_qp + hi > 51) hi = 51 - opt_qp;
+    return pct(30) ? 0 : lo + rnd(hi - lo + 1);
+}
 typedef struct { int16_t dc_luma[16], dc_c[2][16], blk[24][16]; int has[24]; } resid_t;
 
 /* draw residual content for the MB; returns cbp (luma bits 0-3, chroma bits 4-5) */
@@ -344,7 +361,7 @@ static void put_intra(bw_t *b, int mbx, int mby, int type_offset)
         for (int k = 0; k < 48; k++) if (cbp_intra_of_code[k] == cbp) code = k;
         bw_ue(b, (uint32_t)code);
     }
-    if (cbp || is16) { bw_se(b, 0); put_residual(b, mbx, mby, &r, is16, cbp); }
+    if (cbp || is16) { bw_se(b, rand_qp_delta()); put_residual(b, mbx, mby, &r, is16, cbp); }
     else memset(nnz + (size_t)cur * 24, 0, 24);
 }
 
@@ -371,21 +388,28 @@ static void put_inter(bw_t *b, int mbx, int mby)
             set_mv(geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], mx, my, pref[k]);
         }
     } else {
-        for (int k = 0; k < 4; k++) bw_ue(b, 0);                       /* sub_mb_type 8x8 (A-Q4) */
+        int sub[4];
+        for (int k = 0; k < 4; k++) { sub[k] = opt_sub8x8 ? rnd(4) : 0; bw_ue(b, (uint32_t)sub[k]); }   /* sub_mb_type: 8x8 only inside the reference's safe subset (A-Q4) */
         for (int k = 0; k < 4; k++) if (n_active > 1) { pref[k] = pct(35); bw_put(b, 1, !pref[k]); }
         for (int k = 0; k < 4; k++) {
-            int ox = (k & 1) * 2, oy = (k >> 1) * 2, mx, my, px, py;
-            predict_mv(mbx, mby, ox, oy, 2, 0, pref[k], &px, &py);
-            random_mv(mbx, mby, ox, oy, 2, 2, &mx, &my);
-            bw_se(b, mx - px); bw_se(b, my - py);
-            set_mv(ox, oy, 2, 2, mx, my, pref[k]);
+            int ox = (k & 1) * 2, oy = (k >> 1) * 2;
+            int sw = (sub[k] == 0 || sub[k] == 1) ? 2 : 1, sh = (sub[k] == 0 || sub[k] == 2) ? 2 : 1;   /* 8x8, 8x4, 4x8, 4x4 */
+            for (int sy = 0; sy < 2; sy += sh)
+                for (int sx = 0; sx < 2; sx += sw) {
+                    int mx, my, px, py;
+                    predict_mv(mbx, mby, ox + sx, oy + sy, sw, 0, pref[k], &px, &py);
+                    if (sub[k] && pct(30) && mv_ok(mbx, mby, ox + sx, oy + sy, sw, sh, px, py)) { mx = px; my = py; }
+                    else random_mv(mbx, mby, ox + sx, oy + sy, sw, sh, &mx, &my);
+                    bw_se(b, mx - px); bw_se(b, my - py);
+                    set_mv(ox + sx, oy + sy, sw, sh, mx, my, pref[k]);
+                }
         }
     }
     resid_t r; int dummy;
     int cbp = rand_residual(&r, 0, &dummy), code = -1;
     for (int k = 0; k < 48; k++) if (cbp_inter_of_code[k] == cbp) code = k;
     bw_ue(b, (uint32_t)code);
-    if (cbp) { bw_se(b, 0); put_residual(b, mbx, mby, &r, 0, cbp); }
+    if (cbp) { bw_se(b, rand_qp_delta()); put_residual(b, mbx, mby, &r, 0, cbp); }
     else memset(nnz + (size_t)cur * 24, 0, 24);
 }
 
@@ -408,6 +432,7 @@ static int try_skip(int mbx, int mby)
 static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn, int refs_available)
 {
     n_active = is_p && opt_refs > 1 && refs_available > 1 ? 2 : 1;
+    slice_reordered = opt_reorder && n_active > 1 && pct(50);
     for (int sl = 0; sl < opt_slices; sl++) {
         const int first = (int)((long)NMB * sl / opt_slices), end = (int)((long)NMB * (sl + 1) / opt_slices);
         if (first == end) continue;
@@ -421,13 +446,16 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         if (is_p) {
             if (opt_refs > 1) { bw_put(&b, 1, 1); bw_ue(&b, (uint32_t)(n_active - 1)); }   /* num_ref_idx_active_override */
             else bw_put(&b, 1, 0);
-            bw_put(&b, 1, 0);                               /* no reordering */
+            if (opt_reorder && n_active > 1 && slice_reordered) {
+                /* list 0 starts as (frame_num - 1, frame_num - 2); "subtract 2 from the prediction" puts frame_num - 2 first */
+                bw_put(&b, 1, 1); bw_ue(&b, 0); bw_ue(&b, 1); bw_ue(&b, 3);
+            } else bw_put(&b, 1, 0);                        /* no reordering */
         }
         if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }    /* no_output_of_prior_pics, long_term_reference */
         else bw_put(&b, 1, 0);                              /* sliding-window marking */
         bw_se(&b, 0);                               /* slice_qp_delta */
         bw_ue(&b, (uint32_t)(opt_deblock ? opt_idc : 1)); /* disable_deblocking_filter_idc: 0 also across slice boundaries, 2 not */
-        if (opt_deblock) { bw_se(&b, 0); bw_se(&b, 0); }
+        if (opt_deblock) { bw_se(&b, opt_alpha); bw_se(&b, opt_beta); }
         int skip_run = 0;
         for (cur = first; cur < end; cur++) {
             int mbx = cur % W, mby = cur / W;
@@ -444,7 +472,10 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         free(b.buf);
     }
     slice_first = 0;
-    if (dump_mv) { fwrite(mvs, 2, (size_t)NMB * 32, dump_mv); fwrite(refs, 1, (size_t)NMB * 16, dump_mv); }
+    if (dump_mv) {
+        fwrite(mvs, 2, (size_t)NMB * 32, dump_mv); fwrite(refs, 1, (size_t)NMB * 16, dump_mv);
+        if (opt_reorder) fputc(slice_reordered, dump_mv);
+    }
 }
 
 int main(int argc, char **argv)
@@ -473,9 +504,13 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--slices")) { opt_slices = v < 1 ? 1 : v; i++; }
         else if (!strcmp(a, "--deblock-idc")) { opt_idc = v == 2 ? 2 : 0; i++; }
         else if (!strcmp(a, "--dump-mv")) { dump_mv = fopen(argv[i + 1], "wb"); i++; }
+        else if (!strcmp(a, "--qp-delta")) { opt_qpdelta = v < 0 ? -v : v; i++; }
+        else if (!strcmp(a, "--deblock-offsets")) { opt_alpha = v; opt_beta = i + 2 < argc ? atoi(argv[i + 2]) : 0; i += 2; }
+        else if (!strcmp(a, "--sub8x8")) opt_sub8x8 = 1;
+        else if (!strcmp(a, "--reorder")) opt_reorder = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
-    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > 2) { fprintf(stderr, "bad geometry\n"); return 2; }
+    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > 2 || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
     NMB = W * H;
     g_rng = seed * 0x9e3779b97f4a7c15ull + 264;
     mb_type = calloc((size_t)NMB, 1); mvs = calloc((size_t)NMB * 32, 2); nnz = calloc((size_t)NMB, 24); i4m = calloc((size_t)NMB, 16); refs = calloc((size_t)NMB, 16);

@@ -39,9 +39,17 @@ CASES = {
     "cqo_pos": ("--mbw 6 --mbh 5 --frames 6 --gop 3 --seed 25 --qp 40 --cqo 9 --coded 30 --maxlevel 3", None),
     "nodeblock": ("--mbw 8 --mbh 6 --frames 8 --gop 4 --seed 26 --nodeblock --coded 25 --maxlevel 12", None),
     "dense": ("--mbw 8 --mbh 6 --frames 8 --gop 4 --seed 27 --coded 90 --maxlevel 6", None),
+    # per-macroblock QP (mb_qp_delta; the reference adds it to the slice QP and carries the last QP over skipped /
+    # residual-free macroblocks and across pictures, SURVEY A-Q2) and non-zero deblocking offsets (used unshifted, A-Q3)
+    "qpdelta": ("--mbw 11 --mbh 9 --frames 12 --gop 6 --seed 51 --qp 28 --qp-delta 6 --coded 25 --maxlevel 6", None),
+    "qpdelta_wide": ("--mbw 8 --mbh 6 --frames 10 --gop 5 --seed 52 --qp 26 --qp-delta 25 --coded 30 --maxlevel 2", None),
+    "dboffs_pos": ("--mbw 11 --mbh 9 --frames 10 --gop 5 --seed 53 --qp 30 --deblock-offsets 6 5 --coded 20 --maxlevel 8", None),
+    "dboffs_neg": ("--mbw 11 --mbh 9 --frames 10 --gop 5 --seed 54 --qp 34 --deblock-offsets -6 -4 --coded 20 --maxlevel 6", None),
+    "qpd_dbo": ("--mbw 12 --mbh 7 --frames 10 --gop 5 --seed 55 --qp 30 --qp-delta 8 --deblock-offsets 3 -2 --cqo 4 --coded 25 --maxlevel 5", None),
+    "qpd_1080p": ("--mbw 120 --mbh 68 --frames 4 --gop 0 --seed 56 --qp 27 --qp-delta 5 --deblock-offsets 2 1 --coded 12 --maxlevel 8 --crop-bottom 4", 2),
     "mv_far": ("--mbw 10 --mbh 8 --frames 10 --gop 10 --seed 28 --mvmax 64 --coded 5 --maxlevel 6", None),
 }
-BIG = ("cfg2_720p_intra", "cfg3_1080p_ip", "cfg3_1080p_allp")
+BIG = ("cfg2_720p_intra", "cfg3_1080p_ip", "cfg3_1080p_allp", "qpd_1080p")
 
 
 def ensure_tool():

@@ -53,6 +53,33 @@ def test_config3_1080p_allp_vs_oracle(lib, oracle):
     run_case(lib, oracle, "cfg3_1080p_allp")
 
 
+def test_per_macroblock_qp_1080p(lib, oracle):
+    """mb_qp_delta on every coded macroblock plus non-zero deblocking offsets at 1080p (A-Q2, A-Q3), reference-pinned"""
+    run_case(lib, oracle, "qpd_1080p")
+
+
+def test_bench_shape_batch_against_reference_hashes(lib):
+    """The batch bench.py times: more pictures than 2 x compute units in ONE reconstruct call (that is what selects the
+    small-band workgroup shapes of the row-wavefront kernels: 4 intra wavefronts, 4 pictures per deblocking workgroup),
+    1080p, every stream a private clone of the config-3 all-P pictures.  Every stream's pictures must hash to what the
+    real reference decoder produced for that stream (tests/golden/synth_cfg3_1080p_allp.sha256)."""
+    _, hashes = synth_cases.golden("cfg3_1080p_allp")
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("cfg3_1080p_allp"), limit=4)      # IDR + 3 P pictures
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    S = 2 * 256 + 3
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=parser.slots, max_pictures=S, lib=lib)
+    for i, p in enumerate(pics):
+        hip.upload(0, [p])
+        for s in range(1, S):
+            hip.clone_picture(s, 0)
+        hip.reconstruct(list(range(S)), list(range(S)))
+        hip.sync()
+        for s in range(S):
+            assert frame_sha256(*hip.read_frame(s, p.desc.dst_slot)) == hashes[i], "picture %d stream %d differs from the reference decoder" % (i, s)
+    hip.close()
+
+
 def test_config3_through_dropin_api(lib):
     _, hashes = synth_cases.golden("cfg3_1080p_ip")
     dec = Decoder(lib=lib)

@@ -23,6 +23,13 @@ SLICED = ["--mbw 11 --mbh 9 --frames 8 --gop 4 --seed 43 --slices 4 --coded 10 -
           "--mbw 9 --mbh 7 --frames 8 --gop 4 --seed 45 --slices 3 --deblock-idc 2 --coded 14 --maxlevel 8"]   # no filtering across slices
 
 
+# sub-8x8 partitions (8x4, 4x8, 4x4; the reference mis-decodes them, A-Q4) and list-0 reordering (ignored by the reference,
+# decoder/lists.c:146-149): spec-driven, pinned by the writer's record and by HIP == oracle
+SUB8X8 = ["--mbw 11 --mbh 9 --frames 8 --gop 4 --seed 46 --sub8x8 --coded 10 --maxlevel 6",
+          "--mbw 9 --mbh 8 --frames 9 --gop 0 --seed 47 --sub8x8 --refs 2 --slices 2 --mvmax 40 --coded 12 --maxlevel 6"]
+REORDER = "--mbw 10 --mbh 8 --frames 12 --gop 0 --seed 48 --refs 2 --reorder --sub8x8 --coded 10 --maxlevel 6"
+
+
 def make(tmp_path, args=ARGS):
     synth_cases.ensure_tool()
     stream, dump = str(tmp_path / "mr.264"), str(tmp_path / "mr.mv")
@@ -72,8 +79,70 @@ def test_sliced_pictures_parser_against_writer(lib, tmp_path, args):
     assert len(patterns) >= 7                                 # far more neighbour patterns than a single slice produces
 
 
+@pytest.mark.parametrize("args", SUB8X8)
+def test_sub8x8_partitions_parser_against_writer(lib, tmp_path, args):
+    data, dump = make(tmp_path, args)
+    pics = Parser(quiet=True, lib=lib).parse_stream(data)
+    n = pics[0].n_mb
+    per = n * 64 + n * 16
+    assert len(dump) == per * len(pics)
+    shapes = set()
+    for i, p in enumerate(pics):
+        blob = dump[i * per:(i + 1) * per]
+        mv = blob[:n * 64].view(np.int16).reshape(n, 16, 2)
+        rf = blob[n * 64:].view(np.int8).reshape(n, 16)
+        rec = p.mb_records()
+        inter = rec["mb_type"] > N.MB_IPCM
+        got = p.mv.reshape(n, 16, 2)
+        assert np.array_equal(got[inter], mv[inter]), "picture %d: vectors" % i
+        assert np.array_equal(p.ref_idx.reshape(n, 4)[inter], rf[:, [0, 2, 8, 10]][inter]), "picture %d: reference indices" % i
+        # which sub-partition shapes occur: per 8x8 quadrant, are the two rows / the two columns of vectors different?
+        for m in np.nonzero(rec["mb_type"] == N.MB_P_8x8)[0]:
+            v = got[m].reshape(4, 4, 2)
+            for qy in (0, 2):
+                for qx in (0, 2):
+                    q = v[qy:qy + 2, qx:qx + 2]
+                    rows = not np.array_equal(q[0], q[1])
+                    cols = not np.array_equal(q[:, 0], q[:, 1])
+                    shapes.add((rows, cols))
+        # macroblocks with sub-8x8 vectors are not handed to the quadrant kernel
+        if p.desc.n_quads:
+            listed = set((p.quads[:p.desc.n_quads][p.quads[:p.desc.n_quads] != 0xffffffff] >> 2).tolist())
+            for m in listed:
+                v = got[m].reshape(4, 4, 2)
+                for qy in (0, 2):
+                    for qx in (0, 2):
+                        assert (v[qy:qy + 2, qx:qx + 2] == v[qy, qx]).all()
+    assert shapes == {(False, False), (True, False), (False, True), (True, True)}      # 8x8, 8x4, 4x8, 4x4 all present
+
+
+def test_list0_reordering_parser_against_writer(lib, tmp_path):
+    data, dump = make(tmp_path, REORDER)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(data)
+    n = pics[0].n_mb
+    per = n * 64 + n * 16 + 1
+    assert len(pics) == 12 and len(dump) == per * len(pics)
+    swapped = 0
+    for i, p in enumerate(pics):
+        blob = dump[i * per:(i + 1) * per]
+        mv = blob[:n * 64].view(np.int16).reshape(n, 16, 2)
+        rf = blob[n * 64:n * 80].view(np.int8).reshape(n, 16)
+        reordered = int(blob[-1])
+        inter = p.mb_records()["mb_type"] > N.MB_IPCM
+        assert np.array_equal(p.mv.reshape(n, 16, 2)[inter], mv[inter]), "picture %d: vectors" % i
+        assert np.array_equal(p.ref_idx.reshape(n, 4)[inter], rf[:, [0, 2, 8, 10]][inter]), "picture %d: reference indices" % i
+        if i >= 2:
+            want = [pics[i - 1].desc.dst_slot, pics[i - 2].desc.dst_slot]
+            if reordered:
+                want.reverse()
+                swapped += 1
+            assert [p.desc.ref_slot[0], p.desc.ref_slot[1]] == want, "picture %d: list 0" % i
+    assert 2 <= swapped <= 8
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [ARGS] + SLICED)
+@pytest.mark.parametrize("args", [ARGS] + SLICED + SUB8X8 + [REORDER])
 def test_two_references_hip_vs_oracle(lib, oracle, tmp_path, args):
     from p264decoder_amd import HipReconstructor
     from tests import oracle_bind

@@ -1,0 +1,40 @@
+"""CPU half of the seam fuzz: the random-picture builder (tests/seam_fuzz.py) produces well-formed p264hip_picture_t input -
+the oracle consumes it, the result is deterministic for a seed, and the packed coefficient stream is laid out as
+include/p264hip.h says.  (The comparison with the HIP kernels is tests/test_gpu_seam_fuzz.py.)"""
+import numpy as np
+
+from p264decoder_amd import _native as N
+from tests import oracle_bind, seam_fuzz
+
+
+def run(oracle, seed):
+    rng = np.random.default_rng(seed)
+    store = oracle_bind.FrameStore(7, 5, 3)
+    for s in range(3):
+        for dst, src in zip(store[s], seam_fuzz.random_frame(rng, 7, 5)):
+            dst[:] = src
+    out = []
+    for i in range(4):
+        pic = seam_fuzz.make_picture(rng, 7, 5, p_picture=(i != 1), n_ref=2, slots=3, dst_slot=i % 3, level_style="mixed", slices=2, with_quads=True)
+        rec = pic.rec
+        # coefficient stream: indices are consecutive, block counts match the masks
+        want_index = 0
+        for m in range(pic.n_mb):
+            assert rec["coef_index"][m] == want_index
+            mask = int(rec["coef_mask"][m])
+            want_index += bin(mask & 0x3ffffff).count("1")
+        assert want_index == pic.desc.n_coef_blocks and len(pic.coefs) >= 16 * want_index
+        inter = rec["mb_type"] > N.MB_IPCM
+        assert (pic.ref_idx.reshape(-1, 4)[~inter] == -1).all()
+        got = oracle_bind.reconstruct(oracle, store, pic)
+        out.append([p.copy() for p in got])
+    return out
+
+
+def test_builder_is_deterministic_and_wellformed(oracle):
+    a, b = run(oracle, 5), run(oracle, 5)
+    for x, y in zip(a, b):
+        for p, q in zip(x, y):
+            assert np.array_equal(p, q)
+    c = run(oracle, 6)
+    assert any(not np.array_equal(p, q) for x, y in zip(a, c) for p, q in zip(x, y))

@@ -10,69 +10,53 @@
 
 #define WAVE 64
 
-// One entry per picture of a batch; built on the host for every reconstruct call.
+// One entry per picture of a batch; built on the host for every reconstruct call.  Wave-uniform in every kernel
+// (a wavefront never mixes pictures), so the fields are fetched with scalar loads.
 struct PicDev {
     const p264hip_mb_t *mb;
     const int          *mv;        // packed (mvy << 16) | (mvx & 0xffff) per 4x4 block, [mb][16]
     const int8_t       *ref_idx;   // [mb][4]
     const uint8_t      *i4modes;   // [mb][16]
     const int16_t      *coefs;     // [blocks][16]
-    uint8_t            *dst;       // frame base (macroblock-tiled, see MB_TILE)
-    const uint8_t      *ref[P264HIP_MAX_REFS];
+    uint8_t            *dst;       // destination frame (strip layout, see below)
+    uint8_t            *store;     // the stream's frame store: slot 0; every reference and dst lie inside [store, store + store_bytes)
+    uint32_t           *mc;        // this picture's motion-compensation work lists (kernel_mc.h), written by k_mc_sort
+    uint32_t store_bytes, dst_off; // dst - store
     int32_t n_ref, slice_type, chroma_qp_offset, deblock, alpha_off, beta_off;
-    int32_t n_quads, pad;
-    const uint32_t     *quads;     // quadrant list (p264hip.h), n_quads entries incl. padding
+    uint32_t ref_off[P264HIP_MAX_REFS];   // reference frame k - store, list-0 order (entries >= n_ref repeat entry 0)
 };
-
-// The fields of a PicDev a kernel needs, fetched with TWO loads issued together (the descriptor address is
-// wave-uniform, so these are scalar loads).  Reading the fields one by one where they are used makes the compiler
-// emit a chain of dependent scalar loads - pointer, record, next pointer, ... - each a full round trip.
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-struct PicHead {
-    const p264hip_mb_t *mb; const int *mv; const int8_t *ref_idx; const uint8_t *i4modes; const int16_t *coefs;
-    uint8_t *dst; const uint8_t *ref0, *ref1;
-    int n_ref, slice_type, chroma_qp_offset, deblock;
-};
-__device__ __forceinline__ PicHead load_pic_head(const PicDev *pd)
-{
-    static_assert(offsetof(PicDev, ref) == 48 && offsetof(PicDev, n_ref) == 176 && offsetof(PicDev, quads) == 208 && sizeof(PicDev) == 216, "PicDev layout");
-    const u32x16 a = *(const u32x16 *)pd;
-    const u32x4v b = *(const u32x4v *)((const char *)pd + 176);
-    auto p64 = [&](int i) { return ((uint64_t)a[2 * i + 1] << 32) | a[2 * i]; };
-    PicHead h;
-    h.mb = (const p264hip_mb_t *)p64(0); h.mv = (const int *)p64(1); h.ref_idx = (const int8_t *)p64(2);
-    h.i4modes = (const uint8_t *)p64(3); h.coefs = (const int16_t *)p64(4); h.dst = (uint8_t *)p64(5);
-    h.ref0 = (const uint8_t *)p64(6); h.ref1 = (const uint8_t *)p64(7);
-    h.n_ref = (int)b[0]; h.slice_type = (int)b[1]; h.chroma_qp_offset = (int)b[2]; h.deblock = (int)b[3];
-    return h;
-}
 
 // Geometry shared by every picture of a context.
 struct Geom {
     int mb_w, mb_h, n_mb;
     int w, h, cw, ch;              // luma / chroma plane sizes in samples
+    uint32_t ystrip, cstrip, coff; // frame layout below: bytes per luma strip, per chroma strip, offset of the chroma part
 };
 
 // ---- frame layout in HBM -------------------------------------------------------------------
-// Frames are stored macroblock-tiled, not as planes: macroblock (mx,my) owns MB_TILE = 384 consecutive
-// bytes = three 128-byte cache lines: 16 luma rows x 16 bytes, then 8 U rows x 8 bytes, then 8 V rows
-// x 8 bytes.  Every kernel of the path touches whole macroblocks, so a wavefront's loads and stores
-// cover whole lines (a planar frame costs one line per 16-byte row piece and thrashes L1/L2: measured
-// 3-5x HBM write amplification in the row-wavefront kernels), and a motion-compensation window spans
-// 2x2..3x3 tiles instead of 21 row lines.  Planar views exist only at the host boundary
+// Frames are stored as vertical STRIPS, one macroblock wide, each strip contiguous from the top of the picture to the
+// bottom with a row pitch of 16 bytes:
+//   luma   sample (x,y)  at  (x >> 4) * ystrip + y * 16 + (x & 15)                      ystrip = 16 * h
+//   chroma sample (x,y)  at  coff + (x >> 3) * cstrip + y * 16 + plane * 8 + (x & 7)    cstrip = 16 * ch, coff = w * h
+// (a chroma row holds 8 bytes of U then 8 bytes of V).  A macroblock is still whole cache lines - 256 contiguous luma
+// bytes, 128 contiguous chroma bytes - which is what the two row-wavefront kernels need (a planar frame costs one line
+// per 16-byte row piece: measured 3-5x HBM write amplification), and consecutive ROWS of a motion-compensation window
+// are exactly 16 bytes apart wherever the window lies: its loads are one register offset per dword column plus an
+// immediate per row, no per-row address arithmetic (kernel_mc.h).  Planar views exist only at the host boundary
 // (p264hip_read_frame / p264hip_write_frame).
-#define MB_TILE    384
-#define MB_TILE_U  256
-#define MB_TILE_V  320
+#define MB_LUMA_BYTES   256
+#define MB_CHROMA_BYTES 128
 __device__ __forceinline__ uint32_t luma_off(const Geom &g, int x, int y)
 {
-    return (uint32_t)((y >> 4) * g.mb_w + (x >> 4)) * MB_TILE + (uint32_t)((y & 15) * 16 + (x & 15));
+    return (uint32_t)(x >> 4) * g.ystrip + (uint32_t)(y * 16 + (x & 15));
 }
 __device__ __forceinline__ uint32_t chroma_off(const Geom &g, int plane, int x, int y)
 {
-    return (uint32_t)((y >> 3) * g.mb_w + (x >> 3)) * MB_TILE + (uint32_t)(MB_TILE_U + plane * 64 + (y & 7) * 8 + (x & 7));
+    return g.coff + (uint32_t)(x >> 3) * g.cstrip + (uint32_t)(y * 16 + plane * 8 + (x & 7));
 }
+// first byte of a macroblock's luma / chroma part
+__device__ __forceinline__ uint32_t mb_luma_off(const Geom &g, int mbx, int mby) { return (uint32_t)mbx * g.ystrip + (uint32_t)mby * MB_LUMA_BYTES; }
+__device__ __forceinline__ uint32_t mb_chroma_off(const Geom &g, int mbx, int mby) { return g.coff + (uint32_t)mbx * g.cstrip + (uint32_t)mby * MB_CHROMA_BYTES; }
 
 // ---- global-memory accessors ------------------------------------------------------------
 // Pointers that reach a kernel through memory (the fields of PicDev) are "flat" to the compiler:
@@ -104,6 +88,8 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// v_perm_b32: result byte i = byte sel[i] of {hi (4..7), lo (0..3)}; 0x0c = zero
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- tables (H.264 standard data; the reference holds them at the cited places) --------

@@ -235,7 +235,6 @@ template <int K> __device__ __forceinline__ pk16 pair_byte(uint32_t a, uint32_t 
 {
     return as_pk(__builtin_amdgcn_perm(b, a, 0x0c040c00u + (uint32_t)K * 0x00010001u));
 }
-__device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 
 // ------------------------------------------------------------------------------------------
 // K4b
@@ -286,7 +285,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
     const PicDev *pd = pics + min(pic, n_pics - 1);
     const bool pic_ok = pi < pics_per_wg && pic < n_pics && pd->deblock;
     OctLds &L = lds[wave][o];
-    uint8_t *F = pd->dst;                                     // macroblock-tiled frame (device_common.h)
+    uint8_t *F = pd->dst;                                     // strip frame layout (device_common.h)
     const EdgeInfo *pinfo = info + (size_t)min(pic, n_pics - 1) * g.n_mb;
     const int seg = j >> 1, cseg = j & 3;                     // bS segment of this lane's luma / chroma lines
     const int cp = j >> 2, cr = (j & 3) * 2;                  // chroma plane, first chroma line of this lane
@@ -302,13 +301,16 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         const bool top_exists = row > 0;
         const bool from_above = have_row && gr == 0 && band > 0;   // the rows above come from the band above, through memory
         const int rowc = min(row, g.mb_h - 1);
-        // Tiled frame: macroblock x of this row is the 384 bytes at rowT + x*384.  This lane's two luma rows are the 32
-        // bytes at +32j, its two chroma rows the 16 bytes at +256+16j: an octet reads and writes whole cache lines.
-        uint8_t *rowT = F + (size_t)rowc * g.mb_w * MB_TILE;
-        uint8_t *ownY = rowT + j * 32, *ownC = rowT + MB_TILE_U + j * 16;
+        // Strip layout: macroblock x of this row owns the 256 luma bytes at x*ystrip + row*256 and the 128 chroma bytes at
+        // coff + x*cstrip + row*128 (rows of 8 bytes U, 8 bytes V).  This lane's two luma rows are the 32 bytes at +32j, its
+        // two chroma rows 8 bytes each: an octet reads and writes whole cache lines.
+        const uint32_t sY = g.ystrip, sC = g.cstrip;
+        uint8_t *ownY = F + (size_t)rowc * MB_LUMA_BYTES + j * 32, *ownC = F + g.coff + (size_t)rowc * MB_CHROMA_BYTES + cr * 16 + cp * 8;
         // the rows above (valid if top_exists): lanes 0..3 luma rows 12..15 of the macroblock above, lanes 4..7 its chroma
         // rows 6,7 of plane (j>>1)&1
-        uint8_t *topP = rowT - (ptrdiff_t)g.mb_w * MB_TILE + (j < 4 ? 192 + j * 16 : MB_TILE_U + ((j >> 1) & 1) * 64 + 48 + (j & 1) * 8);
+        const uint32_t sT = j < 4 ? sY : sC;
+        uint8_t *topP = j < 4 ? F + (ptrdiff_t)(rowc - 1) * MB_LUMA_BYTES + 192 + j * 16
+                              : F + g.coff + (ptrdiff_t)(rowc - 1) * MB_CHROMA_BYTES + (6 + (j & 1)) * 16 + ((j >> 1) & 1) * 8;
         int *my_progress = &progress[pi & (MAX_PICS_PER_WG - 1)][band];
         const bool publisher = have_row && gr == last && j == 0;
         OctLds &Lnext = lds[wave][min(o + 1, 7)];
@@ -338,11 +340,11 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             if (actn) {
                 if (j < 4) fE = gload4((const uint4 *)(pinfo + row * g.mb_w + x) + j);
                 if (from_above) {
-                    if (j < 4) fT = gload4(topP + x * MB_TILE);
-                    else { uint2 v2 = gload2(topP + x * MB_TILE); fT.x = v2.x; fT.y = v2.y; }
+                    if (j < 4) fT = gload4(topP + x * sT);
+                    else { uint2 v2 = gload2(topP + x * sT); fT.x = v2.x; fT.y = v2.y; }
                 }
-                fYa = gload4(ownY + x * MB_TILE); fYb = gload4(ownY + x * MB_TILE + 16);
-                fC = gload4(ownC + x * MB_TILE);
+                fYa = gload4(ownY + x * sY); fYb = gload4(ownY + x * sY + 16);
+                { const uint2 ca2 = gload2(ownC + x * sC), cb2 = gload2(ownC + x * sC + 16); fC = make_uint4(ca2.x, ca2.y, cb2.x, cb2.y); }
             }
         };
 
@@ -370,8 +372,8 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
             if (flush && top_exists && !EXPD_NOSTORE) {
                 const uint32_t *pr = L.ring[(x - 1) & 3];
-                if (j < 4) gstore4(topP + (x - 1) * MB_TILE, *(const uint4 *)(pr + j * 4));
-                else gstore2(topP + (x - 1) * MB_TILE, *(const uint2 *)(pr + 16 + (j - 4) * 2));
+                if (j < 4) gstore4(topP + (x - 1) * sT, *(const uint4 *)(pr + j * 4));
+                else gstore2(topP + (x - 1) * sT, *(const uint2 *)(pr + 16 + (j - 4) * 2));
             }
             EdgeRegs E;
             {
@@ -429,9 +431,9 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 sa.w = ya[0]; sb.w = yb[0]; ta.y = ca[0]; tb.y = cb[0];
                 uint32_t *nr = Lnext.ring[(x - 1) & 3];
                 if (below_in_band && j >= 6) { *(uint4 *)(nr + (2 * j - 12) * 4) = sa; *(uint4 *)(nr + (2 * j - 11) * 4) = sb; }
-                else if (!EXPD_NOSTORE) { gstore4(ownY + (x - 1) * MB_TILE, sa); gstore4(ownY + (x - 1) * MB_TILE + 16, sb); }
+                else if (!EXPD_NOSTORE) { gstore4(ownY + (x - 1) * sY, sa); gstore4(ownY + (x - 1) * sY + 16, sb); }
                 if (below_in_band && (j & 3) == 3) { *(uint2 *)(nr + 16 + cp * 4) = ta; *(uint2 *)(nr + 16 + cp * 4 + 2) = tb; }
-                else if (!EXPD_NOSTORE) gstore4(ownC + (x - 1) * MB_TILE, make_uint4(ta.x, ta.y, tb.x, tb.y));
+                else if (!EXPD_NOSTORE) { gstore2(ownC + (x - 1) * sC, ta); gstore2(ownC + (x - 1) * sC + 16, tb); }
             }
             wave_lds_fence();
             // ---------- rows of macroblock x -> tile ----------

@@ -8,7 +8,7 @@
 // Intra prediction reads the UNFILTERED reconstruction of the left / top / top-left / top-right
 // neighbours, so macroblocks form a 2-MB-lag wavefront over the picture (wavefront_sync.h): one
 // workgroup per picture, one wavefront per macroblock row.  In P pictures the inter MBs were
-// already written by k_inter, so only the sparse intra MBs are visited.  Missing neighbours are
+// already written by k_mc_luma / k_mc_chroma, so only the sparse intra MBs are visited.  Missing neighbours are
 // substituted in registers (128 / replicated t3) instead of being written into the frame as the
 // reference does (decoder/macroblock.c:697-713, SURVEY A-Q7).
 #pragma once
@@ -61,7 +61,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w, X0 = mbx * 16, Y0 = mby * 16;
     const bool aL = m.avail & P264_AVAIL_LEFT, aT = m.avail & P264_AVAIL_TOP;
     const bool aTR = m.avail & P264_AVAIL_TOPRIGHT, aTL = m.avail & P264_AVAIL_TOPLEFT;
-    uint8_t *F = pd->dst;                                  // macroblock-tiled frame (device_common.h)
+    uint8_t *F = pd->dst;                                  // strip frame layout (device_common.h)
     const AS1 uint8_t *Fg = glob(F);
     const unsigned mask = m.coef_mask;
     const AS1 int16_t *cf = glob(pd->coefs) + (size_t)m.coef_index * 16;
@@ -280,7 +280,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
                 else if (mode == 5) v = ((qd & 1) ? s1 + 2 : s0 + 2) >> 2;
                 else v = 128;
             }
-            if (has_chroma) {                                                     // residual, as in k_inter
+            if (has_chroma) {                                                     // residual, same arithmetic as kernel_mc.h
                 // the four DC levels of plane p sit in lanes 4p .. 4p+3 (all shuffles before any use)
                 const int d0 = __shfl(cdcv, p * 4), d1 = __shfl(cdcv, p * 4 + 1), d2 = __shfl(cdcv, p * 4 + 2), d3 = __shfl(cdcv, p * 4 + 3);
                 int cv;
@@ -308,11 +308,12 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     // ---- write the macroblock out ----
     {
         int row = lane >> 2, d = lane & 3;
-        uint8_t *tile = F + (size_t)mbi * MB_TILE;             // lane (row, d) owns luma dword lane, (p, r, dd) chroma dword lane
-        gstore1(tile + lane * 4, *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4));
+        // lane (row, d) owns dword `lane` of the macroblock's 256 contiguous luma bytes, lane (p, r, dd) a dword of its
+        // 128 chroma bytes (rows of 8 bytes U + 8 bytes V)
+        gstore1(F + mb_luma_off(g, mbx, mby) + lane * 4, *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4));
         if (lane < 32) {
             int p = lane >> 4, r = (lane >> 1) & 7, dd = lane & 1;
-            gstore1(tile + MB_TILE_U + lane * 4, *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4));
+            gstore1(F + mb_chroma_off(g, mbx, mby) + r * 16 + p * 8 + dd * 4, *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4));
         }
     }
 }
@@ -336,7 +337,7 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
     for (int row = wave; row < g.mb_h; row += n_waves) {
         for (int base = 0; base < g.mb_w; base += 64) {
             // which of the next 64 macroblocks of this row are intra, and which of them touch an intra macroblock of
-            // the row above?  Only those can still be in flight there (inter MBs were finished by k_inter), so the
+            // the row above?  Only those can still be in flight there (inter MBs were finished by the motion-compensation kernels), so the
             // wavefront dependency only bites where intra macroblocks touch.  One batch of loads per 64 macroblocks.
             const int x = base + lane;
             const AS1 p264hip_mb_t *recs = glob(pd->mb) + row * g.mb_w;

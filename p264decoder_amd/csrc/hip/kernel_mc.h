@@ -1,0 +1,679 @@
+// kernel_mc.h - K1: inter prediction + residual for every non-intra macroblock of a batch.
+//
+// Replaces p264_mb_mc / p264_mb_mc_0xywh (core/macroblock.c:506-524,633-676), mc_luma / pixel_avg / mc_copy
+// (core/mc.c:58-74,160-171,237-266), the half-pel plane generator p264_frame_filter (core/mc.c:172-235,409-451 -
+// computed on the fly here, never stored), motion_compensation_chroma (core/mc.c:303-334), p264_macroblock_decode_skip
+// (decoder/macroblock.c:895-934), the border expansion (core/frame.c:183-222 - clamped coordinates instead, SURVEY A-Q9)
+// and the inter half of p264_macroblock_decode (decoder/macroblock.c:832-890: unscan, dequant_4x4, add4x4_idct, chroma DC).
+//
+// The first version of this stage (one wavefront per macroblock, LDS-staged windows) was bound by scalar and vector
+// instruction issue: per-macroblock header work in SGPRs, one interpolation pass per distinct vector, a shared inverse
+// transform with LDS round trips.  This version is built on three ideas:
+//
+//  1. ONE LANE = ONE 4x4 BLOCK.  The lane fetches its own 9x9 (or smaller) reference window straight into registers with
+//     dword loads (strip frame layout, device_common.h: one register offset per dword column, rows as immediates),
+//     interpolates its 16 samples, runs the whole inverse transform of its block in registers (no LDS anywhere in these
+//     kernels, nothing is shared between lanes) and stores four dwords.  Every partition shape down to 4x4 is the same
+//     code: a lane only ever looks at its own vector.  All per-macroblock header work is vector work shared by 64 blocks.
+//  2. WORK LISTS SORTED BY WHAT THE CODE HAS TO DO.  The quarter-pel phase decides the arithmetic (copy / horizontal /
+//     vertical / both / centre ...), so k_mc_sort (one workgroup per picture, a counting sort in LDS) hands the 8x8
+//     quadrants of all inter macroblocks over grouped by {phase class, window inside the picture or not, residual
+//     present or not} (and by band of macroblock rows, for cache locality).  A wavefront takes 16 quadrants of ONE key:
+//     the class is a scalar, the switch on it is free, nobody executes code it does not need - a P_SKIP macroblock at an
+//     integer position costs a few loads and stores, windows inside the picture need no clamping, wavefronts without
+//     coded blocks skip the transform.  Sorting on the device keeps the host parser and the CPU->GPU seam unchanged.
+//  3. Chroma (4x4 per quadrant and plane, bilinear) has no phase classes; it is its own kernel over its own list
+//     (inside / clamped, residual or not), 32 quadrants x 2 planes per wavefront.
+//
+// Arithmetic to preserve: core/mc.c:172-266 (half-pel planes, quarter-pel averages), :303-334 (chroma),
+// core/quant.c:66-99,138-159, core/dct.c:55-68,205-247 with their int16 stores (A-Q8).
+#pragma once
+#include "device_common.h"
+
+// ------------------------------------------------------------------------------------------
+// work lists
+// ------------------------------------------------------------------------------------------
+enum { PC_COPY = 0, PC_H = 1, PC_V = 2, PC_DIAG = 3, PC_C = 4, PC_CH = 5, PC_CV = 6, PC_GEN = 7 };
+#define MCY_CLAMP   8               // luma key bits: phase class | window not provably inside the picture | quadrant has coded luma blocks
+#define MCY_RESID   16
+#define MCY_KEYS    32
+#define MCC_SLOW    1               // chroma key bits: clamped window or vectors differing inside the quadrant | macroblock has chroma residual
+#define MCC_RESID   2
+#define MCC_KEYS    4
+#define MCY_CHUNK   16              // quadrants per luma wavefront (4 lanes each)
+#define MCC_CHUNK   32              // quadrants per chroma wavefront (2 lanes each: the planes)
+#define MC_MAX_BANDS 32
+#define MC_SORT_THREADS 1024
+
+// Per-picture scratch written by k_mc_sort (32-bit words): [0] luma chunks, [1] chroma chunks, then one class byte per
+// chunk, then the lists (entry = macroblock index << 2 | quadrant, 0xffffffff = padding).  Same for every picture of a batch.
+struct McLayout {
+    uint32_t band_log2, n_bands;
+    uint32_t max_chunks_y, max_chunks_c;
+    uint32_t off_cls_y, off_cls_c, off_list_y, off_list_c, words;
+};
+static inline McLayout mc_layout(int mb_w, int mb_h, int band_log2)
+{
+    McLayout L;
+    L.band_log2 = (uint32_t)band_log2;
+    L.n_bands = (uint32_t)((mb_h + (1 << band_log2) - 1) >> band_log2);
+    const uint32_t items = (uint32_t)(mb_w * mb_h) * 4u;
+    L.max_chunks_y = (items + L.n_bands * MCY_KEYS * (MCY_CHUNK - 1)) / MCY_CHUNK + 1;
+    L.max_chunks_c = (items + L.n_bands * MCC_KEYS * (MCC_CHUNK - 1)) / MCC_CHUNK + 1;
+    L.off_cls_y = 16;
+    L.off_cls_c = L.off_cls_y + (L.max_chunks_y + 3) / 4;
+    L.off_list_y = (L.off_cls_c + (L.max_chunks_c + 3) / 4 + 15) & ~15u;
+    L.off_list_c = L.off_list_y + L.max_chunks_y * MCY_CHUNK;
+    L.words = (L.off_list_c + L.max_chunks_c * MCC_CHUNK + 63) & ~63u;
+    return L;
+}
+
+__device__ __forceinline__ int mv_x(int packed) { return (int)(int16_t)(packed & 0xffff); }
+__device__ __forceinline__ int mv_y(int packed) { return packed >> 16; }
+
+// phase class of a quarter-pel vector (which of the reference's planes core/mc.c:244-257 combines)
+__device__ __forceinline__ int phase_class(int fx, int fy)
+{
+    if ((fx | fy) == 0) return PC_COPY;
+    if (fy == 0) return PC_H;
+    if (fx == 0) return PC_V;
+    if (fx & fy & 1) return PC_DIAG;
+    if (fx == 2) return fy == 2 ? PC_C : PC_CH;
+    return PC_CV;
+}
+
+struct McKeys { int ky, kc; };       // -1: nothing to do (intra macroblock)
+__device__ __forceinline__ McKeys mc_classify(const PicDev *pd, const Geom &g, uint32_t item, uint32_t inv_mbw, int band_log2)
+{
+    const int mbi = (int)(item >> 2), q = (int)(item & 3);
+    const uint4 rec = gload4(pd->mb + mbi);
+    McKeys k = { -1, -1 };
+    if (P264_MB_IS_INTRA(rec.x & 255)) return k;
+    const int b0 = (q >> 1) * 8 + (q & 1) * 2;
+    const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
+    const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
+    int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+    const int mbx = mbi - mby * g.mb_w;
+    const int X0 = mbx * 16 + (q & 1) * 8, Y0 = mby * 16 + (q >> 1) * 8;
+    const int mvx = mv_x((int)va.x), mvy = mv_y((int)va.x);
+    // luma: the four lanes of the quadrant read dwords inside [wx & ~3, wx + 16) x [wy, wy + 13)
+    const int wx = X0 + (mvx >> 2) - 2, wy = Y0 + (mvy >> 2) - 2;
+    const bool in_y = wx >= 0 && wx <= g.w - 16 && wy >= 0 && wy <= g.h - 13;
+    const int cx = X0 / 2 + (mvx >> 3), cy = Y0 / 2 + (mvy >> 3);
+    const bool in_c = cx >= 0 && cx <= g.cw - 8 && cy >= 0 && cy <= g.ch - 5;
+    const int band = mby >> band_log2;
+    const unsigned mask = rec.y, cbp = (rec.x >> 16) & 255;
+    int pc = phase_class(mvx & 3, mvy & 3), fl = in_y ? 0 : MCY_CLAMP;
+    if (!uniform) { pc = PC_GEN; fl = MCY_CLAMP; }
+    if ((mask >> (4 * q)) & 15) fl |= MCY_RESID;
+    k.ky = band * MCY_KEYS + (pc | fl);
+    k.kc = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_SLOW) + ((cbp >> 4) ? MCC_RESID : 0);
+    return k;
+}
+
+// One workgroup per picture: count the keys, lay the key segments out (each padded to whole chunks), scatter the items.
+__global__ __launch_bounds__(MC_SORT_THREADS)
+void k_mc_sort(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t inv_mbw)
+{
+    __shared__ uint32_t cnt_y[MC_MAX_BANDS * MCY_KEYS], cnt_c[MC_MAX_BANDS * MCC_KEYS];
+    __shared__ uint32_t pos_y[MC_MAX_BANDS * MCY_KEYS], pos_c[MC_MAX_BANDS * MCC_KEYS];
+    const PicDev *pd = pics + blockIdx.x;
+    uint32_t *out = pd->mc;
+    const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
+    const int tid = threadIdx.x;
+    if (pd->slice_type != P264_SLICE_P) {                 // wave-uniform
+        if (tid == 0) { gstore1(out, 0); gstore1(out + 1, 0); }
+        return;
+    }
+    for (int k = tid; k < nky; k += MC_SORT_THREADS) cnt_y[k] = 0;
+    for (int k = tid; k < nkc; k += MC_SORT_THREADS) cnt_c[k] = 0;
+    __syncthreads();
+    const uint32_t n_items = (uint32_t)g.n_mb * 4u;
+    for (uint32_t it = tid; it < n_items; it += MC_SORT_THREADS) {
+        const McKeys k = mc_classify(pd, g, it, inv_mbw, (int)ml.band_log2);
+        if (k.ky >= 0) { atomicAdd(&cnt_y[k.ky], 1u); atomicAdd(&cnt_c[k.kc], 1u); }
+    }
+    __syncthreads();
+    // segment starts: every thread sums the padded counts in front of its key (a few hundred LDS reads at most), notes the
+    // key's class bits for each of its chunks, and the thread of the last key writes the number of chunks in use
+    for (int k = tid; k < nky + nkc; k += MC_SORT_THREADS) {
+        const bool is_y = k < nky;
+        const int kk = is_y ? k : k - nky, nk = is_y ? nky : nkc;
+        const uint32_t *cnt = is_y ? cnt_y : cnt_c;
+        const uint32_t chunk = is_y ? MCY_CHUNK : MCC_CHUNK;
+        uint32_t start = 0;
+        for (int j = 0; j < kk; j++) start += (cnt[j] + chunk - 1) / chunk;
+        const uint32_t n = (cnt[kk] + chunk - 1) / chunk;                       // chunks of this key, from chunk `start`
+        (is_y ? pos_y : pos_c)[kk] = start * chunk;
+        AS1 uint8_t *cls = glob((uint8_t *)(out + (is_y ? ml.off_cls_y : ml.off_cls_c)));
+        const uint8_t v = (uint8_t)(kk % (is_y ? MCY_KEYS : MCC_KEYS));
+        for (uint32_t c = 0; c < n; c++) cls[start + c] = v;
+        if (kk == nk - 1) gstore1(out + (is_y ? 0 : 1), start + n);
+    }
+    __syncthreads();
+    uint32_t *list_y = out + ml.off_list_y, *list_c = out + ml.off_list_c;
+    for (uint32_t it = tid; it < n_items; it += MC_SORT_THREADS) {
+        const McKeys k = mc_classify(pd, g, it, inv_mbw, (int)ml.band_log2);
+        if (k.ky >= 0) {
+            gstore1(list_y + atomicAdd(&pos_y[k.ky], 1u), it);
+            gstore1(list_c + atomicAdd(&pos_c[k.kc], 1u), it);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < nky + nkc; k += MC_SORT_THREADS) {      // padding entries behind every segment
+        const bool is_y = k < nky;
+        const int kk = is_y ? k : k - nky;
+        const uint32_t chunk = is_y ? MCY_CHUNK : MCC_CHUNK;
+        const uint32_t end = (is_y ? pos_y : pos_c)[kk];
+        uint32_t *list = is_y ? list_y : list_c;
+        for (uint32_t p = end; p < (end + chunk - 1) / chunk * chunk; p++) gstore1(list + p, 0xffffffffu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// byte-parallel (a + b + 1) >> 1 (pixel_avg, core/mc.c:58-74)
+__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) & 0xfefefefeu) >> 1); }
+// hipcc (ROCm 7.2) fuses "arithmetic shift right -> clamp to 0..255 -> pack two bytes" into gfx950's v_ashr_pk_u8_i32 and
+// then ORs further bytes into the upper half of its result, which the hardware does not leave zero (measured: wrong upper
+// bytes).  An empty asm on the shifted value keeps the shift and the clamp apart; it emits no instruction.
+__device__ __forceinline__ int no_fuse(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
+__device__ __forceinline__ uint32_t sel32(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t bload(rsrc_t r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
+__device__ __forceinline__ void bstore(rsrc_t r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)off, 0, 0); }
+
+// ------------------------------------------------------------------------------------------
+// reference windows in registers
+// ------------------------------------------------------------------------------------------
+// d[r][k] = the aligned dword k of window row r.  The window starts at sample (xw, yw); xa = xw & ~3 is the first dword.
+// Rows R0 .. R0+NR-1 and NC dword columns are fetched.  Inside the picture a load is `column register + 16 * row` (the
+// compiler folds the row into the instruction's immediate offset).  CLAMP: coordinates clamped to the picture = the
+// reference's replicated borders (core/frame.c:183-222, A-Q9); a dword is either entirely inside or entirely outside
+// (plane widths are multiples of 8), outside it becomes the replicated edge byte.
+template <int R0, int NR, int NC, bool CLAMP>
+__device__ __forceinline__ void load_luma(uint32_t (&d)[9][3], rsrc_t rs, uint32_t roff, const Geom &g, int xw, int yw)
+{
+    const int xa = xw & ~3;
+    if (!CLAMP) {
+        uint32_t col[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { const int x = xa + 4 * k; col[k] = roff + (uint32_t)(x >> 4) * g.ystrip + (uint32_t)(yw * 16 + (x & 15)); }
+#pragma unroll
+        for (int r = R0; r < R0 + NR; r++)
+#pragma unroll
+            for (int k = 0; k < NC; k++) d[r][k] = bload(rs, col[k] + (uint32_t)(r * 16));
+    } else {
+        uint32_t col[NC], sel[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const int x = xa + 4 * k, xc = clip3i(x, 0, g.w - 4);
+            col[k] = roff + (uint32_t)(xc >> 4) * g.ystrip + (uint32_t)(xc & 15);
+            sel[k] = x < 0 ? 0x00000000u : x >= g.w ? 0x03030303u : 0x03020100u;
+        }
+#pragma unroll
+        for (int r = R0; r < R0 + NR; r++) {
+            const uint32_t ro = (uint32_t)clip3i(yw + r, 0, g.h - 1) * 16u;
+#pragma unroll
+            for (int k = 0; k < NC; k++) { const uint32_t v = bload(rs, col[k] + ro); d[r][k] = perm(v, v, sel[k]); }
+        }
+    }
+}
+
+// horizontal 6-tap sums (core/mc.c:53-56) for 4 adjacent samples; n0..n2 hold window bytes 0..11, output sample i uses
+// bytes i..i+5.  Samples are taken as (s - 128) in int8: the taps sum to 32, so the true sum is the dot product + 4096;
+// `bias` = 4096 + rounding term.
+__device__ __forceinline__ void tap_h4(uint32_t n0, uint32_t n1, uint32_t n2, int bias, int t[4])
+{
+    const int C0 = 0x1414fb01, C1 = 0x000001fb;            // (1,-5,20,20) and (-5,1,0,0) as int8
+    n0 ^= 0x80808080u; n1 ^= 0x80808080u; n2 ^= 0x80808080u;
+    t[0] = __builtin_amdgcn_sdot4((int)n0, C0, __builtin_amdgcn_sdot4((int)n1, C1, bias, false), false);
+    t[1] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 1), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 1), C1, bias, false), false);
+    t[2] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 2), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 2), C1, bias, false), false);
+    t[3] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 3), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 3), C1, bias, false), false);
+}
+// (t >> sh) clipped to a byte, four at once
+template <int SH> __device__ __forceinline__ uint32_t round_pack4(const int t[4])
+{
+    return pack4(clip255(no_fuse(t[0] >> SH)), clip255(no_fuse(t[1] >> SH)), clip255(no_fuse(t[2] >> SH)), clip255(no_fuse(t[3] >> SH)));
+}
+// window bytes 0..11 of a row, the window starting at byte s of dword 0
+__device__ __forceinline__ void align_row(const uint32_t (&w)[3], uint32_t s, uint32_t &n0, uint32_t &n1, uint32_t &n2)
+{
+    n0 = alignbyte(w[1], w[0], s); n1 = alignbyte(w[2], w[1], s); n2 = w[2] >> (8 * s);
+}
+// vertical 6-tap of four columns over six rows of samples (mc_hv, core/mc.c:186-199), packed 16-bit
+__device__ __forceinline__ uint32_t tap_v4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4, uint32_t r5)
+{
+    const uint32_t M = 0x00ff00ffu;
+    const s16x2 c20 = { 20, 20 }, c5 = { 5, 5 }, c16 = { 16, 16 }, z = { 0, 0 }, m = { 255, 255 };
+    s16x2 a = (as_s16x2(r0 & M) + as_s16x2(r5 & M)) + c20 * (as_s16x2(r2 & M) + as_s16x2(r3 & M)) - c5 * (as_s16x2(r1 & M) + as_s16x2(r4 & M));
+    s16x2 b = (as_s16x2((r0 >> 8) & M) + as_s16x2((r5 >> 8) & M)) + c20 * (as_s16x2((r2 >> 8) & M) + as_s16x2((r3 >> 8) & M))
+              - c5 * (as_s16x2((r1 >> 8) & M) + as_s16x2((r4 >> 8) & M));
+    a = (a + c16) >> 5; b = (b + c16) >> 5;
+    a = __builtin_elementwise_min(__builtin_elementwise_max(a, z), m);
+    b = __builtin_elementwise_min(__builtin_elementwise_max(b, z), m);
+    return as_u32(a) | (as_u32(b) << 8);
+}
+
+// ---- the seven phase classes: out[y] = the four samples of row y of the lane's 4x4 block -----------------------------
+// (ix, iy) = integer position of the block's first sample in the reference, (fx, fy) = quarter-pel phase.
+template <bool CLAMP> __device__ __forceinline__ void mc_copy(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy)
+{
+    uint32_t d[9][3];
+    load_luma<0, 4, 2, CLAMP>(d, rs, roff, g, ix, iy);
+    const uint32_t s = (uint32_t)ix & 3u;
+#pragma unroll
+    for (int y = 0; y < 4; y++) out[y] = alignbyte(d[y][1], d[y][0], s);
+}
+template <bool CLAMP> __device__ __forceinline__ void mc_h(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx)
+{   // fx = 1: avg(G, h), 2: h, 3: avg(h, G one to the right)
+    uint32_t d[9][3];
+    load_luma<0, 4, 3, CLAMP>(d, rs, roff, g, ix - 2, iy);
+    const uint32_t s = (uint32_t)(ix - 2) & 3u, gs = 2u + (uint32_t)(fx == 3);
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t n0, n1, n2; int t[4];
+        align_row(d[y], s, n0, n1, n2);
+        tap_h4(n0, n1, n2, 4096 + 16, t);
+        const uint32_t hh = round_pack4<5>(t);
+        out[y] = sel32(fx == 2, hh, avg4(hh, alignbyte(n1, n0, gs)));
+    }
+}
+template <bool CLAMP> __device__ __forceinline__ void mc_v(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fy)
+{   // fy = 1: avg(v, G), 2: v, 3: avg(G one down, v)
+    uint32_t d[9][3], c[9];
+    load_luma<0, 9, 2, CLAMP>(d, rs, roff, g, ix, iy - 2);
+    const uint32_t s = (uint32_t)ix & 3u;
+#pragma unroll
+    for (int r = 0; r < 9; r++) c[r] = alignbyte(d[r][1], d[r][0], s);
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const uint32_t vv = tap_v4(c[y], c[y + 1], c[y + 2], c[y + 3], c[y + 4], c[y + 5]);
+        out[y] = sel32(fy == 2, vv, avg4(vv, sel32(fy == 3, c[y + 3], c[y + 2])));
+    }
+}
+template <bool CLAMP> __device__ __forceinline__ void mc_diag(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx, int fy)
+{   // avg(h of row y + (fy == 3), v of column x + (fx == 3))
+    uint32_t d[9][3], n0[9], n1[9], c[9];
+    load_luma<0, 9, 3, CLAMP>(d, rs, roff, g, ix - 2, iy - 2);
+    const uint32_t s = (uint32_t)(ix - 2) & 3u, vs = 2u + (uint32_t)(fx == 3);
+#pragma unroll
+    for (int r = 0; r < 9; r++) { n0[r] = alignbyte(d[r][1], d[r][0], s); n1[r] = alignbyte(d[r][2], d[r][1], s); c[r] = alignbyte(n1[r], n0[r], vs); }
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const bool dn = fy == 3;
+        const uint32_t h0 = sel32(dn, n0[y + 3], n0[y + 2]), h1 = sel32(dn, n1[y + 3], n1[y + 2]);
+        const uint32_t h2 = sel32(dn, d[y + 3][2], d[y + 2][2]) >> (8 * s);
+        int t[4];
+        tap_h4(h0, h1, h2, 4096 + 16, t);
+        out[y] = avg4(round_pack4<5>(t), tap_v4(c[y], c[y + 1], c[y + 2], c[y + 3], c[y + 4], c[y + 5]));
+    }
+}
+// centre position (mc_hc, core/mc.c:200-235): horizontal sums of nine rows, unrounded, then the vertical filter on them,
+// (sum + 512) >> 10.  Each row's sum carries + 16, which the vertical taps (sum 32) turn into the + 512 - and which is
+// also the rounding term of the horizontal half-pel sample of that row.  WITH: 0 centre only, 1 avg with h of row
+// y + (fy == 3), 2 avg with v of column x + (fx == 3).
+template <bool CLAMP, int WITH> __device__ __forceinline__ void mc_centre(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx, int fy)
+{
+    uint32_t d[9][3];
+    load_luma<0, 9, 3, CLAMP>(d, rs, roff, g, ix - 2, iy - 2);
+    const uint32_t s = (uint32_t)(ix - 2) & 3u;
+    int t[9][4];
+    uint32_t c[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        uint32_t n0, n1, n2;
+        align_row(d[r], s, n0, n1, n2);
+        tap_h4(n0, n1, n2, 4096 + 16, t[r]);
+        if (WITH == 2) c[r] = alignbyte(n1, n0, 2u + (uint32_t)(fx == 3));
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        int a[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            a[x] = (t[y][x] + t[y + 5][x]) + 20 * (t[y + 2][x] + t[y + 3][x]) - 5 * (t[y + 1][x] + t[y + 4][x]);
+        const uint32_t cc = round_pack4<10>(a);
+        if (WITH == 0) out[y] = cc;
+        else if (WITH == 1) {
+            int hsel[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) hsel[x] = fy == 3 ? t[y + 3][x] : t[y + 2][x];
+            out[y] = avg4(cc, round_pack4<5>(hsel));
+        } else out[y] = avg4(cc, tap_v4(c[y], c[y + 1], c[y + 2], c[y + 3], c[y + 4], c[y + 5]));
+    }
+}
+
+template <bool CLAMP> __device__ __forceinline__ void mc_luma_class(int pc, uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx, int fy)
+{
+    switch (pc) {                                          // wave-uniform
+    case PC_COPY: mc_copy<CLAMP>(out, rs, roff, g, ix, iy); break;
+    case PC_H:    mc_h<CLAMP>(out, rs, roff, g, ix, iy, fx); break;
+    case PC_V:    mc_v<CLAMP>(out, rs, roff, g, ix, iy, fy); break;
+    case PC_DIAG: mc_diag<CLAMP>(out, rs, roff, g, ix, iy, fx, fy); break;
+    case PC_C:    mc_centre<CLAMP, 0>(out, rs, roff, g, ix, iy, fx, fy); break;
+    case PC_CH:   mc_centre<CLAMP, 1>(out, rs, roff, g, ix, iy, fx, fy); break;
+    default:      mc_centre<CLAMP, 2>(out, rs, roff, g, ix, iy, fx, fy); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// residual of one 4x4 block, entirely in the lane's registers
+// ------------------------------------------------------------------------------------------
+// dequantisation scale of a position class (core/set.c:27-35, without the factor 16 the reference folds in)
+__device__ __forceinline__ uint32_t dq_s(int cls, int rem)
+{
+    const uint32_t k = cls == 0 ? (10u | 11u << 5 | 13u << 10 | 14u << 15 | 16u << 20 | 18u << 25)
+                     : cls == 1 ? (13u | 14u << 5 | 16u << 10 | 18u << 15 | 20u << 20 | 23u << 25)
+                                : (16u | 18u << 5 | 20u << 10 | 23u << 15 | 25u << 20 | 29u << 25);
+    return (k >> (5 * rem)) & 31u;
+}
+// half `ha` of word pa into the low half, half `hb` of word pb into the high half
+template <int HA, int HB> __device__ __forceinline__ uint32_t pick2(uint32_t pa, uint32_t pb)
+{
+    return perm(pb, pa, (uint32_t)(2 * HA) | (uint32_t)(2 * HA + 1) << 8 | (uint32_t)(4 + 2 * HB) << 16 | (uint32_t)(5 + 2 * HB) << 24);
+}
+// Levels in scan order, two per word (lv[j] = levels 2j, 2j+1) -> the block in COLUMNS: col[x][0] = (d[0][x], d[1][x]),
+// col[x][1] = (d[2][x], d[3][x]) (zig-zag, decoder/macroblock.c:602-603).  AC: the 15 levels sit at scan positions 1..15
+// (level k-1 at position k); position 0 is filled by the caller.
+template <bool AC> __device__ __forceinline__ void unscan_cols(const uint32_t (&lv)[8], uint32_t (&col)[4][2])
+{
+    // scan index of raster position (y,x): 0 1 5 6 / 2 4 7 12 / 3 8 11 13 / 9 10 14 15
+    if (!AC) {
+        col[0][0] = pick2<0, 0>(lv[0], lv[1]);  col[0][1] = pick2<1, 1>(lv[1], lv[4]);      // s0 s2 | s3 s9
+        col[1][0] = pick2<1, 0>(lv[0], lv[2]);  col[1][1] = pick2<0, 0>(lv[4], lv[5]);      // s1 s4 | s8 s10
+        col[2][0] = pick2<1, 1>(lv[2], lv[3]);  col[2][1] = pick2<1, 0>(lv[5], lv[7]);      // s5 s7 | s11 s14
+        col[3][0] = pick2<0, 0>(lv[3], lv[6]);  col[3][1] = pick2<1, 1>(lv[6], lv[7]);      // s6 s12 | s13 s15
+    } else {   // level index = scan index - 1
+        col[0][0] = lv[0] & 0xffff0000u;        col[0][1] = pick2<0, 0>(lv[1], lv[4]);      // -  l1 | l2 l8
+        col[1][0] = pick2<0, 1>(lv[0], lv[1]);  col[1][1] = pick2<1, 1>(lv[3], lv[4]);      // l0 l3 | l7 l9
+        col[2][0] = pick2<0, 0>(lv[2], lv[3]);  col[2][1] = pick2<0, 1>(lv[5], lv[6]);      // l4 l6 | l10 l13
+        col[3][0] = pick2<1, 1>(lv[2], lv[5]);  col[3][1] = pick2<0, 0>(lv[6], lv[7]);      // l5 l11 | l12 l14
+    }
+}
+// dequant_4x4 (core/quant.c:66-99) on the column form.  For every QP the reference's value is level * (scale << qp/6)
+// truncated to int16: below QP 24 its rounding shift divides a multiple of 16 exactly (16 * scale * level >> n, n <= 4).
+__device__ __forceinline__ void dequant_cols(uint32_t (&col)[4][2], int qp)
+{
+    const int per = (qp * 43) >> 8, rem = qp - per * 6;
+    const uint32_t m0 = dq_s(0, rem) << per, m1 = dq_s(1, rem) << per, m2 = dq_s(2, rem) << per;
+    const u16x2 even = __builtin_bit_cast(u16x2, m0 | (m1 << 16)), odd = __builtin_bit_cast(u16x2, m1 | (m2 << 16));
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            col[x][j] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, col[x][j]) * ((x & 1) ? odd : even)));
+}
+// add4x4_idct (core/dct.c:205-247): first pass along the rows in packed 16-bit (int16 stores, as the reference's tmp),
+// second pass along the columns in 32-bit ((sum + 32) >> 6 is taken before the int16 store), added to the prediction.
+__device__ __forceinline__ void idct_add(const uint32_t (&col)[4][2], uint32_t (&px)[4])
+{
+    s16x2 T[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const s16x2 c0 = as_s16x2(col[0][j]), c1 = as_s16x2(col[1][j]), c2 = as_s16x2(col[2][j]), c3 = as_s16x2(col[3][j]);
+        const s16x2 s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
+        T[0][j] = s02 + s13; T[1][j] = d02 + d13; T[2][j] = d02 - d13; T[3][j] = s02 - s13;
+    }
+    int res[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int a0 = T[x][0].x, a1 = T[x][0].y, a2 = T[x][1].x, a3 = T[x][1].y;
+        const int s02 = a0 + a2 + 32, d02 = a0 - a2 + 32, s13 = a1 + (a3 >> 1), d13 = (a1 >> 1) - a3;
+        res[0][x] = (s02 + s13) >> 6; res[1][x] = (d02 + d13) >> 6; res[2][x] = (d02 - d13) >> 6; res[3][x] = (s02 - s13) >> 6;
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const uint32_t p = px[y];
+        px[y] = pack4(clip255((int)(p & 255) + res[y][0]), clip255((int)((p >> 8) & 255) + res[y][1]),
+                      clip255((int)((p >> 16) & 255) + res[y][2]), clip255((int)(p >> 24) + res[y][3]));
+    }
+}
+
+__device__ __forceinline__ void split_mb(int mbi, const Geom &g, uint32_t inv_mbw, int &mbx, int &mby)
+{
+    mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+    mbx = mbi - mby * g.mb_w;
+}
+
+// XCD-aware block mapping: the dispatcher deals workgroups round-robin over the 8 XCDs; every XCD gets one contiguous
+// eighth of the batch, so that the windows of a picture meet in ONE L2 (speed only, never correctness).
+__device__ __forceinline__ int xcd_logical_block()
+{
+    const int per_xcd = gridDim.x >> 3;
+    return (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mc_luma: one wavefront = one chunk of 16 quadrants of one key; lane = (quadrant lane >> 2, 4x4 block lane & 3)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4)
+void k_mc_luma(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    const int logical = xcd_logical_block();
+    if (logical >= n_wgs) return;
+    int pic = (int)__umulhi((unsigned)logical, inv_wgs);
+    if (logical - pic * wgs_per_pic >= wgs_per_pic) pic++;
+    const PicDev *pd = pics + pic;
+    const uint32_t *mc = pd->mc;
+    const int chunk = rfl((logical - pic * wgs_per_pic) * 4 + (int)(threadIdx.x >> 6));
+    if (chunk >= (int)mc[0]) return;
+    const int lane = threadIdx.x & 63;
+    const int key = (int)((mc[ml.off_cls_y + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);     // scalar: the chunk's key bits
+    const int pc = key & 7;
+    const uint32_t item = gload1(mc + ml.off_list_y + chunk * MCY_CHUNK + (lane >> 2));
+    const bool valid = item != 0xffffffffu;
+    const int mbi = valid ? (int)(item >> 2) : 0, q = valid ? (int)(item & 3) : 0;
+    const int bx = (q & 1) * 2 + (lane & 1), by = (q >> 1) * 2 + ((lane >> 1) & 1);     // block position inside the macroblock
+    // ---- header: everything the lane needs about its block ----
+    const uint4 rec = gload4(pd->mb + mbi);
+    const int mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);
+    const int n_ref = pd->n_ref;
+    uint32_t roff = pd->ref_off[0];
+    if (n_ref > 1) {                                       // (wave-uniform) reference index per 8x8 quadrant
+        int ri = glob(pd->ref_idx)[mbi * 4 + q];
+        if (ri < 0 || ri >= n_ref) ri = 0;                 // negative or past the list: entry 0, as the reference's flat lists
+        roff = glob(pd->ref_off)[ri];
+    }
+    const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
+    int mbx, mby;
+    split_mb(mbi, g, inv_mbw, mbx, mby);
+    const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
+    const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
+    const unsigned mask = rec.y;
+    const int blk = blk_at(bx, by);                        // decode-order index: bit of coef_mask, position in the packed stream
+    const bool coded = valid && ((mask >> blk) & 1);
+    // coded levels are requested before the window (the reads are independent)
+    uint4 la = make_uint4(0, 0, 0, 0), lb = la;
+    if (key & MCY_RESID) {
+        if (coded) {
+            const int16_t *cf = pd->coefs + ((size_t)rec.z + coef_slot(mask, blk)) * 16;
+            la = gload4(cf); lb = gload4(cf + 8);
+        }
+    }
+    // ---- prediction ----
+    uint32_t out[4];
+    if (!(key & MCY_CLAMP)) mc_luma_class<false>(pc, out, rs, roff, g, ix, iy, fx, fy);
+    else {
+        // Clamped windows.  PC_GEN: the vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own
+        // phase: one pass per phase class present among the lanes.  Otherwise the one pass of the chunk's class.
+        out[0] = out[1] = out[2] = out[3] = 0;
+        const int mine = phase_class(fx, fy);
+        const int c_lo = pc == PC_GEN ? 0 : pc, c_hi = pc == PC_GEN ? 6 : pc;
+#pragma unroll 1
+        for (int c = c_lo; c <= c_hi; c++) {
+            if (__ballot(valid && mine == c) == 0) continue;
+            uint32_t o[4];
+            mc_luma_class<true>(c, o, rs, roff, g, ix, iy, fx, fy);
+            if (mine == c) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; }
+        }
+    }
+    // ---- residual (decoder/macroblock.c:839-847) ----
+    if ((key & MCY_RESID) && __ballot(coded)) {
+        const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
+        uint32_t col[4][2];
+        unscan_cols<false>(lv, col);
+        dequant_cols(col, (int)((rec.x >> 8) & 255));
+        uint32_t px[4] = { out[0], out[1], out[2], out[3] };
+        idct_add(col, px);
+        if (coded) { out[0] = px[0]; out[1] = px[1]; out[2] = px[2]; out[3] = px[3]; }
+    }
+    // ---- the block leaves as four dwords of its macroblock's 256 contiguous luma bytes ----
+    if (valid) {
+        const uint32_t o = pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)(by * 64 + bx * 4);
+#pragma unroll
+        for (int y = 0; y < 4; y++) bstore(rs, o + (uint32_t)(y * 16), out[y]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mc_chroma: one wavefront = one chunk of 32 quadrants; lane = (quadrant lane >> 1, plane lane & 1): a 4x4 chroma block
+// ------------------------------------------------------------------------------------------
+// 1/8-pel bilinear (core/mc.c:303-334) of one 4x4 block whose first sample sits at (cx, cy) of plane p, weights (dx, dy)
+template <bool CLAMP>
+__device__ __forceinline__ void mc_chroma_block(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int p, int cx, int cy, int dx, int dy)
+{
+    const int xa = cx & ~3;
+    const uint32_t s = (uint32_t)cx & 3u;
+    uint32_t a[5], b[5];                                   // bytes cx..cx+3 and cx+1..cx+4 of rows cy..cy+4
+    uint32_t col[2], sel[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int x = xa + 4 * k, xc = CLAMP ? clip3i(x, 0, g.cw - 4) : x;
+        col[k] = roff + g.coff + (uint32_t)(xc >> 3) * g.cstrip + (uint32_t)(p * 8 + (xc & 7)) + (CLAMP ? 0u : (uint32_t)(cy * 16));
+        sel[k] = x < 0 ? 0x00000000u : x >= g.cw ? 0x03030303u : 0x03020100u;
+    }
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        uint32_t d0, d1;
+        if (!CLAMP) { d0 = bload(rs, col[0] + (uint32_t)(r * 16)); d1 = bload(rs, col[1] + (uint32_t)(r * 16)); }
+        else {
+            const uint32_t ro = (uint32_t)clip3i(cy + r, 0, g.ch - 1) * 16u;
+            d0 = bload(rs, col[0] + ro); d1 = bload(rs, col[1] + ro);
+            d0 = perm(d0, d0, sel[0]); d1 = perm(d1, d1, sel[1]);
+        }
+        a[r] = alignbyte(d1, d0, s);
+        b[r] = alignbyte(d1 >> (8 * s), a[r], 1);
+    }
+    // sample x of row y: (8-dx)(8-dy) A + dx (8-dy) B + (8-dx) dy C + dx dy D + 32 >> 6 as one 4-byte dot product with
+    // the weights (they fit a byte: at most 64), A B adjacent in row y, C D in row y + 1
+    const uint32_t wts = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const uint32_t v0 = __builtin_amdgcn_udot4(perm(a[y + 1], a[y], 0x05040100u), wts, 32u, false);
+        const uint32_t v1 = __builtin_amdgcn_udot4(perm(a[y + 1], a[y], 0x06050201u), wts, 32u, false);
+        const uint32_t v2 = __builtin_amdgcn_udot4(perm(a[y + 1], a[y], 0x07060302u), wts, 32u, false);
+        const uint32_t v3 = __builtin_amdgcn_udot4(perm(b[y + 1], b[y], 0x07060302u), wts, 32u, false);
+        // v < 2^14: (v0 | v1 << 16) >> 6 leaves sample 0 in byte 0 and sample 1 in byte 2
+        const uint32_t w01 = (v0 | (v1 << 16)) >> 6, w23 = (v2 | (v3 << 16)) >> 6;
+        out[y] = perm(w23, w01, 0x06040200u);
+    }
+}
+
+__global__ __launch_bounds__(256, 4)
+void k_mc_chroma(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    const int logical = xcd_logical_block();
+    if (logical >= n_wgs) return;
+    int pic = (int)__umulhi((unsigned)logical, inv_wgs);
+    if (logical - pic * wgs_per_pic >= wgs_per_pic) pic++;
+    const PicDev *pd = pics + pic;
+    const uint32_t *mc = pd->mc;
+    const int chunk = rfl((logical - pic * wgs_per_pic) * 4 + (int)(threadIdx.x >> 6));
+    if (chunk >= (int)mc[1]) return;
+    const int lane = threadIdx.x & 63, p = lane & 1;
+    const int key = (int)((mc[ml.off_cls_c + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);
+    const uint32_t item = gload1(mc + ml.off_list_c + chunk * MCC_CHUNK + (lane >> 1));
+    const bool valid = item != 0xffffffffu;
+    const int mbi = valid ? (int)(item >> 2) : 0, q = valid ? (int)(item & 3) : 0;
+    const uint4 rec = gload4(pd->mb + mbi);
+    const int b0 = (q >> 1) * 8 + (q & 1) * 2;
+    const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
+    const int n_ref = pd->n_ref;
+    uint32_t roff = pd->ref_off[0];
+    if (n_ref > 1) {
+        int ri = glob(pd->ref_idx)[mbi * 4 + q];
+        if (ri < 0 || ri >= n_ref) ri = 0;
+        roff = glob(pd->ref_off)[ri];
+    }
+    const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
+    int mbx, mby;
+    split_mb(mbi, g, inv_mbw, mbx, mby);
+    const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;
+    const unsigned mask = rec.y;
+    const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
+    const bool has_res = valid && ((rec.x >> 20) & 3) != 0;  // cbp >> 4
+    const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+    uint4 la = make_uint4(0, 0, 0, 0), lb = la; uint2 dcl = make_uint2(0, 0);
+    if (key & MCC_RESID) {
+        if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
+        if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
+    }
+    // ---- prediction ----
+    uint32_t out[4];
+    if (!(key & MCC_SLOW)) {
+        const int mvx = mv_x((int)va.x), mvy = mv_y((int)va.x);
+        mc_chroma_block<false>(out, rs, roff, g, p, CX + (mvx >> 3), CY + (mvy >> 3), mvx & 7, mvy & 7);
+    } else {
+        // clamped windows; where the four 4x4 luma blocks of the quadrant have different vectors (sub-8x8 partitions) every
+        // 2x2 chroma piece follows its own vector: one pass per piece, wave-uniformly skipped when nobody needs it
+        const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
+        const int v4[4] = { (int)va.x, (int)va.y, (int)vb.x, (int)vb.y };
+        out[0] = out[1] = out[2] = out[3] = 0;
+#pragma unroll 1
+        for (int sb = 0; sb < 4; sb++) {
+            if (sb > 0 && __ballot(!uniform) == 0) break;
+            const int mv = sb == 0 ? v4[0] : sb == 1 ? v4[1] : sb == 2 ? v4[2] : v4[3];
+            uint32_t o[4];
+            mc_chroma_block<true>(o, rs, roff, g, p, CX + (mv_x(mv) >> 3), CY + (mv_y(mv) >> 3), mv_x(mv) & 7, mv_y(mv) & 7);
+            if (uniform) { if (sb == 0) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; } }
+            else {
+                const uint32_t m = (sb & 1) ? 0xffff0000u : 0x0000ffffu;
+                const int r0 = (sb >> 1) * 2;
+                out[0] = r0 == 0 ? (out[0] & ~m) | (o[0] & m) : out[0]; out[1] = r0 == 0 ? (out[1] & ~m) | (o[1] & m) : out[1];
+                out[2] = r0 == 2 ? (out[2] & ~m) | (o[2] & m) : out[2]; out[3] = r0 == 2 ? (out[3] & ~m) | (o[3] & m) : out[3];
+            }
+        }
+    }
+    // ---- residual (decoder/macroblock.c:851-890): chroma DC through the 2x2 transform, AC, inverse transform ----
+    if ((key & MCC_RESID) && __ballot(has_res)) {
+        const int qpc = chroma_qp(clip3i((int)((rec.x >> 8) & 255) + pd->chroma_qp_offset, 0, 51));
+        const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
+        uint32_t col[4][2];
+        unscan_cols<true>(lv, col);
+        dequant_cols(col, qpc);
+        // DC of block q: idct2x2dc (core/dct.c:55-68, int16 stores), then p264_mb_dequant_2x2_dc (core/quant.c:138-159):
+        // for every QP its value is (f * (scale << qp/6)) >> 1 - exact for the shifts left, the truncating shift below QP 6
+        const int d0 = (int)(int16_t)(dcl.x & 0xffff), d1 = (int)dcl.x >> 16, d2 = (int)(int16_t)(dcl.y & 0xffff), d3 = (int)dcl.y >> 16;
+        const int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
+        int f = pick_addsub(t0, t1, t2, t3, q & 1, q & 2);                    // {t0+t2, t1+t3, t0-t2, t1-t3}[q]
+        f = (int)(int16_t)f;
+        const int per = (qpc * 43) >> 8, rem = qpc - per * 6;
+        const int dc = (f * (int)(dq_s(0, rem) << per)) >> 1;
+        col[0][0] = (col[0][0] & 0xffff0000u) | ((uint32_t)dc & 0xffffu);
+        uint32_t px[4] = { out[0], out[1], out[2], out[3] };
+        idct_add(col, px);
+        if (has_res) { out[0] = px[0]; out[1] = px[1]; out[2] = px[2]; out[3] = px[3]; }
+    }
+    if (valid) {
+        const uint32_t o = pd->dst_off + mb_chroma_off(g, mbx, mby) + (uint32_t)((q >> 1) * 64 + p * 8 + (q & 1) * 4);
+#pragma unroll
+        for (int y = 0; y < 4; y++) bstore(rs, o + (uint32_t)(y * 16), out[y]);
+    }
+}

@@ -1,5 +1,5 @@
 // p264hip.hip - host side of the C ABI in include/p264hip.h: device context, frame stores,
-// resident picture inputs, batch launch of the three reconstruction kernels, timing hooks.
+// resident picture inputs, batch launch of the reconstruction kernels, timing hooks.
 //
 // One context = one GPU = one HIP stream.  The product has no CPU reconstruction path: when no
 // device is usable every entry point fails with P264HIP_ENODEV.
@@ -11,7 +11,7 @@
 #include <vector>
 #include "p264hip.h"
 #include "device_common.h"
-#include "kernel_inter.h"
+#include "kernel_mc.h"
 #include "kernel_intra.h"
 #include "kernel_deblock.h"
 
@@ -37,27 +37,30 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct PicSlot {                       // one device-resident parsed picture
     uint8_t *dev = nullptr;
     size_t   cap = 0;                  // bytes allocated
-    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_quads = 0, off_coef = 0;
+    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_coef = 0;
     p264hip_picture_t meta;            // scalar fields only; pointers unused
     bool     valid = false;
 };
 
 #define BATCH_RING 4
 
-// tiled frame <-> planar staging (host boundary only): one thread per dword of the tiled frame
-__global__ void k_tile_convert(uint8_t *tiled, uint8_t *planar, Geom g, int to_planar)
+// device frame layout (strips, device_common.h) <-> planar staging (host boundary only): one thread per dword of the frame
+__global__ void k_tile_convert(uint8_t *frame, uint8_t *planar, Geom g, int to_planar)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n_mb * (MB_TILE / 4)) return;
-    const int mb = i / (MB_TILE / 4), d = i - mb * (MB_TILE / 4);
+    if (i >= g.n_mb * 96) return;
+    const int mb = i / 96, d = i - mb * 96;
     const int mx = mb % g.mb_w, my = mb / g.mb_w;
-    size_t po;
-    if (d < 64) po = (size_t)(my * 16 + (d >> 2)) * g.w + mx * 16 + (d & 3) * 4;
-    else {
+    size_t po, fo;
+    if (d < 64) {
+        po = (size_t)(my * 16 + (d >> 2)) * g.w + mx * 16 + (d & 3) * 4;
+        fo = mb_luma_off(g, mx, my) + d * 4;
+    } else {
         const int e = d - 64, p = e >> 4, r = (e >> 1) & 7, dd = e & 1;
         po = (size_t)g.w * g.h + (size_t)p * g.cw * g.ch + (size_t)(my * 8 + r) * g.cw + mx * 8 + dd * 4;
+        fo = mb_chroma_off(g, mx, my) + r * 16 + p * 8 + dd * 4;
     }
-    uint32_t *t = (uint32_t *)(tiled + (size_t)i * 4), *q = (uint32_t *)(planar + po);
+    uint32_t *t = (uint32_t *)(frame + fo), *q = (uint32_t *)(planar + po);
     if (to_planar) *q = *t; else *t = *q;
 }
 
@@ -74,6 +77,9 @@ struct p264hip_ctx {
     int batch_cap = 0, ring = 0;
     int *d_status = nullptr;
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
+    uint32_t *d_mc = nullptr;              // [batch_cap][ml.words], motion-compensation work lists (k_mc_sort -> k_mc_luma / k_mc_chroma)
+    McLayout ml;
+    std::vector<int> stream_seen;          // p264hip_reconstruct: batch index + 1 that last named a stream in the current call
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
     hipEvent_t markers[P264HIP_MARKERS] = {};
     int next_marker = 0;
@@ -105,7 +111,16 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     Geom &g = c->g;
     g.mb_w = mb_w; g.mb_h = mb_h; g.n_mb = mb_w * mb_h;
     g.w = mb_w * 16; g.h = mb_h * 16; g.cw = g.w / 2; g.ch = g.h / 2;
-    c->frame_bytes = align_up((size_t)g.n_mb * MB_TILE + MB_TILE, 256);        // macroblock-tiled (device_common.h), one spare tile
+    g.ystrip = (uint32_t)g.h * 16u; g.cstrip = (uint32_t)g.ch * 16u; g.coff = (uint32_t)g.n_mb * MB_LUMA_BYTES;
+    c->frame_bytes = align_up((size_t)g.n_mb * (MB_LUMA_BYTES + MB_CHROMA_BYTES), 256);      // strip layout (device_common.h)
+    if (c->frame_bytes * (size_t)slots >= (1ull << 32)) { delete c; return fail(P264HIP_EINVAL, "frame store of one stream exceeds 4 GiB (%d slots of %zu bytes)", slots, c->frame_bytes); }
+    {   // locality band of the motion-compensation lists: 16 macroblock rows unless that makes more than MC_MAX_BANDS bands
+        int band_log2 = 4;
+        if (const char *e = getenv("P264AMD_MC_BAND_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 9) band_log2 = v; }
+        while (((mb_h + (1 << band_log2) - 1) >> band_log2) > MC_MAX_BANDS) band_log2++;
+        c->ml = mc_layout(mb_w, mb_h, band_log2);
+    }
+    c->stream_seen.assign((size_t)n_streams, 0);
     c->pics.resize((size_t)max_pictures);
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -138,6 +153,7 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->frames) (void)hipFree(c->frames);
     if (c->d_edge) (void)hipFree(c->d_edge);
+    if (c->d_mc) (void)hipFree(c->d_mc);
     if (c->d_planar) (void)hipFree(c->d_planar);
     for (auto &m : c->markers) if (m) (void)hipEventDestroy(m);
     if (c->d_status) (void)hipFree(c->d_status);
@@ -155,8 +171,14 @@ static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
         if (p->ref_slot[i] < 0 || p->ref_slot[i] >= c->slots) return fail(P264HIP_EINVAL, "ref_slot[%d]=%d out of range", i, p->ref_slot[i]);
     if (p->slice_type == P264_SLICE_P && p->n_ref < 1) return fail(P264HIP_EINVAL, "P picture without reference");
     if (!p->mb || !p->mv || !p->ref_idx || !p->i4modes || (p->n_coef_blocks && !p->coefs)) return fail(P264HIP_EINVAL, "null picture array");
-    if (p->n_quads && (!p->quads || (p->n_quads & 3) || p->n_quads > (uint32_t)c->g.n_mb * 4 + 48))
-        return fail(P264HIP_EINVAL, "bad quadrant list (%u entries)", p->n_quads);
+    // every macroblock's packed blocks must lie inside coefs[] (the kernels index it without further checks)
+    const int n_mb = c->g.n_mb;
+    for (int i = 0; i < n_mb; i++) {
+        const p264hip_mb_t &m = p->mb[i];
+        if (m.coef_mask && (uint64_t)m.coef_index + (uint64_t)__builtin_popcount(m.coef_mask & 0x3ffffffu) > p->n_coef_blocks)
+            return fail(P264HIP_EINVAL, "macroblock %d: coefficient blocks [%u, +%d) outside coefs[%u]", i, m.coef_index,
+                        __builtin_popcount(m.coef_mask & 0x3ffffffu), p->n_coef_blocks);
+    }
     return 0;
 }
 
@@ -169,8 +191,7 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
     size_t off_mv = align_up(n * sizeof(p264hip_mb_t), 256);
     size_t off_ref = off_mv + align_up(n * 64, 256);
     size_t off_i4 = off_ref + align_up(n * 4, 256);
-    size_t off_quads = off_i4 + align_up(n * 16, 256);
-    size_t off_coef = off_quads + align_up((n * 4 + 48) * sizeof(uint32_t), 256);
+    size_t off_coef = off_i4 + align_up(n * 16, 256);
     size_t need = off_coef + align_up((size_t)p->n_coef_blocks * 32, 256) + 256;
     if (need > s.cap) {
         if (s.dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(s.dev)); s.dev = nullptr; s.cap = 0; }
@@ -179,8 +200,7 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
         if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for picture input: %s", cap, hipGetErrorString(e));
         s.cap = cap;
     }
-    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_quads = off_quads; s.off_coef = off_coef;
-    if (p->n_quads) HIPCHK(hipMemcpyAsync(s.dev + off_quads, p->quads, (size_t)p->n_quads * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_coef = off_coef;
     HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(s.dev + off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(s.dev + off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -188,7 +208,7 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
     if (p->n_coef_blocks)
         HIPCHK(hipMemcpyAsync(s.dev + off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
     s.meta = *p;
-    s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr; s.meta.quads = nullptr;
+    s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr; s.meta.quads = nullptr; s.meta.n_quads = 0;
     s.valid = true;
     return 0;
 }
@@ -251,7 +271,7 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
         d.cap = need;
     }
     HIPCHK(hipMemcpyAsync(d.dev, s.dev, need, hipMemcpyDeviceToDevice, c->stream));
-    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_quads = s.off_quads; d.off_coef = s.off_coef;
+    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef;
     d.meta = s.meta; d.valid = true;
     return P264HIP_OK;
 }
@@ -284,19 +304,26 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
             HIPCHK(hipEventRecord(c->batch_free[i], c->stream));
         }
         if (c->d_edge) (void)hipFree(c->d_edge);
-        c->d_edge = nullptr;
+        if (c->d_mc) (void)hipFree(c->d_mc);
+        c->d_edge = nullptr; c->d_mc = nullptr;
         HIPCHK(hipMalloc((void **)&c->d_edge, (size_t)n * c->g.n_mb * sizeof(EdgeInfo)));
+        HIPCHK(hipMalloc((void **)&c->d_mc, (size_t)n * c->ml.words * sizeof(uint32_t)));
         c->batch_cap = n;
     }
     const int r = c->ring; c->ring = (c->ring + 1) % BATCH_RING;
     HIPCHK(hipEventSynchronize(c->batch_free[r]));            // the copy that last used this staging buffer is done
     PicDev *hb = c->h_batch[r];
     bool any_p = false;
-    int max_quads = 0;
+    for (int i = 0; i < n; i++) {                          // two pictures of one call must not share a stream: they would race on its frames
+        const int st = streams[i];
+        if (st < 0 || st >= c->n_streams) return fail(P264HIP_EINVAL, "stream %d out of range", st);
+        c->stream_seen[(size_t)st] = 0;
+    }
     for (int i = 0; i < n; i++) {
         int id = pic_ids[i], st = streams[i];
         if (id < 0 || id >= c->max_pictures || !c->pics[(size_t)id].valid) return fail(P264HIP_EINVAL, "picture slot %d is empty", id);
-        if (st < 0 || st >= c->n_streams) return fail(P264HIP_EINVAL, "stream %d out of range", st);
+        if (c->stream_seen[(size_t)st]) return fail(P264HIP_EINVAL, "stream %d is named twice in one batch (entries %d and %d)", st, c->stream_seen[(size_t)st] - 1, i);
+        c->stream_seen[(size_t)st] = i + 1;
         const PicSlot &s = c->pics[(size_t)id];
         PicDev &d = hb[i];
         memset(&d, 0, sizeof d);
@@ -306,13 +333,15 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         d.i4modes = s.dev + s.off_i4;
         d.coefs = (const int16_t *)(s.dev + s.off_coef);
         d.dst = frame_ptr(c, st, s.meta.dst_slot);
+        d.store = frame_ptr(c, st, 0);
+        d.store_bytes = (uint32_t)(c->frame_bytes * (size_t)c->slots);
+        d.dst_off = (uint32_t)(c->frame_bytes * (size_t)s.meta.dst_slot);
         for (int k = 0; k < P264HIP_MAX_REFS; k++)
-            d.ref[k] = frame_ptr(c, st, k < s.meta.n_ref ? s.meta.ref_slot[k] : (s.meta.n_ref ? s.meta.ref_slot[0] : s.meta.dst_slot));
+            d.ref_off[k] = (uint32_t)(c->frame_bytes * (size_t)(k < s.meta.n_ref ? s.meta.ref_slot[k] : (s.meta.n_ref ? s.meta.ref_slot[0] : s.meta.dst_slot)));
+        d.mc = c->d_mc + (size_t)i * c->ml.words;
         d.n_ref = s.meta.n_ref; d.slice_type = s.meta.slice_type;
         d.chroma_qp_offset = s.meta.chroma_qp_offset; d.deblock = s.meta.deblock;
         d.alpha_off = s.meta.alpha_c0_offset; d.beta_off = s.meta.beta_offset;
-        d.quads = (const uint32_t *)(s.dev + s.off_quads); d.n_quads = (int32_t)s.meta.n_quads;
-        if (d.n_quads > max_quads) max_quads = d.n_quads;
         any_p |= s.meta.slice_type == P264_SLICE_P;
     }
     ScopedStamp whole(c, 3);
@@ -320,16 +349,17 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     HIPCHK(hipEventRecord(c->batch_free[r], c->stream));
     const Geom g = c->g;
     if (any_p) {
+        // motion compensation + residual of all inter macroblocks: device-side counting sort of their 8x8 quadrants by what
+        // the interpolation has to do, then one luma and one chroma kernel over the sorted lists (kernel_mc.h)
         ScopedStamp t(c, 0);
-        int per_pic = (g.n_mb + 3) / 4, n_blocks = per_pic * n, grid = (n_blocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(k_inter, dim3(grid), dim3(256), 0, c->stream, c->d_batch[r], g, per_pic, n_blocks,
-                           (uint32_t)(((1ull << 32) - 1) / (unsigned)per_pic), (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w));
-        // multi-vector macroblocks, quadrant by quadrant: a wavefront takes four list entries, a workgroup sixteen
-        if (max_quads) {
-            const int chunks = (max_quads + 15) / 16, total = chunks * n;
-            hipLaunchKernelGGL(k_inter_quads, dim3((total + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], g,
-                               (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w), chunks, total, (uint32_t)(((1ull << 32) - 1) / (unsigned)chunks));
-        }
+        const McLayout ml = c->ml;
+        const uint32_t inv_mbw = (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w);
+        hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], g, ml, inv_mbw);
+        const int wgs_y = (int)(ml.max_chunks_y + 3) / 4, wgs_c = (int)(ml.max_chunks_c + 3) / 4;
+        hipLaunchKernelGGL(k_mc_luma, dim3(((size_t)wgs_y * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], g, ml, inv_mbw,
+                           wgs_y, wgs_y * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs_y));
+        hipLaunchKernelGGL(k_mc_chroma, dim3(((size_t)wgs_c * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], g, ml, inv_mbw,
+                           wgs_c, wgs_c * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs_c));
     }
     {
         ScopedStamp t(c, 1);
@@ -405,7 +435,7 @@ static int frame_io(p264hip_ctx *c, int stream, int slot, uint8_t *y, int ys, ui
     HIPCHK(hipSetDevice(c->device));
     int rc = p264hip_sync(c);
     if (rc) return rc;
-    // frames live macroblock-tiled on the device; the host sees planes, through a planar staging buffer
+    // frames live in the strip layout on the device; the host sees planes, through a planar staging buffer
     uint8_t *f = frame_ptr(c, stream, slot);
     const Geom &g = c->g;
     const size_t ysz = (size_t)g.w * g.h, csz = (size_t)g.cw * g.ch;
@@ -414,7 +444,7 @@ static int frame_io(p264hip_ctx *c, int stream, int slot, uint8_t *y, int ys, ui
     hipMemcpyKind k = read ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
     struct { uint8_t *host; int hs; uint8_t *dev; int w, h; } pl[3] = {
         { y, ys, s, g.w, g.h }, { u, cs, s + ysz, g.cw, g.ch }, { v, cs, s + ysz + csz, g.cw, g.ch } };
-    const int n_dw = g.n_mb * (MB_TILE / 4);
+    const int n_dw = g.n_mb * 96;
     if (read) {
         hipLaunchKernelGGL(k_tile_convert, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, f, s, g, 1);
         HIPCHK(hipStreamSynchronize(c->stream));

@@ -20,7 +20,6 @@ struct PicDev {
     const int16_t      *coefs;     // [blocks][16]
     uint8_t            *dst;       // destination frame (strip layout, see below)
     uint8_t            *store;     // the stream's frame store: slot 0; every reference and dst lie inside [store, store + store_bytes)
-    uint32_t           *mc;        // this picture's motion-compensation work lists (kernel_mc.h), written by k_mc_sort
     uint32_t store_bytes, dst_off; // dst - store
     int32_t n_ref, slice_type, chroma_qp_offset, deblock, alpha_off, beta_off;
     uint32_t ref_off[P264HIP_MAX_REFS];   // reference frame k - store, list-0 order (entries >= n_ref repeat entry 0)

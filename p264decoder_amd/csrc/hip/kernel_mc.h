@@ -46,7 +46,13 @@ enum { PC_COPY = 0, PC_H = 1, PC_V = 2, PC_DIAG = 3, PC_C = 4, PC_CH = 5, PC_CV 
 #define MC_SORT_THREADS 1024
 
 // Per-picture scratch written by k_mc_sort (32-bit words): [0] luma chunks, [1] chroma chunks, then one class byte per
-// chunk, then the lists (entry = macroblock index << 2 | quadrant, 0xffffffff = padding).  Same for every picture of a batch.
+// chunk, then the lists.  A list entry is 16 bytes and carries everything a wavefront needs to start on the quadrant
+// without looking at the macroblock arrays again (each saved look-up is a dependent memory round trip per wavefront):
+//   luma    x = macroblock index << 2 | quadrant (0xffffffff = padding)   y = the quadrant's vector (packed)
+//           z = index of the quadrant's first packed coefficient block     w = qp | coded bits of its 4 blocks << 8 | reference index << 16
+//   chroma  x, y as above   z = index of the macroblock's chroma DC block
+//           w = qp | cbp chroma << 8 | DC present << 10 | AC coded U, V << 11 | blocks from z to the U / V AC block << 16 / << 21 | reference index << 26
+// Same layout for every picture of a batch.
 struct McLayout {
     uint32_t band_log2, n_bands;
     uint32_t max_chunks_y, max_chunks_c;
@@ -63,8 +69,8 @@ static inline McLayout mc_layout(int mb_w, int mb_h, int band_log2)
     L.off_cls_y = 16;
     L.off_cls_c = L.off_cls_y + (L.max_chunks_y + 3) / 4;
     L.off_list_y = (L.off_cls_c + (L.max_chunks_c + 3) / 4 + 15) & ~15u;
-    L.off_list_c = L.off_list_y + L.max_chunks_y * MCY_CHUNK;
-    L.words = (L.off_list_c + L.max_chunks_c * MCC_CHUNK + 63) & ~63u;
+    L.off_list_c = L.off_list_y + L.max_chunks_y * MCY_CHUNK * 4;
+    L.words = (L.off_list_c + L.max_chunks_c * MCC_CHUNK * 4 + 63) & ~63u;
     return L;
 }
 
@@ -82,12 +88,13 @@ __device__ __forceinline__ int phase_class(int fx, int fy)
     return PC_CV;
 }
 
-struct McKeys { int ky, kc; };       // -1: nothing to do (intra macroblock)
-__device__ __forceinline__ McKeys mc_classify(const PicDev *pd, const Geom &g, uint32_t item, uint32_t inv_mbw, int band_log2)
+struct McItem { int ky, kc; uint4 ey, ec; };       // keys (-1: nothing to do, intra macroblock) and the two list entries
+__device__ __forceinline__ McItem mc_item(const PicDev *pd, const Geom &g, uint32_t item, uint32_t inv_mbw, int band_log2, bool entries)
 {
     const int mbi = (int)(item >> 2), q = (int)(item & 3);
     const uint4 rec = gload4(pd->mb + mbi);
-    McKeys k = { -1, -1 };
+    McItem k;
+    k.ky = k.kc = -1;
     if (P264_MB_IS_INTRA(rec.x & 255)) return k;
     const int b0 = (q >> 1) * 8 + (q & 1) * 2;
     const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
@@ -103,23 +110,32 @@ __device__ __forceinline__ McKeys mc_classify(const PicDev *pd, const Geom &g, u
     const int cx = X0 / 2 + (mvx >> 3), cy = Y0 / 2 + (mvy >> 3);
     const bool in_c = cx >= 0 && cx <= g.cw - 8 && cy >= 0 && cy <= g.ch - 5;
     const int band = mby >> band_log2;
-    const unsigned mask = rec.y, cbp = (rec.x >> 16) & 255;
+    const unsigned mask = rec.y, cc = (rec.x >> 20) & 3, m4 = (mask >> (4 * q)) & 15;
     int pc = phase_class(mvx & 3, mvy & 3), fl = in_y ? 0 : MCY_CLAMP;
     if (!uniform) { pc = PC_GEN; fl = MCY_CLAMP; }
-    if ((mask >> (4 * q)) & 15) fl |= MCY_RESID;
+    if (m4) fl |= MCY_RESID;
     k.ky = band * MCY_KEYS + (pc | fl);
-    k.kc = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_SLOW) + ((cbp >> 4) ? MCC_RESID : 0);
+    k.kc = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_SLOW) + (cc ? MCC_RESID : 0);
+    if (entries) {
+        int ri = glob(pd->ref_idx)[mbi * 4 + q];
+        if (ri < 0 || ri >= pd->n_ref) ri = 0;             // negative or past the list: entry 0, as the reference's flat lists
+        const uint32_t qp = (rec.x >> 8) & 255, ldc = (mask >> 24) & 1, cdc = (mask >> 25) & 1;
+        k.ey = make_uint4(item, va.x, rec.z + coef_slot(mask, 4 * q), qp | m4 << 8 | (uint32_t)ri << 16);
+        const uint32_t offU = cdc + __popc(mask & ((1u << (16 + q)) - 1u) & 0xffffffu), offV = cdc + __popc(mask & ((1u << (20 + q)) - 1u) & 0xffffffu);
+        k.ec = make_uint4(item, va.x, rec.z + ldc,
+                          qp | cc << 8 | cdc << 10 | ((mask >> (16 + q)) & 1) << 11 | ((mask >> (20 + q)) & 1) << 12 | offU << 16 | offV << 21 | (uint32_t)ri << 26);
+    }
     return k;
 }
 
 // One workgroup per picture: count the keys, lay the key segments out (each padded to whole chunks), scatter the items.
 __global__ __launch_bounds__(MC_SORT_THREADS)
-void k_mc_sort(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t inv_mbw)
+void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
 {
     __shared__ uint32_t cnt_y[MC_MAX_BANDS * MCY_KEYS], cnt_c[MC_MAX_BANDS * MCC_KEYS];
     __shared__ uint32_t pos_y[MC_MAX_BANDS * MCY_KEYS], pos_c[MC_MAX_BANDS * MCC_KEYS];
     const PicDev *pd = pics + blockIdx.x;
-    uint32_t *out = pd->mc;
+    uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
     const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
     const int tid = threadIdx.x;
     if (pd->slice_type != P264_SLICE_P) {                 // wave-uniform
@@ -131,7 +147,7 @@ void k_mc_sort(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t in
     __syncthreads();
     const uint32_t n_items = (uint32_t)g.n_mb * 4u;
     for (uint32_t it = tid; it < n_items; it += MC_SORT_THREADS) {
-        const McKeys k = mc_classify(pd, g, it, inv_mbw, (int)ml.band_log2);
+        const McItem k = mc_item(pd, g, it, inv_mbw, (int)ml.band_log2, false);
         if (k.ky >= 0) { atomicAdd(&cnt_y[k.ky], 1u); atomicAdd(&cnt_c[k.kc], 1u); }
     }
     __syncthreads();
@@ -154,10 +170,10 @@ void k_mc_sort(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t in
     __syncthreads();
     uint32_t *list_y = out + ml.off_list_y, *list_c = out + ml.off_list_c;
     for (uint32_t it = tid; it < n_items; it += MC_SORT_THREADS) {
-        const McKeys k = mc_classify(pd, g, it, inv_mbw, (int)ml.band_log2);
+        const McItem k = mc_item(pd, g, it, inv_mbw, (int)ml.band_log2, true);
         if (k.ky >= 0) {
-            gstore1(list_y + atomicAdd(&pos_y[k.ky], 1u), it);
-            gstore1(list_c + atomicAdd(&pos_c[k.kc], 1u), it);
+            gstore4(list_y + 4 * atomicAdd(&pos_y[k.ky], 1u), k.ey);
+            gstore4(list_c + 4 * atomicAdd(&pos_c[k.kc], 1u), k.ec);
         }
     }
     __syncthreads();
@@ -167,7 +183,7 @@ void k_mc_sort(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t in
         const uint32_t chunk = is_y ? MCY_CHUNK : MCC_CHUNK;
         const uint32_t end = (is_y ? pos_y : pos_c)[kk];
         uint32_t *list = is_y ? list_y : list_c;
-        for (uint32_t p = end; p < (end + chunk - 1) / chunk * chunk; p++) gstore1(list + p, 0xffffffffu);
+        for (uint32_t p = end; p < (end + chunk - 1) / chunk * chunk; p++) gstore4(list + 4 * p, make_uint4(0xffffffffu, 0, 0, 0));
     }
 }
 
@@ -196,28 +212,74 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes)
 }
 __device__ __forceinline__ uint32_t bload(rsrc_t r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
 __device__ __forceinline__ void bstore(rsrc_t r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)off, 0, 0); }
+__device__ __forceinline__ u32x4 bload4(rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); }
+__device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b) { const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, 0); }
+// the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
+__device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
 
 // ------------------------------------------------------------------------------------------
 // reference windows in registers
 // ------------------------------------------------------------------------------------------
 // d[r][k] = the aligned dword k of window row r.  The window starts at sample (xw, yw); xa = xw & ~3 is the first dword.
-// Rows R0 .. R0+NR-1 and NC dword columns are fetched.  Inside the picture a load is `column register + 16 * row` (the
-// compiler folds the row into the instruction's immediate offset).  CLAMP: coordinates clamped to the picture = the
-// reference's replicated borders (core/frame.c:183-222, A-Q9); a dword is either entirely inside or entirely outside
-// (plane widths are multiples of 8), outside it becomes the replicated edge byte.
-template <int R0, int NR, int NC, bool CLAMP>
-__device__ __forceinline__ void load_luma(uint32_t (&d)[9][3], rsrc_t rs, uint32_t roff, const Geom &g, int xw, int yw)
+// Rows R0 .. R0+NR-1 and NC dword columns are fetched.  Two sources:
+//
+// LWin - the normal case.  A lane fetching its own window from memory costs one L1 tag look-up per lane and dword (the
+// first version of this kernel did exactly that and was bound by the L1's look-up rate: ~50 look-ups per load instruction,
+// 27 loads).  So the four lanes of a quadrant stage the quadrant's window - 13 rows x two strips x 16 bytes - in LDS
+// with 16-byte loads of consecutive rows (64 contiguous bytes per four lanes: one or two look-ups), and every lane reads
+// its window out of that image: one address register, rows and columns as immediates.
+//
+// GWin - straight from memory with clamped coordinates; only for quadrants whose 4x4 blocks have different vectors
+// (sub-8x8 partitions), where there is no common window.
+#define LY_PITCH   40               // image row: 32 samples (strip A | strip B) + 8 bytes so that rows spread over the banks
+#define LY_QUAD    (13 * LY_PITCH + 8)
+
+// Stage rows R0S .. R0S+NRS-1 of the window whose top-left sample is (wx, wy); li = lane & 3.  CLAMP: coordinates clamped
+// to the picture = the reference's replicated borders (core/frame.c:183-222, A-Q9): a strip that lies outside the picture
+// becomes the replicated first (last) sample of the row.
+template <int R0S, int NRS, bool CLAMP>
+__device__ __forceinline__ void stage_luma(uint8_t *qimg, rsrc_t rs, uint32_t roff, const Geom &g, int wx, int wy, int li)
 {
-    const int xa = xw & ~3;
-    if (!CLAMP) {
-        uint32_t col[NC];
+    constexpr int NP = 2 * NRS, NJ = (NP + 3) / 4;
+    const int sA = wx >> 4;
+    u32x4 v[NJ];
+    int dst[NJ];
 #pragma unroll
-        for (int k = 0; k < NC; k++) { const int x = xa + 4 * k; col[k] = roff + (uint32_t)(x >> 4) * g.ystrip + (uint32_t)(yw * 16 + (x & 15)); }
+    for (int j = 0; j < NJ; j++) {
+        const int p = min(li + 4 * j, NP - 1), s = p >= NRS ? 1 : 0, row = R0S + p - s * NRS;
+        dst[j] = row * LY_PITCH + s * 16;
+        if (!CLAMP) v[j] = bload4(rs, roff + (uint32_t)(sA + s) * g.ystrip + (uint32_t)((wy + row) * 16));
+        else {
+            const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
+            u32x4 t = bload4(rs, roff + (uint32_t)sc * g.ystrip + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
+            if (st < 0) { const uint32_t e = perm(t.x, t.x, 0x00000000u); t.x = t.y = t.z = t.w = e; }
+            if (st >= g.mb_w) { const uint32_t e = perm(t.w, t.w, 0x03030303u); t.x = t.y = t.z = t.w = e; }
+            v[j] = t;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        *(uint2 *)(qimg + dst[j]) = make_uint2(v[j].x, v[j].y);
+        *(uint2 *)(qimg + dst[j] + 8) = make_uint2(v[j].z, v[j].w);
+    }
+}
+struct LWin {
+    const uint8_t *qimg; int x0, y0;                       // the image's sample (0,0) is (x0, y0) of the reference
+    template <int R0, int NR, int NC> __device__ __forceinline__ void load(uint32_t (&d)[9][3], int xw, int yw) const
+    {
+        const uint8_t *b = qimg + (yw - y0) * LY_PITCH + ((xw & ~3) - x0);
 #pragma unroll
         for (int r = R0; r < R0 + NR; r++)
 #pragma unroll
-            for (int k = 0; k < NC; k++) d[r][k] = bload(rs, col[k] + (uint32_t)(r * 16));
-    } else {
+            for (int k = 0; k < NC; k++) d[r][k] = *(const uint32_t *)(b + r * LY_PITCH + 4 * k);
+    }
+};
+struct GWin {
+    rsrc_t rs; uint32_t roff; const Geom &g;
+    template <int R0, int NR, int NC> __device__ __forceinline__ void load(uint32_t (&d)[9][3], int xw, int yw) const
+    {
+        const int xa = xw & ~3;
         uint32_t col[NC], sel[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) {
@@ -232,7 +294,7 @@ __device__ __forceinline__ void load_luma(uint32_t (&d)[9][3], rsrc_t rs, uint32
             for (int k = 0; k < NC; k++) { const uint32_t v = bload(rs, col[k] + ro); d[r][k] = perm(v, v, sel[k]); }
         }
     }
-}
+};
 
 // horizontal 6-tap sums (core/mc.c:53-56) for 4 adjacent samples; n0..n2 hold window bytes 0..11, output sample i uses
 // bytes i..i+5.  Samples are taken as (s - 128) in int8: the taps sum to 32, so the true sum is the dot product + 4096;
@@ -272,18 +334,18 @@ __device__ __forceinline__ uint32_t tap_v4(uint32_t r0, uint32_t r1, uint32_t r2
 
 // ---- the seven phase classes: out[y] = the four samples of row y of the lane's 4x4 block -----------------------------
 // (ix, iy) = integer position of the block's first sample in the reference, (fx, fy) = quarter-pel phase.
-template <bool CLAMP> __device__ __forceinline__ void mc_copy(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy)
+template <class W> __device__ __forceinline__ void mc_copy(uint32_t (&out)[4], const W &w, int ix, int iy)
 {
     uint32_t d[9][3];
-    load_luma<0, 4, 2, CLAMP>(d, rs, roff, g, ix, iy);
+    w.template load<0, 4, 2>(d, ix, iy);
     const uint32_t s = (uint32_t)ix & 3u;
 #pragma unroll
     for (int y = 0; y < 4; y++) out[y] = alignbyte(d[y][1], d[y][0], s);
 }
-template <bool CLAMP> __device__ __forceinline__ void mc_h(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx)
+template <class W> __device__ __forceinline__ void mc_h(uint32_t (&out)[4], const W &w, int ix, int iy, int fx)
 {   // fx = 1: avg(G, h), 2: h, 3: avg(h, G one to the right)
     uint32_t d[9][3];
-    load_luma<0, 4, 3, CLAMP>(d, rs, roff, g, ix - 2, iy);
+    w.template load<0, 4, 3>(d, ix - 2, iy);
     const uint32_t s = (uint32_t)(ix - 2) & 3u, gs = 2u + (uint32_t)(fx == 3);
 #pragma unroll
     for (int y = 0; y < 4; y++) {
@@ -294,10 +356,10 @@ template <bool CLAMP> __device__ __forceinline__ void mc_h(uint32_t (&out)[4], r
         out[y] = sel32(fx == 2, hh, avg4(hh, alignbyte(n1, n0, gs)));
     }
 }
-template <bool CLAMP> __device__ __forceinline__ void mc_v(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fy)
+template <class W> __device__ __forceinline__ void mc_v(uint32_t (&out)[4], const W &w, int ix, int iy, int fy)
 {   // fy = 1: avg(v, G), 2: v, 3: avg(G one down, v)
     uint32_t d[9][3], c[9];
-    load_luma<0, 9, 2, CLAMP>(d, rs, roff, g, ix, iy - 2);
+    w.template load<0, 9, 2>(d, ix, iy - 2);
     const uint32_t s = (uint32_t)ix & 3u;
 #pragma unroll
     for (int r = 0; r < 9; r++) c[r] = alignbyte(d[r][1], d[r][0], s);
@@ -307,68 +369,71 @@ template <bool CLAMP> __device__ __forceinline__ void mc_v(uint32_t (&out)[4], r
         out[y] = sel32(fy == 2, vv, avg4(vv, sel32(fy == 3, c[y + 3], c[y + 2])));
     }
 }
-template <bool CLAMP> __device__ __forceinline__ void mc_diag(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx, int fy)
-{   // avg(h of row y + (fy == 3), v of column x + (fx == 3))
-    uint32_t d[9][3], n0[9], n1[9], c[9];
-    load_luma<0, 9, 3, CLAMP>(d, rs, roff, g, ix - 2, iy - 2);
+template <class W> __device__ __forceinline__ void mc_diag(uint32_t (&out)[4], const W &w, int ix, int iy, int fx, int fy)
+{   // avg(h of row y + (fy == 3), v of column x + (fx == 3)); rows are consumed one at a time to keep the live set small
+    uint32_t d[9][3], c[9], hh[5];
+    w.template load<0, 9, 3>(d, ix - 2, iy - 2);
     const uint32_t s = (uint32_t)(ix - 2) & 3u, vs = 2u + (uint32_t)(fx == 3);
-#pragma unroll
-    for (int r = 0; r < 9; r++) { n0[r] = alignbyte(d[r][1], d[r][0], s); n1[r] = alignbyte(d[r][2], d[r][1], s); c[r] = alignbyte(n1[r], n0[r], vs); }
-#pragma unroll
-    for (int y = 0; y < 4; y++) {
-        const bool dn = fy == 3;
-        const uint32_t h0 = sel32(dn, n0[y + 3], n0[y + 2]), h1 = sel32(dn, n1[y + 3], n1[y + 2]);
-        const uint32_t h2 = sel32(dn, d[y + 3][2], d[y + 2][2]) >> (8 * s);
-        int t[4];
-        tap_h4(h0, h1, h2, 4096 + 16, t);
-        out[y] = avg4(round_pack4<5>(t), tap_v4(c[y], c[y + 1], c[y + 2], c[y + 3], c[y + 4], c[y + 5]));
-    }
-}
-// centre position (mc_hc, core/mc.c:200-235): horizontal sums of nine rows, unrounded, then the vertical filter on them,
-// (sum + 512) >> 10.  Each row's sum carries + 16, which the vertical taps (sum 32) turn into the + 512 - and which is
-// also the rounding term of the horizontal half-pel sample of that row.  WITH: 0 centre only, 1 avg with h of row
-// y + (fy == 3), 2 avg with v of column x + (fx == 3).
-template <bool CLAMP, int WITH> __device__ __forceinline__ void mc_centre(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx, int fy)
-{
-    uint32_t d[9][3];
-    load_luma<0, 9, 3, CLAMP>(d, rs, roff, g, ix - 2, iy - 2);
-    const uint32_t s = (uint32_t)(ix - 2) & 3u;
-    int t[9][4];
-    uint32_t c[9];
 #pragma unroll
     for (int r = 0; r < 9; r++) {
         uint32_t n0, n1, n2;
         align_row(d[r], s, n0, n1, n2);
-        tap_h4(n0, n1, n2, 4096 + 16, t[r]);
+        c[r] = alignbyte(n1, n0, vs);
+        if (r >= 2 && r <= 6) { int t[4]; tap_h4(n0, n1, n2, 4096 + 16, t); hh[r - 2] = round_pack4<5>(t); }
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+        out[y] = avg4(sel32(fy == 3, hh[y + 1], hh[y]), tap_v4(c[y], c[y + 1], c[y + 2], c[y + 3], c[y + 4], c[y + 5]));
+}
+// centre position (mc_hc, core/mc.c:200-235): horizontal sums of nine rows, unrounded, then the vertical filter on them,
+// (sum + 512) >> 10.  Each row's sum carries + 16, which the vertical taps (sum 32) turn into the + 512 - and which is
+// also the rounding term of the horizontal half-pel sample of that row.  A row's sums are folded into the (up to four)
+// output rows they belong to as soon as they exist: 16 accumulators instead of 36 sums kept alive.
+// WITH: 0 centre only, 1 avg with h of row y + (fy == 3), 2 avg with v of column x + (fx == 3).
+template <class W, int WITH> __device__ __forceinline__ void mc_centre(uint32_t (&out)[4], const W &w, int ix, int iy, int fx, int fy)
+{
+    uint32_t d[9][3];
+    w.template load<0, 9, 3>(d, ix - 2, iy - 2);
+    const uint32_t s = (uint32_t)(ix - 2) & 3u;
+    int acc[4][4];
+    uint32_t c[9], hsel[4];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        uint32_t n0, n1, n2; int t[4];
+        align_row(d[r], s, n0, n1, n2);
+        tap_h4(n0, n1, n2, 4096 + 16, t);
         if (WITH == 2) c[r] = alignbyte(n1, n0, 2u + (uint32_t)(fx == 3));
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const int k = r - y;                           // tap of output row y this window row meets
+            if (k < 0 || k > 5) continue;
+            const int cv = (k == 0 || k == 5) ? 1 : (k == 1 || k == 4) ? -5 : 20;
+#pragma unroll
+            for (int x = 0; x < 4; x++) acc[y][x] = k == 0 ? t[x] : acc[y][x] + cv * t[x];
+        }
+        if (WITH == 1 && r >= 2 && r <= 6) {               // horizontal half-pel sample of window row r: output row r-2 (fy = 1) or r-3 (fy = 3)
+            const uint32_t hh = round_pack4<5>(t);
+            if (r <= 5) hsel[r - 2] = hh;
+            if (r >= 3) hsel[r - 3] = sel32(fy == 3, hh, hsel[r - 3]);
+        }
     }
 #pragma unroll
     for (int y = 0; y < 4; y++) {
-        int a[4];
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-            a[x] = (t[y][x] + t[y + 5][x]) + 20 * (t[y + 2][x] + t[y + 3][x]) - 5 * (t[y + 1][x] + t[y + 4][x]);
-        const uint32_t cc = round_pack4<10>(a);
-        if (WITH == 0) out[y] = cc;
-        else if (WITH == 1) {
-            int hsel[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++) hsel[x] = fy == 3 ? t[y + 3][x] : t[y + 2][x];
-            out[y] = avg4(cc, round_pack4<5>(hsel));
-        } else out[y] = avg4(cc, tap_v4(c[y], c[y + 1], c[y + 2], c[y + 3], c[y + 4], c[y + 5]));
+        const uint32_t cc = round_pack4<10>(acc[y]);
+        out[y] = WITH == 0 ? cc : WITH == 1 ? avg4(cc, hsel[y]) : avg4(cc, tap_v4(c[y], c[y + 1], c[y + 2], c[y + 3], c[y + 4], c[y + 5]));
     }
 }
 
-template <bool CLAMP> __device__ __forceinline__ void mc_luma_class(int pc, uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int ix, int iy, int fx, int fy)
+template <class W> __device__ __forceinline__ void mc_luma_class(int pc, uint32_t (&out)[4], const W &w, int ix, int iy, int fx, int fy)
 {
     switch (pc) {                                          // wave-uniform
-    case PC_COPY: mc_copy<CLAMP>(out, rs, roff, g, ix, iy); break;
-    case PC_H:    mc_h<CLAMP>(out, rs, roff, g, ix, iy, fx); break;
-    case PC_V:    mc_v<CLAMP>(out, rs, roff, g, ix, iy, fy); break;
-    case PC_DIAG: mc_diag<CLAMP>(out, rs, roff, g, ix, iy, fx, fy); break;
-    case PC_C:    mc_centre<CLAMP, 0>(out, rs, roff, g, ix, iy, fx, fy); break;
-    case PC_CH:   mc_centre<CLAMP, 1>(out, rs, roff, g, ix, iy, fx, fy); break;
-    default:      mc_centre<CLAMP, 2>(out, rs, roff, g, ix, iy, fx, fy); break;
+    case PC_COPY: mc_copy(out, w, ix, iy); break;
+    case PC_H:    mc_h(out, w, ix, iy, fx); break;
+    case PC_V:    mc_v(out, w, ix, iy, fy); break;
+    case PC_DIAG: mc_diag(out, w, ix, iy, fx, fy); break;
+    case PC_C:    mc_centre<W, 0>(out, w, ix, iy, fx, fy); break;
+    case PC_CH:   mc_centre<W, 1>(out, w, ix, iy, fx, fy); break;
+    default:      mc_centre<W, 2>(out, w, ix, iy, fx, fy); break;
     }
 }
 
@@ -464,63 +529,71 @@ __device__ __forceinline__ int xcd_logical_block()
 // k_mc_luma: one wavefront = one chunk of 16 quadrants of one key; lane = (quadrant lane >> 2, 4x4 block lane & 3)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4)
-void k_mc_luma(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+void k_mc_luma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t images[4][MCY_CHUNK * LY_QUAD];
     const int logical = xcd_logical_block();
     if (logical >= n_wgs) return;
     int pic = (int)__umulhi((unsigned)logical, inv_wgs);
     if (logical - pic * wgs_per_pic >= wgs_per_pic) pic++;
     const PicDev *pd = pics + pic;
-    const uint32_t *mc = pd->mc;
-    const int chunk = rfl((logical - pic * wgs_per_pic) * 4 + (int)(threadIdx.x >> 6));
+    const uint32_t *mc = mc_all + (size_t)pic * ml.words;  // (addresses from kernel arguments only: the first loads depend on nothing)
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
     if (chunk >= (int)mc[0]) return;
     const int lane = threadIdx.x & 63;
     const int key = (int)((mc[ml.off_cls_y + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);     // scalar: the chunk's key bits
     const int pc = key & 7;
-    const uint32_t item = gload1(mc + ml.off_list_y + chunk * MCY_CHUNK + (lane >> 2));
-    const bool valid = item != 0xffffffffu;
-    const int mbi = valid ? (int)(item >> 2) : 0, q = valid ? (int)(item & 3) : 0;
+    const uint4 e = gload4(mc + ml.off_list_y + (size_t)(chunk * MCY_CHUNK + (lane >> 2)) * 4);
+    const bool valid = e.x != 0xffffffffu;
+    const int mbi = valid ? (int)(e.x >> 2) : 0, q = valid ? (int)(e.x & 3) : 0;
     const int bx = (q & 1) * 2 + (lane & 1), by = (q >> 1) * 2 + ((lane >> 1) & 1);     // block position inside the macroblock
-    // ---- header: everything the lane needs about its block ----
-    const uint4 rec = gload4(pd->mb + mbi);
-    const int mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);
-    const int n_ref = pd->n_ref;
-    uint32_t roff = pd->ref_off[0];
-    if (n_ref > 1) {                                       // (wave-uniform) reference index per 8x8 quadrant
-        int ri = glob(pd->ref_idx)[mbi * 4 + q];
-        if (ri < 0 || ri >= n_ref) ri = 0;                 // negative or past the list: entry 0, as the reference's flat lists
-        roff = glob(pd->ref_off)[ri];
-    }
+    int mvp = (int)e.y;
+    if (pc == PC_GEN) mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);          // sub-8x8 partitions: the block's own vector
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
+    uint32_t roff = pd->ref_off[0];
+    if (pd->n_ref > 1) roff = glob(pd->ref_off)[(e.w >> 16) & 15];                  // (wave-uniform branch)
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
     const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
-    const unsigned mask = rec.y;
-    const int blk = blk_at(bx, by);                        // decode-order index: bit of coef_mask, position in the packed stream
-    const bool coded = valid && ((mask >> blk) & 1);
+    const unsigned m4 = (e.w >> 8) & 15;                   // coded bits of the quadrant's blocks, decode order = lane & 3
+    const bool coded = valid && ((m4 >> (lane & 3)) & 1);
     // coded levels are requested before the window (the reads are independent)
     uint4 la = make_uint4(0, 0, 0, 0), lb = la;
     if (key & MCY_RESID) {
         if (coded) {
-            const int16_t *cf = pd->coefs + ((size_t)rec.z + coef_slot(mask, blk)) * 16;
+            const int16_t *cf = pd->coefs + ((size_t)e.z + __popc(m4 & ((1u << (lane & 3)) - 1u))) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
         }
     }
     // ---- prediction ----
     uint32_t out[4];
-    if (!(key & MCY_CLAMP)) mc_luma_class<false>(pc, out, rs, roff, g, ix, iy, fx, fy);
-    else {
-        // Clamped windows.  PC_GEN: the vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own
-        // phase: one pass per phase class present among the lanes.  Otherwise the one pass of the chunk's class.
+    if (pc != PC_GEN) {
+        // the quadrant's window (all four lanes hold the same vector): top-left sample (wx, wy), staged in LDS
+        const int wx = ix - (lane & 1) * 4 - 2, wy = iy - ((lane >> 1) & 1) * 4 - 2;
+        uint8_t *qimg = images[wave] + (lane >> 2) * LY_QUAD;
+        const bool rows8 = pc <= PC_H;                     // copy / horizontal: rows 2..9 of the window only
+        if (!(key & MCY_CLAMP)) { if (rows8) stage_luma<2, 8, false>(qimg, rs, roff, g, wx, wy, lane & 3); else stage_luma<0, 13, false>(qimg, rs, roff, g, wx, wy, lane & 3); }
+        else                    { if (rows8) stage_luma<2, 8, true>(qimg, rs, roff, g, wx, wy, lane & 3);  else stage_luma<0, 13, true>(qimg, rs, roff, g, wx, wy, lane & 3); }
+        wave_lds_fence();
+        const LWin w = { qimg, (wx >> 4) * 16, wy };
+        mc_luma_class(pc, out, w, ix, iy, fx, fy);
+    } else {
+        // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
+        // straight from memory, one pass per phase class present among the lanes.
         out[0] = out[1] = out[2] = out[3] = 0;
+        const GWin w = { rs, roff, g };
         const int mine = phase_class(fx, fy);
-        const int c_lo = pc == PC_GEN ? 0 : pc, c_hi = pc == PC_GEN ? 6 : pc;
 #pragma unroll 1
-        for (int c = c_lo; c <= c_hi; c++) {
+        for (int c = 0; c < 7; c++) {
             if (__ballot(valid && mine == c) == 0) continue;
+            // (the window addresses do not depend on c: without this the compiler computes the clamped addresses of every
+            // class in front of the loop and keeps all of them alive - far more registers than the rest of the kernel needs)
+            int jx = ix, jy = iy;
+            asm volatile("" : "+v"(jx), "+v"(jy));
             uint32_t o[4];
-            mc_luma_class<true>(c, o, rs, roff, g, ix, iy, fx, fy);
+            mc_luma_class(c, o, w, jx, jy, fx, fy);
             if (mine == c) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; }
         }
     }
@@ -529,48 +602,36 @@ void k_mc_luma(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t in
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<false>(lv, col);
-        dequant_cols(col, (int)((rec.x >> 8) & 255));
+        dequant_cols(col, (int)(e.w & 255));
         uint32_t px[4] = { out[0], out[1], out[2], out[3] };
         idct_add(col, px);
         if (coded) { out[0] = px[0]; out[1] = px[1]; out[2] = px[2]; out[3] = px[3]; }
     }
-    // ---- the block leaves as four dwords of its macroblock's 256 contiguous luma bytes ----
-    if (valid) {
-        const uint32_t o = pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)(by * 64 + bx * 4);
-#pragma unroll
-        for (int y = 0; y < 4; y++) bstore(rs, o + (uint32_t)(y * 16), out[y]);
+    // ---- store: the two lanes of a block row swap halves, so that a lane writes two rows of 8 samples (four lanes: eight
+    // consecutive rows of the quadrant, one or two cache lines) instead of four rows of 4 ----
+    {
+        const bool right = lane & 1;
+        const uint32_t g0 = lane_xor1(right ? out[0] : out[2]), g1 = lane_xor1(right ? out[1] : out[3]);
+        const uint32_t r0a = right ? g0 : out[0], r0b = right ? out[2] : g0;       // row 4*by' + 2*right: samples 0-3, 4-7
+        const uint32_t r1a = right ? g1 : out[1], r1b = right ? out[3] : g1;       // the row below
+        if (valid) {
+            const uint32_t o = pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + (right ? 2 : 0)) * 16 + (q & 1) * 8);
+            bstore2(rs, o, r0a, r0b);
+            bstore2(rs, o + 16, r1a, r1b);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_mc_chroma: one wavefront = one chunk of 32 quadrants; lane = (quadrant lane >> 1, plane lane & 1): a 4x4 chroma block
 // ------------------------------------------------------------------------------------------
-// 1/8-pel bilinear (core/mc.c:303-334) of one 4x4 block whose first sample sits at (cx, cy) of plane p, weights (dx, dy)
-template <bool CLAMP>
-__device__ __forceinline__ void mc_chroma_block(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int p, int cx, int cy, int dx, int dy)
+// 1/8-pel bilinear (core/mc.c:303-334) of one 4x4 block from the two aligned dwords d0, d1 of five window rows; the
+// block's first sample is byte s of d0; weights (dx, dy)
+__device__ __forceinline__ void chroma_bilinear(uint32_t (&out)[4], const uint32_t (&d0)[5], const uint32_t (&d1)[5], uint32_t s, int dx, int dy)
 {
-    const int xa = cx & ~3;
-    const uint32_t s = (uint32_t)cx & 3u;
     uint32_t a[5], b[5];                                   // bytes cx..cx+3 and cx+1..cx+4 of rows cy..cy+4
-    uint32_t col[2], sel[2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int x = xa + 4 * k, xc = CLAMP ? clip3i(x, 0, g.cw - 4) : x;
-        col[k] = roff + g.coff + (uint32_t)(xc >> 3) * g.cstrip + (uint32_t)(p * 8 + (xc & 7)) + (CLAMP ? 0u : (uint32_t)(cy * 16));
-        sel[k] = x < 0 ? 0x00000000u : x >= g.cw ? 0x03030303u : 0x03020100u;
-    }
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-        uint32_t d0, d1;
-        if (!CLAMP) { d0 = bload(rs, col[0] + (uint32_t)(r * 16)); d1 = bload(rs, col[1] + (uint32_t)(r * 16)); }
-        else {
-            const uint32_t ro = (uint32_t)clip3i(cy + r, 0, g.ch - 1) * 16u;
-            d0 = bload(rs, col[0] + ro); d1 = bload(rs, col[1] + ro);
-            d0 = perm(d0, d0, sel[0]); d1 = perm(d1, d1, sel[1]);
-        }
-        a[r] = alignbyte(d1, d0, s);
-        b[r] = alignbyte(d1 >> (8 * s), a[r], 1);
-    }
+    for (int r = 0; r < 5; r++) { a[r] = alignbyte(d1[r], d0[r], s); b[r] = alignbyte(d1[r] >> (8 * s), a[r], 1); }
     // sample x of row y: (8-dx)(8-dy) A + dx (8-dy) B + (8-dx) dy C + dx dy D + 32 >> 6 as one 4-byte dot product with
     // the weights (they fit a byte: at most 64), A B adjacent in row y, C D in row y + 1
     const uint32_t wts = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
@@ -585,63 +646,106 @@ __device__ __forceinline__ void mc_chroma_block(uint32_t (&out)[4], rsrc_t rs, u
         out[y] = perm(w23, w01, 0x06040200u);
     }
 }
+// the window straight from memory, coordinates clamped to the picture (slow class only)
+__device__ __forceinline__ void mc_chroma_clamped(uint32_t (&out)[4], rsrc_t rs, uint32_t roff, const Geom &g, int p, int cx, int cy, int dx, int dy)
+{
+    const int xa = cx & ~3;
+    uint32_t d0[5], d1[5], col[2], sel[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int x = xa + 4 * k, xc = clip3i(x, 0, g.cw - 4);
+        col[k] = roff + g.coff + (uint32_t)(xc >> 3) * g.cstrip + (uint32_t)(p * 8 + (xc & 7));
+        sel[k] = x < 0 ? 0x00000000u : x >= g.cw ? 0x03030303u : 0x03020100u;
+    }
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t ro = (uint32_t)clip3i(cy + r, 0, g.ch - 1) * 16u;
+        const uint32_t v0 = bload(rs, col[0] + ro), v1 = bload(rs, col[1] + ro);
+        d0[r] = perm(v0, v0, sel[0]); d1[r] = perm(v1, v1, sel[1]);
+    }
+    chroma_bilinear(out, d0, d1, (uint32_t)cx & 3u, dx, dy);
+}
+
+#define LC_PITCH  40                // image row: strip A (8 U, 8 V) | strip B (8 U, 8 V) + 8 bytes
+#define LC_QUAD   (5 * LC_PITCH + 8)
 
 __global__ __launch_bounds__(256, 4)
-void k_mc_chroma(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+void k_mc_chroma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t images[4][MCC_CHUNK * LC_QUAD];
     const int logical = xcd_logical_block();
     if (logical >= n_wgs) return;
     int pic = (int)__umulhi((unsigned)logical, inv_wgs);
     if (logical - pic * wgs_per_pic >= wgs_per_pic) pic++;
     const PicDev *pd = pics + pic;
-    const uint32_t *mc = pd->mc;
-    const int chunk = rfl((logical - pic * wgs_per_pic) * 4 + (int)(threadIdx.x >> 6));
+    const uint32_t *mc = mc_all + (size_t)pic * ml.words;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
     if (chunk >= (int)mc[1]) return;
     const int lane = threadIdx.x & 63, p = lane & 1;
     const int key = (int)((mc[ml.off_cls_c + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);
-    const uint32_t item = gload1(mc + ml.off_list_c + chunk * MCC_CHUNK + (lane >> 1));
-    const bool valid = item != 0xffffffffu;
-    const int mbi = valid ? (int)(item >> 2) : 0, q = valid ? (int)(item & 3) : 0;
-    const uint4 rec = gload4(pd->mb + mbi);
-    const int b0 = (q >> 1) * 8 + (q & 1) * 2;
-    const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
-    const int n_ref = pd->n_ref;
-    uint32_t roff = pd->ref_off[0];
-    if (n_ref > 1) {
-        int ri = glob(pd->ref_idx)[mbi * 4 + q];
-        if (ri < 0 || ri >= n_ref) ri = 0;
-        roff = glob(pd->ref_off)[ri];
-    }
+    const uint4 e = gload4(mc + ml.off_list_c + (size_t)(chunk * MCC_CHUNK + (lane >> 1)) * 4);
+    const bool valid = e.x != 0xffffffffu;
+    const int mbi = valid ? (int)(e.x >> 2) : 0, q = valid ? (int)(e.x & 3) : 0;
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
+    uint32_t roff = pd->ref_off[0];
+    if (pd->n_ref > 1) roff = glob(pd->ref_off)[(e.w >> 26) & 15];
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;
-    const unsigned mask = rec.y;
-    const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
-    const bool has_res = valid && ((rec.x >> 20) & 3) != 0;  // cbp >> 4
-    const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+    const bool has_res = valid && ((e.w >> 8) & 3) != 0;    // cbp >> 4
     uint4 la = make_uint4(0, 0, 0, 0), lb = la; uint2 dcl = make_uint2(0, 0);
     if (key & MCC_RESID) {
-        if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
-        if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
+        const int16_t *cf = pd->coefs + (size_t)e.z * 16;  // the macroblock's chroma DC block (if present), the AC blocks behind it
+        if (has_res && ((e.w >> (11 + p)) & 1)) { const int16_t *c = cf + ((e.w >> (16 + 5 * p)) & 31) * 16; la = gload4(c); lb = gload4(c + 8); }
+        if (has_res && ((e.w >> 10) & 1)) dcl = gload2(cf + p * 4);
     }
     // ---- prediction ----
     uint32_t out[4];
     if (!(key & MCC_SLOW)) {
-        const int mvx = mv_x((int)va.x), mvy = mv_y((int)va.x);
-        mc_chroma_block<false>(out, rs, roff, g, p, CX + (mvx >> 3), CY + (mvy >> 3), mvx & 7, mvy & 7);
+        // The window of the quadrant - 5 rows x two strips x 16 bytes (8 U, 8 V) - goes through LDS like the luma windows.
+        // Four lanes = two quadrants stage together: rows 0..3 of one strip of one quadrant per load (64 contiguous bytes),
+        // then row 4 of their own strips.
+        const int mvx = mv_x((int)e.y), mvy = mv_y((int)e.y);
+        const int cx = CX + (mvx >> 3), cy = CY + (mvy >> 3), sA = cx >> 3;
+        const uint32_t own = roff + g.coff + (uint32_t)sA * g.cstrip + (uint32_t)(cy * 16), other = lane_xor2(own);
+        const int i = lane & 3;
+        uint8_t *pimg = images[wave] + (lane >> 2) * (2 * LC_QUAD);
+        u32x4 v[5];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = bload4(rs, (((j >> 1) == (i >> 1)) ? own : other) + (uint32_t)(j & 1) * g.cstrip + (uint32_t)(i * 16));
+        v[4] = bload4(rs, own + (uint32_t)(i & 1) * g.cstrip + 64u);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint8_t *dp = pimg + (j >> 1) * LC_QUAD + i * LC_PITCH + (j & 1) * 16;
+            *(uint2 *)dp = make_uint2(v[j].x, v[j].y); *(uint2 *)(dp + 8) = make_uint2(v[j].z, v[j].w);
+        }
+        {
+            uint8_t *dp = pimg + (i >> 1) * LC_QUAD + 4 * LC_PITCH + (i & 1) * 16;
+            *(uint2 *)dp = make_uint2(v[4].x, v[4].y); *(uint2 *)(dp + 8) = make_uint2(v[4].z, v[4].w);
+        }
+        wave_lds_fence();
+        const uint8_t *qimg = pimg + (i >> 1) * LC_QUAD + p * 8;
+        const int xa = cx & ~3, o0 = ((xa >> 3) - sA) * 16 + (xa & 7), o1 = (((xa + 4) >> 3) - sA) * 16 + ((xa + 4) & 7);
+        uint32_t d0[5], d1[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) { d0[r] = *(const uint32_t *)(qimg + r * LC_PITCH + o0); d1[r] = *(const uint32_t *)(qimg + r * LC_PITCH + o1); }
+        chroma_bilinear(out, d0, d1, (uint32_t)cx & 3u, mvx & 7, mvy & 7);
     } else {
-        // clamped windows; where the four 4x4 luma blocks of the quadrant have different vectors (sub-8x8 partitions) every
-        // 2x2 chroma piece follows its own vector: one pass per piece, wave-uniformly skipped when nobody needs it
+        // clamped windows straight from memory; where the four 4x4 luma blocks of the quadrant have different vectors
+        // (sub-8x8 partitions) every 2x2 chroma piece follows its own vector: one pass per piece, wave-uniformly skipped
+        // when nobody needs it
+        const int b0 = (q >> 1) * 8 + (q & 1) * 2;
+        const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
         const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
         const int v4[4] = { (int)va.x, (int)va.y, (int)vb.x, (int)vb.y };
         out[0] = out[1] = out[2] = out[3] = 0;
 #pragma unroll 1
         for (int sb = 0; sb < 4; sb++) {
-            if (sb > 0 && __ballot(!uniform) == 0) break;
+            if (sb > 0 && __ballot(valid && !uniform) == 0) break;
             const int mv = sb == 0 ? v4[0] : sb == 1 ? v4[1] : sb == 2 ? v4[2] : v4[3];
             uint32_t o[4];
-            mc_chroma_block<true>(o, rs, roff, g, p, CX + (mv_x(mv) >> 3), CY + (mv_y(mv) >> 3), mv_x(mv) & 7, mv_y(mv) & 7);
+            mc_chroma_clamped(o, rs, roff, g, p, CX + (mv_x(mv) >> 3), CY + (mv_y(mv) >> 3), mv_x(mv) & 7, mv_y(mv) & 7);
             if (uniform) { if (sb == 0) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; } }
             else {
                 const uint32_t m = (sb & 1) ? 0xffff0000u : 0x0000ffffu;
@@ -653,7 +757,7 @@ void k_mc_chroma(const PicDev *__restrict__ pics, Geom g, McLayout ml, uint32_t 
     }
     // ---- residual (decoder/macroblock.c:851-890): chroma DC through the 2x2 transform, AC, inverse transform ----
     if ((key & MCC_RESID) && __ballot(has_res)) {
-        const int qpc = chroma_qp(clip3i((int)((rec.x >> 8) & 255) + pd->chroma_qp_offset, 0, 51));
+        const int qpc = chroma_qp(clip3i((int)(e.w & 255) + pd->chroma_qp_offset, 0, 51));
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<true>(lv, col);

@@ -338,7 +338,6 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         d.dst_off = (uint32_t)(c->frame_bytes * (size_t)s.meta.dst_slot);
         for (int k = 0; k < P264HIP_MAX_REFS; k++)
             d.ref_off[k] = (uint32_t)(c->frame_bytes * (size_t)(k < s.meta.n_ref ? s.meta.ref_slot[k] : (s.meta.n_ref ? s.meta.ref_slot[0] : s.meta.dst_slot)));
-        d.mc = c->d_mc + (size_t)i * c->ml.words;
         d.n_ref = s.meta.n_ref; d.slice_type = s.meta.slice_type;
         d.chroma_qp_offset = s.meta.chroma_qp_offset; d.deblock = s.meta.deblock;
         d.alpha_off = s.meta.alpha_c0_offset; d.beta_off = s.meta.beta_offset;
@@ -354,11 +353,11 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         ScopedStamp t(c, 0);
         const McLayout ml = c->ml;
         const uint32_t inv_mbw = (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w);
-        hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], g, ml, inv_mbw);
+        hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
         const int wgs_y = (int)(ml.max_chunks_y + 3) / 4, wgs_c = (int)(ml.max_chunks_c + 3) / 4;
-        hipLaunchKernelGGL(k_mc_luma, dim3(((size_t)wgs_y * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], g, ml, inv_mbw,
+        hipLaunchKernelGGL(k_mc_luma, dim3(((size_t)wgs_y * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], (const uint32_t *)c->d_mc, g, ml, inv_mbw,
                            wgs_y, wgs_y * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs_y));
-        hipLaunchKernelGGL(k_mc_chroma, dim3(((size_t)wgs_c * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], g, ml, inv_mbw,
+        hipLaunchKernelGGL(k_mc_chroma, dim3(((size_t)wgs_c * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], (const uint32_t *)c->d_mc, g, ml, inv_mbw,
                            wgs_c, wgs_c * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs_c));
     }
     {

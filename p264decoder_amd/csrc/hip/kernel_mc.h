@@ -6,24 +6,31 @@
 // (decoder/macroblock.c:895-934), the border expansion (core/frame.c:183-222 - clamped coordinates instead, SURVEY A-Q9)
 // and the inter half of p264_macroblock_decode (decoder/macroblock.c:832-890: unscan, dequant_4x4, add4x4_idct, chroma DC).
 //
-// The first version of this stage (one wavefront per macroblock, LDS-staged windows) was bound by scalar and vector
-// instruction issue: per-macroblock header work in SGPRs, one interpolation pass per distinct vector, a shared inverse
-// transform with LDS round trips.  This version is built on three ideas:
+// The first version of this stage (one wavefront per macroblock, everything about the macroblock in SGPRs) was bound by
+// scalar and vector instruction issue.  This version is built on three ideas:
 //
-//  1. ONE LANE = ONE 4x4 BLOCK.  The lane fetches its own 9x9 (or smaller) reference window straight into registers with
-//     dword loads (strip frame layout, device_common.h: one register offset per dword column, rows as immediates),
-//     interpolates its 16 samples, runs the whole inverse transform of its block in registers (no LDS anywhere in these
-//     kernels, nothing is shared between lanes) and stores four dwords.  Every partition shape down to 4x4 is the same
-//     code: a lane only ever looks at its own vector.  All per-macroblock header work is vector work shared by 64 blocks.
+//  1. ONE LANE = ONE 4x4 BLOCK.  The lane interpolates its 16 samples from a 9x9 (or smaller) window held in registers,
+//     runs the whole inverse transform of its block in registers and stores two rows of 8 samples (after swapping halves
+//     with its neighbour lane).  Every partition shape down to 4x4 is the same code: a lane only ever looks at its own
+//     vector.  All per-macroblock header work is vector work shared by 64 blocks.
 //  2. WORK LISTS SORTED BY WHAT THE CODE HAS TO DO.  The quarter-pel phase decides the arithmetic (copy / horizontal /
-//     vertical / both / centre ...), so k_mc_sort (one workgroup per picture, a counting sort in LDS) hands the 8x8
-//     quadrants of all inter macroblocks over grouped by {phase class, window inside the picture or not, residual
-//     present or not} (and by band of macroblock rows, for cache locality).  A wavefront takes 16 quadrants of ONE key:
-//     the class is a scalar, the switch on it is free, nobody executes code it does not need - a P_SKIP macroblock at an
-//     integer position costs a few loads and stores, windows inside the picture need no clamping, wavefronts without
-//     coded blocks skip the transform.  Sorting on the device keeps the host parser and the CPU->GPU seam unchanged.
-//  3. Chroma (4x4 per quadrant and plane, bilinear) has no phase classes; it is its own kernel over its own list
-//     (inside / clamped, residual or not), 32 quadrants x 2 planes per wavefront.
+//     vertical / both / centre ...), so k_mc_sort (one workgroup per picture, a counting sort in LDS) hands the work over
+//     grouped by {phase class, window inside the picture or not, residual present or not} (and by band of macroblock
+//     rows, for cache locality).  A wavefront takes one chunk of ONE key: the class is a scalar, the switch on it is free,
+//     nobody executes code it does not need - a P_SKIP macroblock at an integer position costs a few loads and stores,
+//     windows inside the picture need no clamping, wavefronts without coded blocks skip the transform.  Sorting on the
+//     device keeps the host parser and the CPU->GPU seam unchanged.
+//  3. WINDOWS SHARED THROUGH LDS, AT THE LARGEST GRANULARITY THAT HAS ONE VECTOR.  A lane fetching its own window from
+//     memory costs one L1 tag look-up per lane and dword (measured: ~50 look-ups per load instruction, 27 loads per
+//     wavefront - the L1's look-up rate was the bound).  So the lanes of a work item stage the item's window in LDS with
+//     16-byte loads of consecutive rows of a strip (64 contiguous bytes per four lanes) and read their own 9x9 windows out
+//     of that image: one address register, rows and columns as immediates.  Work items are whole macroblocks where the
+//     macroblock has one vector (16 lanes, a 21-row window: P_SKIP, 16x16 - most of a typical stream) and 8x8 quadrants
+//     otherwise (4 lanes, a 13-row window); quadrants whose 4x4 blocks differ (sub-8x8 partitions) fetch per lane with
+//     clamped coordinates.
+//
+// Chroma (4x4 per quadrant and plane, bilinear) has no phase classes; it has its own kernel and lists (macroblock items
+// of 8 lanes, quadrant items of 2), keys {inside / clamped, residual or not}.
 //
 // Arithmetic to preserve: core/mc.c:172-266 (half-pel planes, quarter-pel averages), :303-334 (chroma),
 // core/quant.c:66-99,138-159, core/dct.c:55-68,205-247 with their int16 stores (A-Q8).
@@ -34,43 +41,43 @@
 // work lists
 // ------------------------------------------------------------------------------------------
 enum { PC_COPY = 0, PC_H = 1, PC_V = 2, PC_DIAG = 3, PC_C = 4, PC_CH = 5, PC_CV = 6, PC_GEN = 7 };
-#define MCY_CLAMP   8               // luma key bits: phase class | window not provably inside the picture | quadrant has coded luma blocks
+#define MCY_CLAMP   8               // luma key bits: phase class | window not inside the picture | item has coded luma blocks
 #define MCY_RESID   16
 #define MCY_KEYS    32
-#define MCC_SLOW    1               // chroma key bits: clamped window or vectors differing inside the quadrant | macroblock has chroma residual
+#define MCC_CLAMP   1               // chroma key bits: window not inside the picture (quadrant items: or vectors differing inside) | residual
 #define MCC_RESID   2
 #define MCC_KEYS    4
-#define MCY_CHUNK   16              // quadrants per luma wavefront (4 lanes each)
-#define MCC_CHUNK   32              // quadrants per chroma wavefront (2 lanes each: the planes)
+enum { ML_YM = 0, ML_YQ = 1, ML_CM = 2, ML_CQ = 3, ML_LISTS = 4 };      // luma macroblocks, luma quadrants, chroma macroblocks, chroma quadrants
 #define MC_MAX_BANDS 32
 #define MC_SORT_THREADS 1024
+__host__ __device__ static inline int mc_chunk_items(int l) { return l == ML_YM ? 4 : l == ML_YQ ? 16 : l == ML_CM ? 8 : 32; }   // items per wavefront
+__host__ __device__ static inline int mc_list_keys(int l) { return l < ML_CM ? MCY_KEYS : MCC_KEYS; }
 
-// Per-picture scratch written by k_mc_sort (32-bit words): [0] luma chunks, [1] chroma chunks, then one class byte per
-// chunk, then the lists.  A list entry is 16 bytes and carries everything a wavefront needs to start on the quadrant
-// without looking at the macroblock arrays again (each saved look-up is a dependent memory round trip per wavefront):
-//   luma    x = macroblock index << 2 | quadrant (0xffffffff = padding)   y = the quadrant's vector (packed)
-//           z = index of the quadrant's first packed coefficient block     w = qp | coded bits of its 4 blocks << 8 | reference index << 16
-//   chroma  x, y as above   z = index of the macroblock's chroma DC block
-//           w = qp | cbp chroma << 8 | DC present << 10 | AC coded U, V << 11 | blocks from z to the U / V AC block << 16 / << 21 | reference index << 26
-// Same layout for every picture of a batch.
+// Per-picture scratch written by k_mc_sort (32-bit words): [l] chunks in use of list l, then per list one class byte
+// per chunk, then the lists.  A list entry is 8 bytes: x = reference index << 28 | macroblock index << 2 | quadrant (low
+// 28 bits all ones = padding), y = the item's vector (packed) - all a wavefront needs to start fetching its windows
+// without looking at the macroblock arrays (each look-up is a dependent memory round trip per wavefront); only chunks
+// with residual read the macroblock record.  Same layout for every picture of a batch.
+#define MC_ITEM_MASK 0x0fffffffu
 struct McLayout {
     uint32_t band_log2, n_bands;
-    uint32_t max_chunks_y, max_chunks_c;
-    uint32_t off_cls_y, off_cls_c, off_list_y, off_list_c, words;
+    uint32_t max_chunks[ML_LISTS], off_cls[ML_LISTS], off_list[ML_LISTS], words;
 };
 static inline McLayout mc_layout(int mb_w, int mb_h, int band_log2)
 {
     McLayout L;
     L.band_log2 = (uint32_t)band_log2;
     L.n_bands = (uint32_t)((mb_h + (1 << band_log2) - 1) >> band_log2);
-    const uint32_t items = (uint32_t)(mb_w * mb_h) * 4u;
-    L.max_chunks_y = (items + L.n_bands * MCY_KEYS * (MCY_CHUNK - 1)) / MCY_CHUNK + 1;
-    L.max_chunks_c = (items + L.n_bands * MCC_KEYS * (MCC_CHUNK - 1)) / MCC_CHUNK + 1;
-    L.off_cls_y = 16;
-    L.off_cls_c = L.off_cls_y + (L.max_chunks_y + 3) / 4;
-    L.off_list_y = (L.off_cls_c + (L.max_chunks_c + 3) / 4 + 15) & ~15u;
-    L.off_list_c = L.off_list_y + L.max_chunks_y * MCY_CHUNK * 4;
-    L.words = (L.off_list_c + L.max_chunks_c * MCC_CHUNK * 4 + 63) & ~63u;
+    const uint32_t n_mb = (uint32_t)(mb_w * mb_h);
+    uint32_t at = 16;
+    for (int l = 0; l < ML_LISTS; l++) {
+        const uint32_t items = (l == ML_YM || l == ML_CM) ? n_mb : n_mb * 4u, per = (uint32_t)mc_chunk_items(l);
+        L.max_chunks[l] = (items + L.n_bands * (uint32_t)mc_list_keys(l) * (per - 1)) / per + 1;
+        L.off_cls[l] = at; at += (L.max_chunks[l] + 3) / 4;
+    }
+    at = (at + 15) & ~15u;
+    for (int l = 0; l < ML_LISTS; l++) { L.off_list[l] = at; at += L.max_chunks[l] * (uint32_t)mc_chunk_items(l) * 2u; }
+    L.words = (at + 63) & ~63u;
     return L;
 }
 
@@ -88,102 +95,132 @@ __device__ __forceinline__ int phase_class(int fx, int fy)
     return PC_CV;
 }
 
-struct McItem { int ky, kc; uint4 ey, ec; };       // keys (-1: nothing to do, intra macroblock) and the two list entries
-__device__ __forceinline__ McItem mc_item(const PicDev *pd, const Geom &g, uint32_t item, uint32_t inv_mbw, int band_log2, bool entries)
+// What one inter macroblock contributes: either one macroblock item per plane kind (one vector, one reference) or its
+// four quadrants.  key[] / ex[] / ey[] per entry; n = 1 or 4.
+struct McMb { bool inter, whole; int ky[4], kc[4]; uint32_t ex[4], ey[4]; };
+__device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int mbi, uint32_t inv_mbw, int band_log2)
 {
-    const int mbi = (int)(item >> 2), q = (int)(item & 3);
+    McMb k;
     const uint4 rec = gload4(pd->mb + mbi);
-    McItem k;
-    k.ky = k.kc = -1;
-    if (P264_MB_IS_INTRA(rec.x & 255)) return k;
-    const int b0 = (q >> 1) * 8 + (q & 1) * 2;
-    const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
-    const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
+    const int *mvp = pd->mv + mbi * 16;
+    const uint4 m0 = gload4(mvp), m1 = gload4(mvp + 4), m2 = gload4(mvp + 8), m3 = gload4(mvp + 12);
+    const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
+    k.inter = !P264_MB_IS_INTRA(rec.x & 255);
     int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
     if (mbi - mby * g.mb_w >= g.mb_w) mby++;
-    const int mbx = mbi - mby * g.mb_w;
-    const int X0 = mbx * 16 + (q & 1) * 8, Y0 = mby * 16 + (q >> 1) * 8;
-    const int mvx = mv_x((int)va.x), mvy = mv_y((int)va.x);
-    // luma: the four lanes of the quadrant read dwords inside [wx & ~3, wx + 16) x [wy, wy + 13)
-    const int wx = X0 + (mvx >> 2) - 2, wy = Y0 + (mvy >> 2) - 2;
-    const bool in_y = wx >= 0 && wx <= g.w - 16 && wy >= 0 && wy <= g.h - 13;
-    const int cx = X0 / 2 + (mvx >> 3), cy = Y0 / 2 + (mvy >> 3);
-    const bool in_c = cx >= 0 && cx <= g.cw - 8 && cy >= 0 && cy <= g.ch - 5;
-    const int band = mby >> band_log2;
-    const unsigned mask = rec.y, cc = (rec.x >> 20) & 3, m4 = (mask >> (4 * q)) & 15;
-    int pc = phase_class(mvx & 3, mvy & 3), fl = in_y ? 0 : MCY_CLAMP;
-    if (!uniform) { pc = PC_GEN; fl = MCY_CLAMP; }
-    if (m4) fl |= MCY_RESID;
-    k.ky = band * MCY_KEYS + (pc | fl);
-    k.kc = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_SLOW) + (cc ? MCC_RESID : 0);
-    if (entries) {
-        int ri = glob(pd->ref_idx)[mbi * 4 + q];
-        if (ri < 0 || ri >= pd->n_ref) ri = 0;             // negative or past the list: entry 0, as the reference's flat lists
-        const uint32_t qp = (rec.x >> 8) & 255, ldc = (mask >> 24) & 1, cdc = (mask >> 25) & 1;
-        k.ey = make_uint4(item, va.x, rec.z + coef_slot(mask, 4 * q), qp | m4 << 8 | (uint32_t)ri << 16);
-        const uint32_t offU = cdc + __popc(mask & ((1u << (16 + q)) - 1u) & 0xffffffu), offV = cdc + __popc(mask & ((1u << (20 + q)) - 1u) & 0xffffffu);
-        k.ec = make_uint4(item, va.x, rec.z + ldc,
-                          qp | cc << 8 | cdc << 10 | ((mask >> (16 + q)) & 1) << 11 | ((mask >> (20 + q)) & 1) << 12 | offU << 16 | offV << 21 | (uint32_t)ri << 26);
+    const int mbx = mbi - mby * g.mb_w, band = mby >> band_log2;
+    const unsigned mask = rec.y, cc = (rec.x >> 20) & 3;
+    const int n_ref = pd->n_ref;
+    int ri[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        ri[q] = (int)(int8_t)(refs >> (8 * q));
+        if (ri[q] < 0 || ri[q] >= n_ref) ri[q] = 0;        // negative or past the list: entry 0, as the reference's flat lists
+    }
+    const uint32_t v0 = m0.x;
+    const uint32_t diff = (m0.y ^ v0) | (m0.z ^ v0) | (m0.w ^ v0) | (m1.x ^ v0) | (m1.y ^ v0) | (m1.z ^ v0) | (m1.w ^ v0) | (m2.x ^ v0) | (m2.y ^ v0)
+                        | (m2.z ^ v0) | (m2.w ^ v0) | (m3.x ^ v0) | (m3.y ^ v0) | (m3.z ^ v0) | (m3.w ^ v0);
+    k.whole = diff == 0 && ri[0] == ri[1] && ri[0] == ri[2] && ri[0] == ri[3];
+    if (k.whole) {
+        const int mvx = mv_x((int)v0), mvy = mv_y((int)v0);
+        const int wx = mbx * 16 + (mvx >> 2) - 2, wy = mby * 16 + (mvy >> 2) - 2;      // 21 x 21 samples
+        const bool in_y = wx >= 0 && wx + 21 <= g.w && wy >= 0 && wy + 21 <= g.h;
+        const int cx = mbx * 8 + (mvx >> 3), cy = mby * 8 + (mvy >> 3);                 // 9 x 9 samples
+        const bool in_c = cx >= 0 && cx + 9 <= g.cw && cy >= 0 && cy + 9 <= g.ch;
+        k.ky[0] = band * MCY_KEYS + (phase_class(mvx & 3, mvy & 3) | (in_y ? 0 : MCY_CLAMP) | ((mask & 0xffffu) ? MCY_RESID : 0));
+        k.kc[0] = band * MCC_KEYS + (in_c ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
+        k.ex[0] = (uint32_t)ri[0] << 28 | (uint32_t)mbi << 2;
+        k.ey[0] = v0;
+        return k;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        // vectors of the quadrant's four 4x4 blocks (raster inside the macroblock: b0, b0+1, b0+4, b0+5)
+        const uint4 top = q < 2 ? m0 : m2, bot = q < 2 ? m1 : m3;
+        const uint32_t va = (q & 1) ? top.z : top.x, vb = (q & 1) ? top.w : top.y, vc = (q & 1) ? bot.z : bot.x, vd = (q & 1) ? bot.w : bot.y;
+        const bool uniform = va == vb && va == vc && va == vd;
+        const int X0 = mbx * 16 + (q & 1) * 8, Y0 = mby * 16 + (q >> 1) * 8;
+        const int mvx = mv_x((int)va), mvy = mv_y((int)va);
+        const int wx = X0 + (mvx >> 2) - 2, wy = Y0 + (mvy >> 2) - 2;                   // 13 x 13 samples
+        const bool in_y = wx >= 0 && wx + 13 <= g.w && wy >= 0 && wy + 13 <= g.h;
+        const int cx = X0 / 2 + (mvx >> 3), cy = Y0 / 2 + (mvy >> 3);                   // 5 x 5 samples
+        const bool in_c = cx >= 0 && cx + 5 <= g.cw && cy >= 0 && cy + 5 <= g.ch;
+        int pc = phase_class(mvx & 3, mvy & 3), fl = in_y ? 0 : MCY_CLAMP;
+        if (!uniform) { pc = PC_GEN; fl = MCY_CLAMP; }
+        if ((mask >> (4 * q)) & 15) fl |= MCY_RESID;
+        k.ky[q] = band * MCY_KEYS + (pc | fl);
+        k.kc[q] = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
+        k.ex[q] = (uint32_t)ri[q] << 28 | (uint32_t)mbi << 2 | (uint32_t)q;
+        k.ey[q] = va;
     }
     return k;
 }
 
-// One workgroup per picture: count the keys, lay the key segments out (each padded to whole chunks), scatter the items.
+// One workgroup per picture, one thread per macroblock: count the keys of the four lists, lay the key segments out (each
+// padded to whole chunks), scatter the entries.
+#define MC_KEY_SLOTS (2 * MC_MAX_BANDS * MCY_KEYS + 2 * MC_MAX_BANDS * MCC_KEYS)
 __global__ __launch_bounds__(MC_SORT_THREADS)
 void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
 {
-    __shared__ uint32_t cnt_y[MC_MAX_BANDS * MCY_KEYS], cnt_c[MC_MAX_BANDS * MCC_KEYS];
-    __shared__ uint32_t pos_y[MC_MAX_BANDS * MCY_KEYS], pos_c[MC_MAX_BANDS * MCC_KEYS];
+    __shared__ uint32_t cnt[MC_KEY_SLOTS], pos[MC_KEY_SLOTS];
     const PicDev *pd = pics + blockIdx.x;
     uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
     const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
+    const int b_ym = 0, b_yq = nky, b_cm = 2 * nky, b_cq = 2 * nky + nkc, b_end = 2 * nky + 2 * nkc;     // key slots of the four lists
     const int tid = threadIdx.x;
     if (pd->slice_type != P264_SLICE_P) {                 // wave-uniform
-        if (tid == 0) { gstore1(out, 0); gstore1(out + 1, 0); }
+        if (tid < ML_LISTS) gstore1(out + tid, 0);
         return;
     }
-    for (int k = tid; k < nky; k += MC_SORT_THREADS) cnt_y[k] = 0;
-    for (int k = tid; k < nkc; k += MC_SORT_THREADS) cnt_c[k] = 0;
+    for (int k = tid; k < b_end; k += MC_SORT_THREADS) cnt[k] = 0;
     __syncthreads();
-    const uint32_t n_items = (uint32_t)g.n_mb * 4u;
-    for (uint32_t it = tid; it < n_items; it += MC_SORT_THREADS) {
-        const McItem k = mc_item(pd, g, it, inv_mbw, (int)ml.band_log2, false);
-        if (k.ky >= 0) { atomicAdd(&cnt_y[k.ky], 1u); atomicAdd(&cnt_c[k.kc], 1u); }
-    }
-    __syncthreads();
-    // segment starts: every thread sums the padded counts in front of its key (a few hundred LDS reads at most), notes the
-    // key's class bits for each of its chunks, and the thread of the last key writes the number of chunks in use
-    for (int k = tid; k < nky + nkc; k += MC_SORT_THREADS) {
-        const bool is_y = k < nky;
-        const int kk = is_y ? k : k - nky, nk = is_y ? nky : nkc;
-        const uint32_t *cnt = is_y ? cnt_y : cnt_c;
-        const uint32_t chunk = is_y ? MCY_CHUNK : MCC_CHUNK;
-        uint32_t start = 0;
-        for (int j = 0; j < kk; j++) start += (cnt[j] + chunk - 1) / chunk;
-        const uint32_t n = (cnt[kk] + chunk - 1) / chunk;                       // chunks of this key, from chunk `start`
-        (is_y ? pos_y : pos_c)[kk] = start * chunk;
-        AS1 uint8_t *cls = glob((uint8_t *)(out + (is_y ? ml.off_cls_y : ml.off_cls_c)));
-        const uint8_t v = (uint8_t)(kk % (is_y ? MCY_KEYS : MCC_KEYS));
-        for (uint32_t c = 0; c < n; c++) cls[start + c] = v;
-        if (kk == nk - 1) gstore1(out + (is_y ? 0 : 1), start + n);
-    }
-    __syncthreads();
-    uint32_t *list_y = out + ml.off_list_y, *list_c = out + ml.off_list_c;
-    for (uint32_t it = tid; it < n_items; it += MC_SORT_THREADS) {
-        const McItem k = mc_item(pd, g, it, inv_mbw, (int)ml.band_log2, true);
-        if (k.ky >= 0) {
-            gstore4(list_y + 4 * atomicAdd(&pos_y[k.ky], 1u), k.ey);
-            gstore4(list_c + 4 * atomicAdd(&pos_c[k.kc], 1u), k.ec);
+    for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) {
+        const McMb k = mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2);
+        if (!k.inter) continue;
+        if (k.whole) { atomicAdd(&cnt[b_ym + k.ky[0]], 1u); atomicAdd(&cnt[b_cm + k.kc[0]], 1u); }
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { atomicAdd(&cnt[b_yq + k.ky[q]], 1u); atomicAdd(&cnt[b_cq + k.kc[q]], 1u); }
         }
     }
     __syncthreads();
-    for (int k = tid; k < nky + nkc; k += MC_SORT_THREADS) {      // padding entries behind every segment
-        const bool is_y = k < nky;
-        const int kk = is_y ? k : k - nky;
-        const uint32_t chunk = is_y ? MCY_CHUNK : MCC_CHUNK;
-        const uint32_t end = (is_y ? pos_y : pos_c)[kk];
-        uint32_t *list = is_y ? list_y : list_c;
-        for (uint32_t p = end; p < (end + chunk - 1) / chunk * chunk; p++) gstore4(list + 4 * p, make_uint4(0xffffffffu, 0, 0, 0));
+    // segment starts: every thread sums the padded counts in front of its key (a few hundred LDS reads at most), notes the
+    // key's class bits for each of its chunks, and the thread of a list's last key writes the number of chunks in use
+    for (int k = tid; k < b_end; k += MC_SORT_THREADS) {
+        const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
+        const int first = l == ML_YM ? b_ym : l == ML_YQ ? b_yq : l == ML_CM ? b_cm : b_cq;
+        const int kk = k - first, nk = l < ML_CM ? nky : nkc;
+        const uint32_t per = (uint32_t)mc_chunk_items(l);
+        uint32_t start = 0;
+        for (int j = 0; j < kk; j++) start += (cnt[first + j] + per - 1) / per;
+        const uint32_t n = (cnt[k] + per - 1) / per;                            // chunks of this key, from chunk `start`
+        pos[k] = start * per;
+        AS1 uint8_t *cls = glob((uint8_t *)(out + (l == ML_YM ? ml.off_cls[ML_YM] : l == ML_YQ ? ml.off_cls[ML_YQ] : l == ML_CM ? ml.off_cls[ML_CM] : ml.off_cls[ML_CQ])));
+        const uint8_t v = (uint8_t)(kk % mc_list_keys(l));
+        for (uint32_t c = 0; c < n; c++) cls[start + c] = v;
+        if (kk == nk - 1) gstore1(out + l, start + n);
+    }
+    __syncthreads();
+    for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) {
+        const McMb k = mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2);
+        if (!k.inter) continue;
+        if (k.whole) {
+            gstore2(out + ml.off_list[ML_YM] + 2 * atomicAdd(&pos[b_ym + k.ky[0]], 1u), make_uint2(k.ex[0], k.ey[0]));
+            gstore2(out + ml.off_list[ML_CM] + 2 * atomicAdd(&pos[b_cm + k.kc[0]], 1u), make_uint2(k.ex[0], k.ey[0]));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                gstore2(out + ml.off_list[ML_YQ] + 2 * atomicAdd(&pos[b_yq + k.ky[q]], 1u), make_uint2(k.ex[q], k.ey[q]));
+                gstore2(out + ml.off_list[ML_CQ] + 2 * atomicAdd(&pos[b_cq + k.kc[q]], 1u), make_uint2(k.ex[q], k.ey[q]));
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < b_end; k += MC_SORT_THREADS) {                      // padding entries behind every segment
+        const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
+        const uint32_t per = (uint32_t)mc_chunk_items(l), end = pos[k];
+        const uint32_t lo = l == ML_YM ? ml.off_list[ML_YM] : l == ML_YQ ? ml.off_list[ML_YQ] : l == ML_CM ? ml.off_list[ML_CM] : ml.off_list[ML_CQ];
+        for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore2(out + lo + 2 * p, make_uint2(0xffffffffu, 0));
     }
 }
 
@@ -223,56 +260,65 @@ __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__b
 // ------------------------------------------------------------------------------------------
 // d[r][k] = the aligned dword k of window row r.  The window starts at sample (xw, yw); xa = xw & ~3 is the first dword.
 // Rows R0 .. R0+NR-1 and NC dword columns are fetched.  Two sources:
-//
-// LWin - the normal case.  A lane fetching its own window from memory costs one L1 tag look-up per lane and dword (the
-// first version of this kernel did exactly that and was bound by the L1's look-up rate: ~50 look-ups per load instruction,
-// 27 loads).  So the four lanes of a quadrant stage the quadrant's window - 13 rows x two strips x 16 bytes - in LDS
-// with 16-byte loads of consecutive rows (64 contiguous bytes per four lanes: one or two look-ups), and every lane reads
-// its window out of that image: one address register, rows and columns as immediates.
-//
+// LWin - out of the work item's image in LDS (see the file header): one address register, rows and columns as immediates.
 // GWin - straight from memory with clamped coordinates; only for quadrants whose 4x4 blocks have different vectors
-// (sub-8x8 partitions), where there is no common window.
-#define LY_PITCH   40               // image row: 32 samples (strip A | strip B) + 8 bytes so that rows spread over the banks
-#define LY_QUAD    (13 * LY_PITCH + 8)
+//        (sub-8x8 partitions), where there is no common window.
+//
+// Luma work items: MB = a whole macroblock (16 lanes, window 21 rows x 3 strips) or an 8x8 quadrant (4 lanes, 13 rows x 2
+// strips).  Image row = the strips side by side + 4 bytes so that rows spread over the LDS banks.
+template <bool MB> struct YItem {
+    static constexpr int LANES = MB ? 16 : 4, PER_WAVE = 64 / LANES, STRIPS = MB ? 3 : 2, ROWS = MB ? 21 : 13;
+    static constexpr int PITCH = STRIPS * 16 + 4, BYTES = ROWS * PITCH + 4;
+};
 
-// Stage rows R0S .. R0S+NRS-1 of the window whose top-left sample is (wx, wy); li = lane & 3.  CLAMP: coordinates clamped
-// to the picture = the reference's replicated borders (core/frame.c:183-222, A-Q9): a strip that lies outside the picture
-// becomes the replicated first (last) sample of the row.
-template <int R0S, int NRS, bool CLAMP>
-__device__ __forceinline__ void stage_luma(uint8_t *qimg, rsrc_t rs, uint32_t roff, const Geom &g, int wx, int wy, int li)
+// Stage rows R0S .. R0S+NRS-1 of the window whose top-left sample is (wx, wy); li = lane inside the item.  Piece p = strip
+// p / NRS, row p % NRS: consecutive lanes fetch consecutive rows of one strip (64 contiguous bytes per four lanes).  A
+// macroblock window reaches into its third strip only when it starts in the last 12 samples of a strip: `third` says so.
+// CLAMP: coordinates clamped to the picture = the reference's replicated borders (core/frame.c:183-222, A-Q9): a strip
+// that lies outside the picture becomes the replicated first (last) sample of the row.
+template <bool MB, int R0S, int NRS, bool CLAMP>
+__device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t roff, const Geom &g, int wx, int wy, int li, bool third)
 {
-    constexpr int NP = 2 * NRS, NJ = (NP + 3) / 4;
+    typedef YItem<MB> I;
+    constexpr int NP = I::STRIPS * NRS, NJ = (NP + I::LANES - 1) / I::LANES;
     const int sA = wx >> 4;
     u32x4 v[NJ];
     int dst[NJ];
+    bool on[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-        const int p = min(li + 4 * j, NP - 1), s = p >= NRS ? 1 : 0, row = R0S + p - s * NRS;
-        dst[j] = row * LY_PITCH + s * 16;
-        if (!CLAMP) v[j] = bload4(rs, roff + (uint32_t)(sA + s) * g.ystrip + (uint32_t)((wy + row) * 16));
-        else {
-            const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
-            u32x4 t = bload4(rs, roff + (uint32_t)sc * g.ystrip + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
-            if (st < 0) { const uint32_t e = perm(t.x, t.x, 0x00000000u); t.x = t.y = t.z = t.w = e; }
-            if (st >= g.mb_w) { const uint32_t e = perm(t.w, t.w, 0x03030303u); t.x = t.y = t.z = t.w = e; }
-            v[j] = t;
+        const int p = min(li + I::LANES * j, NP - 1), s = p >= 2 * NRS ? 2 : p >= NRS ? 1 : 0, row = R0S + p - s * NRS;
+        dst[j] = row * I::PITCH + s * 16;
+        on[j] = !MB || s < 2 || third;
+        v[j] = u32x4{ 0, 0, 0, 0 };
+        if (on[j]) {
+            if (!CLAMP) v[j] = bload4(rs, roff + (uint32_t)(sA + s) * g.ystrip + (uint32_t)((wy + row) * 16));
+            else {
+                const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
+                u32x4 t = bload4(rs, roff + (uint32_t)sc * g.ystrip + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
+                if (st < 0) { const uint32_t e = perm(t.x, t.x, 0x00000000u); t.x = t.y = t.z = t.w = e; }
+                if (st >= g.mb_w) { const uint32_t e = perm(t.w, t.w, 0x03030303u); t.x = t.y = t.z = t.w = e; }
+                v[j] = t;
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-        *(uint2 *)(qimg + dst[j]) = make_uint2(v[j].x, v[j].y);
-        *(uint2 *)(qimg + dst[j] + 8) = make_uint2(v[j].z, v[j].w);
+        if (on[j]) {
+            uint32_t *o = (uint32_t *)(img + dst[j]);       // (4-byte aligned: pairs of dwords)
+            o[0] = v[j].x; o[1] = v[j].y; o[2] = v[j].z; o[3] = v[j].w;
+        }
     }
 }
-struct LWin {
-    const uint8_t *qimg; int x0, y0;                       // the image's sample (0,0) is (x0, y0) of the reference
+template <int PITCH> struct LWin {
+    const uint8_t *img; int x0, y0;                        // the image's sample (0,0) is (x0, y0) of the reference
     template <int R0, int NR, int NC> __device__ __forceinline__ void load(uint32_t (&d)[9][3], int xw, int yw) const
     {
-        const uint8_t *b = qimg + (yw - y0) * LY_PITCH + ((xw & ~3) - x0);
+        const uint8_t *b = img + (yw - y0) * PITCH + ((xw & ~3) - x0);
 #pragma unroll
         for (int r = R0; r < R0 + NR; r++)
 #pragma unroll
-            for (int k = 0; k < NC; k++) d[r][k] = *(const uint32_t *)(b + r * LY_PITCH + 4 * k);
+            for (int k = 0; k < NC; k++) d[r][k] = *(const uint32_t *)(b + r * PITCH + 4 * k);
     }
 };
 struct GWin {
@@ -526,12 +572,15 @@ __device__ __forceinline__ int xcd_logical_block()
 }
 
 // ------------------------------------------------------------------------------------------
-// k_mc_luma: one wavefront = one chunk of 16 quadrants of one key; lane = (quadrant lane >> 2, 4x4 block lane & 3)
+// k_mc_luma<MB>: one wavefront = one chunk of one key: 4 macroblock items of 16 lanes, or 16 quadrant items of 4 lanes;
+// the lane is one 4x4 block
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4)
-void k_mc_luma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+template <bool MB>
+__device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g,
+                                             const McLayout &ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t images[4][MCY_CHUNK * LY_QUAD];
+    typedef YItem<MB> I;
+    constexpr int LIST = MB ? ML_YM : ML_YQ;
     const int logical = xcd_logical_block();
     if (logical >= n_wgs) return;
     int pic = (int)__umulhi((unsigned)logical, inv_wgs);
@@ -540,48 +589,60 @@ void k_mc_luma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_
     const uint32_t *mc = mc_all + (size_t)pic * ml.words;  // (addresses from kernel arguments only: the first loads depend on nothing)
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
-    if (chunk >= (int)mc[0]) return;
-    const int lane = threadIdx.x & 63;
-    const int key = (int)((mc[ml.off_cls_y + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);     // scalar: the chunk's key bits
+    if (chunk >= (int)mc[LIST]) return;
+    const int lane = threadIdx.x & 63, li = lane & (I::LANES - 1), it = lane / I::LANES;
+    const int key = (int)((mc[ml.off_cls[LIST] + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);     // scalar: the chunk's key bits
     const int pc = key & 7;
-    const uint4 e = gload4(mc + ml.off_list_y + (size_t)(chunk * MCY_CHUNK + (lane >> 2)) * 4);
-    const bool valid = e.x != 0xffffffffu;
-    const int mbi = valid ? (int)(e.x >> 2) : 0, q = valid ? (int)(e.x & 3) : 0;
-    const int bx = (q & 1) * 2 + (lane & 1), by = (q >> 1) * 2 + ((lane >> 1) & 1);     // block position inside the macroblock
+    const uint2 e = gload2(mc + ml.off_list[LIST] + (size_t)(chunk * I::PER_WAVE + it) * 2);
+    const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
+    const int mbi = valid ? (int)((e.x & MC_ITEM_MASK) >> 2) : 0;
+    // block position inside the macroblock
+    const int q = MB ? 0 : (valid ? (int)(e.x & 3) : 0);
+    const int bx = MB ? (li & 3) : (q & 1) * 2 + (li & 1), by = MB ? (li >> 2) : (q >> 1) * 2 + (li >> 1);
+    // chunks with residual: the macroblock record (QP, coded-block mask, place in the coefficient stream)
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (key & MCY_RESID) rec = gload4(pd->mb + mbi);
     int mvp = (int)e.y;
-    if (pc == PC_GEN) mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);          // sub-8x8 partitions: the block's own vector
+    if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     uint32_t roff = pd->ref_off[0];
-    if (pd->n_ref > 1) roff = glob(pd->ref_off)[(e.w >> 16) & 15];                  // (wave-uniform branch)
+    if (pd->n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];                         // (wave-uniform branch)
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
     const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
-    const unsigned m4 = (e.w >> 8) & 15;                   // coded bits of the quadrant's blocks, decode order = lane & 3
-    const bool coded = valid && ((m4 >> (lane & 3)) & 1);
-    // coded levels are requested before the window (the reads are independent)
+    const unsigned mask = rec.y;
+    const int blk = blk_at(bx, by);                        // decode-order index: bit of coef_mask, position in the packed stream
+    const bool coded = valid && ((mask >> blk) & 1);
+    // coded levels (the record was requested before the windows, the levels fly while the prediction is computed)
     uint4 la = make_uint4(0, 0, 0, 0), lb = la;
-    if (key & MCY_RESID) {
-        if (coded) {
-            const int16_t *cf = pd->coefs + ((size_t)e.z + __popc(m4 & ((1u << (lane & 3)) - 1u))) * 16;
-            la = gload4(cf); lb = gload4(cf + 8);
-        }
-    }
     // ---- prediction ----
     uint32_t out[4];
-    if (pc != PC_GEN) {
-        // the quadrant's window (all four lanes hold the same vector): top-left sample (wx, wy), staged in LDS
-        const int wx = ix - (lane & 1) * 4 - 2, wy = iy - ((lane >> 1) & 1) * 4 - 2;
-        uint8_t *qimg = images[wave] + (lane >> 2) * LY_QUAD;
-        const bool rows8 = pc <= PC_H;                     // copy / horizontal: rows 2..9 of the window only
-        if (!(key & MCY_CLAMP)) { if (rows8) stage_luma<2, 8, false>(qimg, rs, roff, g, wx, wy, lane & 3); else stage_luma<0, 13, false>(qimg, rs, roff, g, wx, wy, lane & 3); }
-        else                    { if (rows8) stage_luma<2, 8, true>(qimg, rs, roff, g, wx, wy, lane & 3);  else stage_luma<0, 13, true>(qimg, rs, roff, g, wx, wy, lane & 3); }
+    if (MB || pc != PC_GEN) {
+        // the item's window (all its lanes hold the same vector): top-left sample (wx, wy), staged in LDS
+        const int ox = MB ? bx * 4 : (li & 1) * 4, oy = MB ? by * 4 : (li >> 1) * 4;
+        const int wx = ix - ox - 2, wy = iy - oy - 2;
+        uint8_t *img = images + (wave * I::PER_WAVE + it) * I::BYTES;
+        const bool rows_mid = pc <= PC_H;                  // copy / horizontal: no rows above and below the blocks
+        // (macroblock items) the window's last dword, read by the lanes of the right-most block column, decides about strip 3
+        const bool third = MB && ((((wx + 12) & ~3) + 11) >> 4) - (wx >> 4) >= 2;
+        constexpr int RM = MB ? 16 : 8;
+        if (!(key & MCY_CLAMP)) { if (rows_mid) stage_luma<MB, 2, RM, false>(img, rs, roff, g, wx, wy, li, third); else stage_luma<MB, 0, I::ROWS, false>(img, rs, roff, g, wx, wy, li, third); }
+        else                    { if (rows_mid) stage_luma<MB, 2, RM, true>(img, rs, roff, g, wx, wy, li, third);  else stage_luma<MB, 0, I::ROWS, true>(img, rs, roff, g, wx, wy, li, third); }
+        if ((key & MCY_RESID) && coded) {
+            const int16_t *cf = pd->coefs + ((size_t)rec.z + coef_slot(mask, blk)) * 16;
+            la = gload4(cf); lb = gload4(cf + 8);
+        }
         wave_lds_fence();
-        const LWin w = { qimg, (wx >> 4) * 16, wy };
+        const LWin<I::PITCH> w = { img, (wx >> 4) * 16, wy };
         mc_luma_class(pc, out, w, ix, iy, fx, fy);
     } else {
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
         // straight from memory, one pass per phase class present among the lanes.
+        if ((key & MCY_RESID) && coded) {
+            const int16_t *cf = pd->coefs + ((size_t)rec.z + coef_slot(mask, blk)) * 16;
+            la = gload4(cf); lb = gload4(cf + 8);
+        }
         out[0] = out[1] = out[2] = out[3] = 0;
         const GWin w = { rs, roff, g };
         const int mine = phase_class(fx, fy);
@@ -602,28 +663,41 @@ void k_mc_luma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<false>(lv, col);
-        dequant_cols(col, (int)(e.w & 255));
+        dequant_cols(col, (int)((rec.x >> 8) & 255));
         uint32_t px[4] = { out[0], out[1], out[2], out[3] };
         idct_add(col, px);
         if (coded) { out[0] = px[0]; out[1] = px[1]; out[2] = px[2]; out[3] = px[3]; }
     }
     // ---- store: the two lanes of a block row swap halves, so that a lane writes two rows of 8 samples (four lanes: eight
-    // consecutive rows of the quadrant, one or two cache lines) instead of four rows of 4 ----
+    // consecutive rows, one or two cache lines) instead of four rows of 4 ----
     {
-        const bool right = lane & 1;
+        const bool right = bx & 1;
         const uint32_t g0 = lane_xor1(right ? out[0] : out[2]), g1 = lane_xor1(right ? out[1] : out[3]);
-        const uint32_t r0a = right ? g0 : out[0], r0b = right ? out[2] : g0;       // row 4*by' + 2*right: samples 0-3, 4-7
+        const uint32_t r0a = right ? g0 : out[0], r0b = right ? out[2] : g0;       // row 4*by + 2*right: samples 0-3, 4-7
         const uint32_t r1a = right ? g1 : out[1], r1b = right ? out[3] : g1;       // the row below
         if (valid) {
-            const uint32_t o = pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + (right ? 2 : 0)) * 16 + (q & 1) * 8);
+            const uint32_t o = pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + (right ? 2 : 0)) * 16 + (bx >> 1) * 8);
             bstore2(rs, o, r0a, r0b);
             bstore2(rs, o + 16, r1a, r1b);
         }
     }
 }
+__global__ __launch_bounds__(256, 4)
+void k_mc_luma_mb(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 4 * YItem<true>::BYTES];
+    mc_luma_body<true>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
+}
+__global__ __launch_bounds__(256, 4)
+void k_mc_luma_quad(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 16 * YItem<false>::BYTES];
+    mc_luma_body<false>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
+}
 
 // ------------------------------------------------------------------------------------------
-// k_mc_chroma: one wavefront = one chunk of 32 quadrants; lane = (quadrant lane >> 1, plane lane & 1): a 4x4 chroma block
+// k_mc_chroma<MB>: one wavefront = one chunk: 8 macroblock items of 8 lanes or 32 quadrant items of 2 lanes;
+// the lane is one 4x4 chroma block (quadrant, plane)
 // ------------------------------------------------------------------------------------------
 // 1/8-pel bilinear (core/mc.c:303-334) of one 4x4 block from the two aligned dwords d0, d1 of five window rows; the
 // block's first sample is byte s of d0; weights (dx, dy)
@@ -666,13 +740,32 @@ __device__ __forceinline__ void mc_chroma_clamped(uint32_t (&out)[4], rsrc_t rs,
     chroma_bilinear(out, d0, d1, (uint32_t)cx & 3u, dx, dy);
 }
 
-#define LC_PITCH  40                // image row: strip A (8 U, 8 V) | strip B (8 U, 8 V) + 8 bytes
-#define LC_QUAD   (5 * LC_PITCH + 8)
 
-__global__ __launch_bounds__(256, 4)
-void k_mc_chroma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+// Chroma work items: image row = strip A (8 U, 8 V) | strip B (8 U, 8 V) + 8 bytes; a macroblock window has 9 rows, a
+// quadrant window 5.
+template <bool MB> struct CItem {
+    static constexpr int LANES = MB ? 8 : 2, PER_WAVE = 64 / LANES, ROWS = MB ? 9 : 5;
+    static constexpr int PITCH = 40, BYTES = ROWS * PITCH + 8;
+};
+// one 16-byte row piece of a chroma strip, coordinates clamped to the picture if CLAMP (a strip outside becomes the
+// replicated first / last sample of each plane's 8 bytes)
+template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece(rsrc_t rs, uint32_t roff, const Geom &g, int strip, int y)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t images[4][MCC_CHUNK * LC_QUAD];
+    if (!CLAMP) return bload4(rs, roff + g.coff + (uint32_t)strip * g.cstrip + (uint32_t)(y * 16));
+    const int sc = clip3i(strip, 0, g.mb_w - 1);             // (a chroma strip is 8 samples wide: one per macroblock column)
+    u32x4 t = bload4(rs, roff + g.coff + (uint32_t)sc * g.cstrip + (uint32_t)(clip3i(y, 0, g.ch - 1) * 16));
+    if (strip < 0) { const uint32_t u = perm(t.x, t.x, 0x00000000u), v = perm(t.z, t.z, 0x00000000u); t.x = t.y = u; t.z = t.w = v; }
+    if (strip >= g.mb_w) { const uint32_t u = perm(t.y, t.y, 0x03030303u), v = perm(t.w, t.w, 0x03030303u); t.x = t.y = u; t.z = t.w = v; }
+    return t;
+}
+__device__ __forceinline__ void lds_put16(uint8_t *p, u32x4 v) { *(uint2 *)p = make_uint2(v.x, v.y); *(uint2 *)(p + 8) = make_uint2(v.z, v.w); }
+
+template <bool MB>
+__device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g,
+                                               const McLayout &ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    typedef CItem<MB> I;
+    constexpr int LIST = MB ? ML_CM : ML_CQ;
     const int logical = xcd_logical_block();
     if (logical >= n_wgs) return;
     int pic = (int)__umulhi((unsigned)logical, inv_wgs);
@@ -681,60 +774,89 @@ void k_mc_chroma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ m
     const uint32_t *mc = mc_all + (size_t)pic * ml.words;
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
-    if (chunk >= (int)mc[1]) return;
-    const int lane = threadIdx.x & 63, p = lane & 1;
-    const int key = (int)((mc[ml.off_cls_c + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);
-    const uint4 e = gload4(mc + ml.off_list_c + (size_t)(chunk * MCC_CHUNK + (lane >> 1)) * 4);
-    const bool valid = e.x != 0xffffffffu;
-    const int mbi = valid ? (int)(e.x >> 2) : 0, q = valid ? (int)(e.x & 3) : 0;
+    if (chunk >= (int)mc[LIST]) return;
+    const int lane = threadIdx.x & 63, p = lane & 1, li = lane & (I::LANES - 1), it = lane / I::LANES;
+    const int key = (int)((mc[ml.off_cls[LIST] + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);
+    const uint2 e = gload2(mc + ml.off_list[LIST] + (size_t)(chunk * I::PER_WAVE + it) * 2);
+    const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
+    const int mbi = valid ? (int)((e.x & MC_ITEM_MASK) >> 2) : 0;
+    const int q = MB ? (li >> 1) : (valid ? (int)(e.x & 3) : 0);
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (key & MCC_RESID) rec = gload4(pd->mb + mbi);
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     uint32_t roff = pd->ref_off[0];
-    if (pd->n_ref > 1) roff = glob(pd->ref_off)[(e.w >> 26) & 15];
+    if (pd->n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
-    const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;
-    const bool has_res = valid && ((e.w >> 8) & 3) != 0;    // cbp >> 4
+    const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;      // the block's first sample
+    const unsigned mask = rec.y;
+    const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
+    const bool has_res = valid && ((rec.x >> 20) & 3) != 0;  // cbp >> 4
     uint4 la = make_uint4(0, 0, 0, 0), lb = la; uint2 dcl = make_uint2(0, 0);
-    if (key & MCC_RESID) {
-        const int16_t *cf = pd->coefs + (size_t)e.z * 16;  // the macroblock's chroma DC block (if present), the AC blocks behind it
-        if (has_res && ((e.w >> (11 + p)) & 1)) { const int16_t *c = cf + ((e.w >> (16 + 5 * p)) & 31) * 16; la = gload4(c); lb = gload4(c + 8); }
-        if (has_res && ((e.w >> 10) & 1)) dcl = gload2(cf + p * 4);
-    }
     // ---- prediction ----
     uint32_t out[4];
-    if (!(key & MCC_SLOW)) {
-        // The window of the quadrant - 5 rows x two strips x 16 bytes (8 U, 8 V) - goes through LDS like the luma windows.
-        // Four lanes = two quadrants stage together: rows 0..3 of one strip of one quadrant per load (64 contiguous bytes),
-        // then row 4 of their own strips.
+    const bool staged = MB || !(key & MCC_CLAMP);
+    if (staged) {
+        // the item's window goes through LDS like the luma windows: 16-byte pieces (8 U, 8 V) of consecutive rows
         const int mvx = mv_x((int)e.y), mvy = mv_y((int)e.y);
-        const int cx = CX + (mvx >> 3), cy = CY + (mvy >> 3), sA = cx >> 3;
-        const uint32_t own = roff + g.coff + (uint32_t)sA * g.cstrip + (uint32_t)(cy * 16), other = lane_xor2(own);
-        const int i = lane & 3;
-        uint8_t *pimg = images[wave] + (lane >> 2) * (2 * LC_QUAD);
-        u32x4 v[5];
+        const int cx = CX + (mvx >> 3), cy = CY + (mvy >> 3);                // the block's window
+        const int wx = cx - (q & 1) * 4, wy = cy - (q >> 1) * 4;             // the macroblock's window (MB); equals (cx, cy) for q = 0
+        uint8_t *img;
+        int x0, y0;                                                          // image origin
+        if (MB) {
+            // 9 rows x 2 strips = 18 pieces over 8 lanes: piece li + 8j = strip (p / 9), row p % 9
+            img = images + (wave * I::PER_WAVE + it) * I::BYTES;
+            const int sA = wx >> 3;
+            x0 = sA * 8; y0 = wy;
+            u32x4 v[3]; int dst[3];
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = bload4(rs, (((j >> 1) == (i >> 1)) ? own : other) + (uint32_t)(j & 1) * g.cstrip + (uint32_t)(i * 16));
-        v[4] = bload4(rs, own + (uint32_t)(i & 1) * g.cstrip + 64u);
+            for (int j = 0; j < 3; j++) {
+                const int pp = min(li + 8 * j, 17), s = pp >= 9 ? 1 : 0, row = pp - 9 * s;
+                dst[j] = row * I::PITCH + s * 16;
+                v[j] = (key & MCC_CLAMP) ? chroma_piece<true>(rs, roff, g, sA + s, wy + row) : chroma_piece<false>(rs, roff, g, sA + s, wy + row);
+            }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint8_t *dp = pimg + (j >> 1) * LC_QUAD + i * LC_PITCH + (j & 1) * 16;
-            *(uint2 *)dp = make_uint2(v[j].x, v[j].y); *(uint2 *)(dp + 8) = make_uint2(v[j].z, v[j].w);
+            for (int j = 0; j < 3; j++) lds_put16(img + dst[j], v[j]);
+        } else {
+            // Four lanes = two quadrants stage together: rows 0..3 of one strip of one quadrant per load (64 contiguous
+            // bytes), then row 4 of their own strips.
+            const int sA = cx >> 3;
+            x0 = sA * 8; y0 = cy;
+            const uint32_t own = roff + g.coff + (uint32_t)sA * g.cstrip + (uint32_t)(cy * 16), other = lane_xor2(own);
+            const int i = lane & 3;
+            uint8_t *pimg = images + (wave * I::PER_WAVE + (lane >> 2) * 2) * I::BYTES;
+            u32x4 v[5];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = bload4(rs, (((j >> 1) == (i >> 1)) ? own : other) + (uint32_t)(j & 1) * g.cstrip + (uint32_t)(i * 16));
+            v[4] = bload4(rs, own + (uint32_t)(i & 1) * g.cstrip + 64u);
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds_put16(pimg + (j >> 1) * I::BYTES + i * I::PITCH + (j & 1) * 16, v[j]);
+            lds_put16(pimg + (i >> 1) * I::BYTES + 4 * I::PITCH + (i & 1) * 16, v[4]);
+            img = pimg + (i >> 1) * I::BYTES;
         }
-        {
-            uint8_t *dp = pimg + (i >> 1) * LC_QUAD + 4 * LC_PITCH + (i & 1) * 16;
-            *(uint2 *)dp = make_uint2(v[4].x, v[4].y); *(uint2 *)(dp + 8) = make_uint2(v[4].z, v[4].w);
+        if (key & MCC_RESID) {
+            const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+            if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
+            if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
         wave_lds_fence();
-        const uint8_t *qimg = pimg + (i >> 1) * LC_QUAD + p * 8;
-        const int xa = cx & ~3, o0 = ((xa >> 3) - sA) * 16 + (xa & 7), o1 = (((xa + 4) >> 3) - sA) * 16 + ((xa + 4) & 7);
+        // the lane's five rows, two aligned dwords each: sample x of plane p sits at ((x - x0) >> 3) * 16 + p * 8 + (x & 7)
+        const int xa = cx & ~3;
+        const uint8_t *b = img + (cy - y0) * I::PITCH + p * 8;
+        const int o0 = ((xa - x0) >> 3) * 16 + (xa & 7), o1 = ((xa + 4 - x0) >> 3) * 16 + ((xa + 4) & 7);
         uint32_t d0[5], d1[5];
 #pragma unroll
-        for (int r = 0; r < 5; r++) { d0[r] = *(const uint32_t *)(qimg + r * LC_PITCH + o0); d1[r] = *(const uint32_t *)(qimg + r * LC_PITCH + o1); }
+        for (int r = 0; r < 5; r++) { d0[r] = *(const uint32_t *)(b + r * I::PITCH + o0); d1[r] = *(const uint32_t *)(b + r * I::PITCH + o1); }
         chroma_bilinear(out, d0, d1, (uint32_t)cx & 3u, mvx & 7, mvy & 7);
     } else {
-        // clamped windows straight from memory; where the four 4x4 luma blocks of the quadrant have different vectors
-        // (sub-8x8 partitions) every 2x2 chroma piece follows its own vector: one pass per piece, wave-uniformly skipped
-        // when nobody needs it
+        // quadrant items outside the picture or with different vectors inside (sub-8x8 partitions: every 2x2 chroma piece
+        // follows its own vector): clamped windows straight from memory, one pass per piece, wave-uniformly skipped when
+        // nobody needs it
+        if (key & MCC_RESID) {
+            const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+            if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
+            if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
+        }
         const int b0 = (q >> 1) * 8 + (q & 1) * 2;
         const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
         const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
@@ -757,7 +879,7 @@ void k_mc_chroma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ m
     }
     // ---- residual (decoder/macroblock.c:851-890): chroma DC through the 2x2 transform, AC, inverse transform ----
     if ((key & MCC_RESID) && __ballot(has_res)) {
-        const int qpc = chroma_qp(clip3i((int)(e.w & 255) + pd->chroma_qp_offset, 0, 51));
+        const int qpc = chroma_qp(clip3i((int)((rec.x >> 8) & 255) + pd->chroma_qp_offset, 0, 51));
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<true>(lv, col);
@@ -780,4 +902,16 @@ void k_mc_chroma(const PicDev *__restrict__ pics, const uint32_t *__restrict__ m
 #pragma unroll
         for (int y = 0; y < 4; y++) bstore(rs, o + (uint32_t)(y * 16), out[y]);
     }
+}
+__global__ __launch_bounds__(256, 4)
+void k_mc_chroma_mb(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 8 * CItem<true>::BYTES];
+    mc_chroma_body<true>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
+}
+__global__ __launch_bounds__(256, 4)
+void k_mc_chroma_quad(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 32 * CItem<false>::BYTES];
+    mc_chroma_body<false>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
 }

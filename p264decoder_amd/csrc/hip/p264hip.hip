@@ -354,11 +354,16 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         const McLayout ml = c->ml;
         const uint32_t inv_mbw = (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w);
         hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
-        const int wgs_y = (int)(ml.max_chunks_y + 3) / 4, wgs_c = (int)(ml.max_chunks_c + 3) / 4;
-        hipLaunchKernelGGL(k_mc_luma, dim3(((size_t)wgs_y * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], (const uint32_t *)c->d_mc, g, ml, inv_mbw,
-                           wgs_y, wgs_y * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs_y));
-        hipLaunchKernelGGL(k_mc_chroma, dim3(((size_t)wgs_c * n + 7) / 8 * 8), dim3(256), 0, c->stream, c->d_batch[r], (const uint32_t *)c->d_mc, g, ml, inv_mbw,
-                           wgs_c, wgs_c * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs_c));
+        const uint32_t *mc = c->d_mc;
+        auto launch = [&](void (*k)(const PicDev *, const uint32_t *, Geom, McLayout, uint32_t, int, int, uint32_t), int list) {
+            const int wgs = (int)(ml.max_chunks[list] + 3) / 4;                // four chunks (wavefronts) per workgroup
+            hipLaunchKernelGGL(k, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, c->stream, (const PicDev *)c->d_batch[r], mc, g, ml, inv_mbw,
+                               wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
+        };
+        launch(k_mc_luma_mb, ML_YM);
+        launch(k_mc_luma_quad, ML_YQ);
+        launch(k_mc_chroma_mb, ML_CM);
+        launch(k_mc_chroma_quad, ML_CQ);
     }
     {
         ScopedStamp t(c, 1);

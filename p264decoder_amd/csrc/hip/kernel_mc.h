@@ -96,8 +96,13 @@ __device__ __forceinline__ int phase_class(int fx, int fy)
 }
 
 // What one inter macroblock contributes: either one macroblock item per plane kind (one vector, one reference) or its
-// four quadrants.  key[] / ex[] / ey[] per entry; n = 1 or 4.
-struct McMb { bool inter, whole; int ky[4], kc[4]; uint32_t ex[4], ey[4]; };
+// four quadrants.  Packed so that a thread can keep the classification of several macroblocks in registers between
+// the counting and the scattering pass: key[q] = luma key | chroma key << 16, vec[q] = the entry's vector,
+// info = inter | whole << 1 | reference indices (4 bits each) << 8.
+struct McMb { uint32_t info, key[4], vec[4]; };
+#define MCMB_INTER 1u
+#define MCMB_WHOLE 2u
+__device__ __forceinline__ uint32_t mcmb_entry(const McMb &k, int mbi, int q) { return ((k.info >> (8 + 4 * q)) & 15u) << 28 | (uint32_t)mbi << 2 | (uint32_t)q; }
 __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int mbi, uint32_t inv_mbw, int band_log2)
 {
     McMb k;
@@ -105,7 +110,7 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
     const int *mvp = pd->mv + mbi * 16;
     const uint4 m0 = gload4(mvp), m1 = gload4(mvp + 4), m2 = gload4(mvp + 8), m3 = gload4(mvp + 12);
     const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
-    k.inter = !P264_MB_IS_INTRA(rec.x & 255);
+    k.info = P264_MB_IS_INTRA(rec.x & 255) ? 0u : MCMB_INTER;
     int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
     if (mbi - mby * g.mb_w >= g.mb_w) mby++;
     const int mbx = mbi - mby * g.mb_w, band = mby >> band_log2;
@@ -116,21 +121,24 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
     for (int q = 0; q < 4; q++) {
         ri[q] = (int)(int8_t)(refs >> (8 * q));
         if (ri[q] < 0 || ri[q] >= n_ref) ri[q] = 0;        // negative or past the list: entry 0, as the reference's flat lists
+        k.info |= (uint32_t)ri[q] << (8 + 4 * q);
     }
     const uint32_t v0 = m0.x;
     const uint32_t diff = (m0.y ^ v0) | (m0.z ^ v0) | (m0.w ^ v0) | (m1.x ^ v0) | (m1.y ^ v0) | (m1.z ^ v0) | (m1.w ^ v0) | (m2.x ^ v0) | (m2.y ^ v0)
                         | (m2.z ^ v0) | (m2.w ^ v0) | (m3.x ^ v0) | (m3.y ^ v0) | (m3.z ^ v0) | (m3.w ^ v0);
-    k.whole = diff == 0 && ri[0] == ri[1] && ri[0] == ri[2] && ri[0] == ri[3];
-    if (k.whole) {
+    const bool whole = diff == 0 && ri[0] == ri[1] && ri[0] == ri[2] && ri[0] == ri[3];
+    if (whole) {
+        k.info |= MCMB_WHOLE;
         const int mvx = mv_x((int)v0), mvy = mv_y((int)v0);
         const int wx = mbx * 16 + (mvx >> 2) - 2, wy = mby * 16 + (mvy >> 2) - 2;      // 21 x 21 samples
         const bool in_y = wx >= 0 && wx + 21 <= g.w && wy >= 0 && wy + 21 <= g.h;
         const int cx = mbx * 8 + (mvx >> 3), cy = mby * 8 + (mvy >> 3);                 // 9 x 9 samples
         const bool in_c = cx >= 0 && cx + 9 <= g.cw && cy >= 0 && cy + 9 <= g.ch;
-        k.ky[0] = band * MCY_KEYS + (phase_class(mvx & 3, mvy & 3) | (in_y ? 0 : MCY_CLAMP) | ((mask & 0xffffu) ? MCY_RESID : 0));
-        k.kc[0] = band * MCC_KEYS + (in_c ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
-        k.ex[0] = (uint32_t)ri[0] << 28 | (uint32_t)mbi << 2;
-        k.ey[0] = v0;
+        const int ky = band * MCY_KEYS + (phase_class(mvx & 3, mvy & 3) | (in_y ? 0 : MCY_CLAMP) | ((mask & 0xffffu) ? MCY_RESID : 0));
+        const int kc = band * MCC_KEYS + (in_c ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
+        k.key[0] = (uint32_t)ky | (uint32_t)kc << 16;
+        k.vec[0] = v0;
+        k.key[1] = k.key[2] = k.key[3] = 0; k.vec[1] = k.vec[2] = k.vec[3] = 0;
         return k;
     }
 #pragma unroll
@@ -148,17 +156,45 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
         int pc = phase_class(mvx & 3, mvy & 3), fl = in_y ? 0 : MCY_CLAMP;
         if (!uniform) { pc = PC_GEN; fl = MCY_CLAMP; }
         if ((mask >> (4 * q)) & 15) fl |= MCY_RESID;
-        k.ky[q] = band * MCY_KEYS + (pc | fl);
-        k.kc[q] = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
-        k.ex[q] = (uint32_t)ri[q] << 28 | (uint32_t)mbi << 2 | (uint32_t)q;
-        k.ey[q] = va;
+        const int ky = band * MCY_KEYS + (pc | fl);
+        const int kc = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
+        k.key[q] = (uint32_t)ky | (uint32_t)kc << 16;
+        k.vec[q] = va;
     }
     return k;
 }
 
 // One workgroup per picture, one thread per macroblock: count the keys of the four lists, lay the key segments out (each
-// padded to whole chunks), scatter the entries.
+// padded to whole chunks), scatter the entries.  Up to MC_SORT_KEEP macroblocks per thread (1080p: 8) the classification
+// stays in registers between the two passes: the macroblock arrays are read once.
 #define MC_KEY_SLOTS (2 * MC_MAX_BANDS * MCY_KEYS + 2 * MC_MAX_BANDS * MCC_KEYS)
+#define MC_SORT_KEEP 8
+struct McSortCtx { uint32_t *cnt, *pos, *out; int b_ym, b_yq, b_cm, b_cq; uint32_t l_ym, l_yq, l_cm, l_cq; };
+__device__ __forceinline__ void mc_count(const McSortCtx &c, const McMb &k)
+{
+    if (!(k.info & MCMB_INTER)) return;
+    if (k.info & MCMB_WHOLE) { atomicAdd(&c.cnt[c.b_ym + (k.key[0] & 0xffffu)], 1u); atomicAdd(&c.cnt[c.b_cm + (k.key[0] >> 16)], 1u); }
+    else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { atomicAdd(&c.cnt[c.b_yq + (k.key[q] & 0xffffu)], 1u); atomicAdd(&c.cnt[c.b_cq + (k.key[q] >> 16)], 1u); }
+    }
+}
+__device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, int mbi)
+{
+    if (!(k.info & MCMB_INTER)) return;
+    if (k.info & MCMB_WHOLE) {
+        const uint2 e = make_uint2(mcmb_entry(k, mbi, 0), k.vec[0]);
+        gstore2(c.out + c.l_ym + 2 * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
+        gstore2(c.out + c.l_cm + 2 * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint2 e = make_uint2(mcmb_entry(k, mbi, q), k.vec[q]);
+            gstore2(c.out + c.l_yq + 2 * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
+            gstore2(c.out + c.l_cq + 2 * atomicAdd(&c.pos[c.b_cq + (k.key[q] >> 16)], 1u), e);
+        }
+    }
+}
 __global__ __launch_bounds__(MC_SORT_THREADS)
 void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
 {
@@ -167,6 +203,7 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
     uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
     const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
     const int b_ym = 0, b_yq = nky, b_cm = 2 * nky, b_cq = 2 * nky + nkc, b_end = 2 * nky + 2 * nkc;     // key slots of the four lists
+    const McSortCtx ctx = { cnt, pos, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[ML_YM], ml.off_list[ML_YQ], ml.off_list[ML_CM], ml.off_list[ML_CQ] };
     const int tid = threadIdx.x;
     if (pd->slice_type != P264_SLICE_P) {                 // wave-uniform
         if (tid < ML_LISTS) gstore1(out + tid, 0);
@@ -174,14 +211,17 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
     }
     for (int k = tid; k < b_end; k += MC_SORT_THREADS) cnt[k] = 0;
     __syncthreads();
-    for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) {
-        const McMb k = mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2);
-        if (!k.inter) continue;
-        if (k.whole) { atomicAdd(&cnt[b_ym + k.ky[0]], 1u); atomicAdd(&cnt[b_cm + k.kc[0]], 1u); }
-        else {
+    const bool keep = g.n_mb <= MC_SORT_KEEP * MC_SORT_THREADS;
+    McMb kept[MC_SORT_KEEP];
+    if (keep) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) { atomicAdd(&cnt[b_yq + k.ky[q]], 1u); atomicAdd(&cnt[b_cq + k.kc[q]], 1u); }
+        for (int j = 0; j < MC_SORT_KEEP; j++) {
+            const int mbi = tid + j * MC_SORT_THREADS;
+            kept[j].info = 0;
+            if (mbi < g.n_mb) { kept[j] = mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2); mc_count(ctx, kept[j]); }
         }
+    } else {
+        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_count(ctx, mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2));
     }
     __syncthreads();
     // segment starts: every thread sums the padded counts in front of its key (a few hundred LDS reads at most), notes the
@@ -201,19 +241,11 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
         if (kk == nk - 1) gstore1(out + l, start + n);
     }
     __syncthreads();
-    for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) {
-        const McMb k = mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2);
-        if (!k.inter) continue;
-        if (k.whole) {
-            gstore2(out + ml.off_list[ML_YM] + 2 * atomicAdd(&pos[b_ym + k.ky[0]], 1u), make_uint2(k.ex[0], k.ey[0]));
-            gstore2(out + ml.off_list[ML_CM] + 2 * atomicAdd(&pos[b_cm + k.kc[0]], 1u), make_uint2(k.ex[0], k.ey[0]));
-        } else {
+    if (keep) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                gstore2(out + ml.off_list[ML_YQ] + 2 * atomicAdd(&pos[b_yq + k.ky[q]], 1u), make_uint2(k.ex[q], k.ey[q]));
-                gstore2(out + ml.off_list[ML_CQ] + 2 * atomicAdd(&pos[b_cq + k.kc[q]], 1u), make_uint2(k.ex[q], k.ey[q]));
-            }
-        }
+        for (int j = 0; j < MC_SORT_KEEP; j++) mc_scatter(ctx, kept[j], tid + j * MC_SORT_THREADS);
+    } else {
+        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_scatter(ctx, mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2), mbi);
     }
     __syncthreads();
     for (int k = tid; k < b_end; k += MC_SORT_THREADS) {                      // padding entries behind every segment
@@ -236,10 +268,6 @@ __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cas
 __device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 // byte-parallel (a + b + 1) >> 1 (pixel_avg, core/mc.c:58-74)
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) & 0xfefefefeu) >> 1); }
-// hipcc (ROCm 7.2) fuses "arithmetic shift right -> clamp to 0..255 -> pack two bytes" into gfx950's v_ashr_pk_u8_i32 and
-// then ORs further bytes into the upper half of its result, which the hardware does not leave zero (measured: wrong upper
-// bytes).  An empty asm on the shifted value keeps the shift and the clamp apart; it emits no instruction.
-__device__ __forceinline__ int no_fuse(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
 __device__ __forceinline__ uint32_t sel32(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
 
@@ -354,10 +382,12 @@ __device__ __forceinline__ void tap_h4(uint32_t n0, uint32_t n1, uint32_t n2, in
     t[2] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 2), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 2), C1, bias, false), false);
     t[3] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 3), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 3), C1, bias, false), false);
 }
-// (t >> sh) clipped to a byte, four at once
+// (t >> sh) clipped to a byte, four at once: gfx950's v_ashr_pk_u8_i32 shifts, saturates and packs two values per
+// instruction (result bits 16..31 are not defined: only its low two bytes are used)
 template <int SH> __device__ __forceinline__ uint32_t round_pack4(const int t[4])
 {
-    return pack4(clip255(no_fuse(t[0] >> SH)), clip255(no_fuse(t[1] >> SH)), clip255(no_fuse(t[2] >> SH)), clip255(no_fuse(t[3] >> SH)));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SH), hi = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SH);
+    return perm(hi, lo, 0x05040100u);
 }
 // window bytes 0..11 of a row, the window starting at byte s of dword 0
 __device__ __forceinline__ void align_row(const uint32_t (&w)[3], uint32_t s, uint32_t &n0, uint32_t &n1, uint32_t &n2)
@@ -541,18 +571,21 @@ __device__ __forceinline__ void idct_add(const uint32_t (&col)[4][2], uint32_t (
         const s16x2 s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
         T[0][j] = s02 + s13; T[1][j] = d02 + d13; T[2][j] = d02 - d13; T[3][j] = s02 - s13;
     }
+    // (sum + 32) >> 6 added to the prediction and clipped = (sum + 32 + 64 * prediction) >> 6 clipped: shift, saturation
+    // and packing in one instruction per two samples
     int res[4][4];
 #pragma unroll
     for (int x = 0; x < 4; x++) {
         const int a0 = T[x][0].x, a1 = T[x][0].y, a2 = T[x][1].x, a3 = T[x][1].y;
         const int s02 = a0 + a2 + 32, d02 = a0 - a2 + 32, s13 = a1 + (a3 >> 1), d13 = (a1 >> 1) - a3;
-        res[0][x] = (s02 + s13) >> 6; res[1][x] = (d02 + d13) >> 6; res[2][x] = (d02 - d13) >> 6; res[3][x] = (s02 - s13) >> 6;
+        res[0][x] = s02 + s13; res[1][x] = d02 + d13; res[2][x] = d02 - d13; res[3][x] = s02 - s13;
     }
 #pragma unroll
     for (int y = 0; y < 4; y++) {
         const uint32_t p = px[y];
-        px[y] = pack4(clip255((int)(p & 255) + res[y][0]), clip255((int)((p >> 8) & 255) + res[y][1]),
-                      clip255((int)((p >> 16) & 255) + res[y][2]), clip255((int)(p >> 24) + res[y][3]));
+        const int v[4] = { res[y][0] + (int)((p & 255u) << 6), res[y][1] + (int)(((p >> 8) & 255u) << 6),
+                           res[y][2] + (int)(((p >> 16) & 255u) << 6), res[y][3] + (int)((p >> 24) << 6) };
+        px[y] = round_pack4<6>(v);
     }
 }
 
@@ -588,12 +621,26 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     const PicDev *pd = pics + pic;
     const uint32_t *mc = mc_all + (size_t)pic * ml.words;  // (addresses from kernel arguments only: the first loads depend on nothing)
     const int wave = rfl((int)(threadIdx.x >> 6));
-    const int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
-    if (chunk >= (int)mc[LIST]) return;
+    // A wavefront walks the picture's chunks with a stride of all the picture's wavefronts; the key and the list entries of
+    // its NEXT chunk are requested before it starts on the current one, so that only the window fetch itself is a memory
+    // round trip the wavefront has to sit through.
+    const int stride = wgs_per_pic * 4, n_chunks = (int)mc[LIST];
+    int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
+    if (chunk >= n_chunks) return;
     const int lane = threadIdx.x & 63, li = lane & (I::LANES - 1), it = lane / I::LANES;
-    const int key = (int)((mc[ml.off_cls[LIST] + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);     // scalar: the chunk's key bits
+    const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
+    const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
+    const int n_ref = pd->n_ref;
+    uint32_t key_w = cls_w[chunk >> 2];
+    uint2 e = gload2(list + (size_t)(chunk * I::PER_WAVE + it) * 2);
+  for (;;) {
+    const int next = chunk + stride;
+    const bool more = next < n_chunks;
+    uint32_t key_w_next = 0; uint2 e_next = make_uint2(0, 0);
+    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload2(list + (size_t)(next * I::PER_WAVE + it) * 2); }
+    const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);                                 // scalar: the chunk's key bits
     const int pc = key & 7;
-    const uint2 e = gload2(mc + ml.off_list[LIST] + (size_t)(chunk * I::PER_WAVE + it) * 2);
+    wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
     const int mbi = valid ? (int)((e.x & MC_ITEM_MASK) >> 2) : 0;
     // block position inside the macroblock
@@ -604,9 +651,8 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     if (key & MCY_RESID) rec = gload4(pd->mb + mbi);
     int mvp = (int)e.y;
     if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
-    const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     uint32_t roff = pd->ref_off[0];
-    if (pd->n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];                         // (wave-uniform branch)
+    if (n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];                             // (wave-uniform branch)
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
@@ -681,6 +727,9 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
             bstore2(rs, o + 16, r1a, r1b);
         }
     }
+    if (!more) break;
+    chunk = next; key_w = key_w_next; e = e_next;
+  }
 }
 __global__ __launch_bounds__(256, 4)
 void k_mc_luma_mb(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
@@ -773,19 +822,30 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     const PicDev *pd = pics + pic;
     const uint32_t *mc = mc_all + (size_t)pic * ml.words;
     const int wave = rfl((int)(threadIdx.x >> 6));
-    const int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
-    if (chunk >= (int)mc[LIST]) return;
+    // (chunk walk with the next chunk's key and entries requested ahead, as in mc_luma_body)
+    const int stride = wgs_per_pic * 4, n_chunks = (int)mc[LIST];
+    int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
+    if (chunk >= n_chunks) return;
     const int lane = threadIdx.x & 63, p = lane & 1, li = lane & (I::LANES - 1), it = lane / I::LANES;
-    const int key = (int)((mc[ml.off_cls[LIST] + (chunk >> 2)] >> (8 * (chunk & 3))) & 255u);
-    const uint2 e = gload2(mc + ml.off_list[LIST] + (size_t)(chunk * I::PER_WAVE + it) * 2);
+    const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
+    const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
+    const int n_ref = pd->n_ref;
+    uint32_t key_w = cls_w[chunk >> 2];
+    uint2 e = gload2(list + (size_t)(chunk * I::PER_WAVE + it) * 2);
+  for (;;) {
+    const int next = chunk + stride;
+    const bool more = next < n_chunks;
+    uint32_t key_w_next = 0; uint2 e_next = make_uint2(0, 0);
+    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload2(list + (size_t)(next * I::PER_WAVE + it) * 2); }
+    const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);
+    wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
     const int mbi = valid ? (int)((e.x & MC_ITEM_MASK) >> 2) : 0;
     const int q = MB ? (li >> 1) : (valid ? (int)(e.x & 3) : 0);
     uint4 rec = make_uint4(0, 0, 0, 0);
     if (key & MCC_RESID) rec = gload4(pd->mb + mbi);
-    const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     uint32_t roff = pd->ref_off[0];
-    if (pd->n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];
+    if (n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;      // the block's first sample
@@ -902,6 +962,9 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
 #pragma unroll
         for (int y = 0; y < 4; y++) bstore(rs, o + (uint32_t)(y * 16), out[y]);
     }
+    if (!more) break;
+    chunk = next; key_w = key_w_next; e = e_next;
+  }
 }
 __global__ __launch_bounds__(256, 4)
 void k_mc_chroma_mb(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)

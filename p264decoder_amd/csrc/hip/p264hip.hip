@@ -356,7 +356,12 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
         const uint32_t *mc = c->d_mc;
         auto launch = [&](void (*k)(const PicDev *, const uint32_t *, Geom, McLayout, uint32_t, int, int, uint32_t), int list) {
-            const int wgs = (int)(ml.max_chunks[list] + 3) / 4;                // four chunks (wavefronts) per workgroup
+            // four wavefronts per workgroup, every wavefront walks its picture's chunks with a stride: enough workgroups
+            // per picture to fill the chip a few times over, no more than there are chunks
+            int wgs = (c->n_cu * 24 + n - 1) / n;
+            const int max_wgs = (int)(ml.max_chunks[list] + 3) / 4;
+            if (wgs > max_wgs) wgs = max_wgs;
+            if (const char *e = getenv("P264AMD_MC_WGS_PER_PIC")) { int v = atoi(e); if (v >= 1 && v <= max_wgs) wgs = v; }
             hipLaunchKernelGGL(k, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, c->stream, (const PicDev *)c->d_batch[r], mc, g, ml, inv_mbw,
                                wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
         };

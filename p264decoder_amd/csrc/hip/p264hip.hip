@@ -358,7 +358,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         auto launch = [&](void (*k)(const PicDev *, const uint32_t *, Geom, McLayout, uint32_t, int, int, uint32_t), int list) {
             // four wavefronts per workgroup, every wavefront walks its picture's chunks with a stride: enough workgroups
             // per picture to fill the chip a few times over, no more than there are chunks
-            int wgs = (c->n_cu * 24 + n - 1) / n;
+            int wgs = (c->n_cu * 192 + n - 1) / n;
             const int max_wgs = (int)(ml.max_chunks[list] + 3) / 4;
             if (wgs > max_wgs) wgs = max_wgs;
             if (const char *e = getenv("P264AMD_MC_WGS_PER_PIC")) { int v = atoi(e); if (v >= 1 && v <= max_wgs) wgs = v; }

@@ -16,7 +16,10 @@ pictures per stream are timed.
   N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
        one rank per GPU, streams sharded across ranks, no data-path collective (weak scaling).
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  Besides the contract's fields: `roofline` (the dominant stage), `kernels` (every stage with
+its own fraction of the HBM roofline), `cpu_baseline` (the real reference decoder on one host core, N=1 only), a
+`golden_check` (the timed output of a golden-seeded stream hashed against the committed reference hash) and `extras`
+(never `value`: config 2, config 3 I+P, the parse- and PCIe-inclusive pipeline, the single-stream drop-in API; N=1 only).
 """
 import argparse
 import ctypes as C
@@ -34,6 +37,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 MB_W, MB_H = 120, 68
 N_MB = MB_W * MB_H
 DISTINCT = 4                   # distinct synthetic streams per rank; the S streams cycle through private copies of them
+STAGE_KERNELS = {"inter": "k_mc_sort + k_mc_luma_mb + k_mc_luma_quad + k_mc_chroma_mb + k_mc_chroma_quad", "intra": "k_intra",
+                 "deblock": "k_deblock_bs + k_deblock"}
 
 
 def synth_args(frames, seed):
@@ -59,6 +64,88 @@ def algorithmic_bytes(pics):
     return {"inter": inter, "intra": intra, "deblock": deblock}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def run_batched(lib, pics, S, mb_w, mb_h, slots):
+    """All pictures of one parsed stream on S streams side by side (private clones), inputs resident: pictures/s and the
+    hash of stream S-1's last picture."""
+    from p264decoder_amd import HipReconstructor
+    from tests.conftest import frame_sha256
+    T = len(pics)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=slots, max_pictures=S * T, lib=lib)
+    hip.upload(0, pics)
+    for s in range(1, S):
+        for t in range(T):
+            hip.clone_picture(s * T + t, t)
+    hip.sync()
+    streams = list(range(S))
+    hip.reconstruct([s * T for s in streams], streams)           # the first picture once, untimed: allocations, first launches
+    hip.sync()
+    t0 = time.perf_counter()
+    for t in range(T):
+        hip.reconstruct([s * T + t for s in streams], streams)
+    hip.sync()
+    dt = time.perf_counter() - t0
+    digest = frame_sha256(*hip.read_frame(S - 1, pics[-1].desc.dst_slot))
+    hip.close()
+    return S * T / dt, digest
+
+
+def extras(lib):
+    """Figures that are NOT the metric (never `value`): the other single-GPU configurations of BASELINE.json and the
+    end-to-end rates, each on a bounded run."""
+    from p264decoder_amd import Decoder, Parser
+    from tests import synth_cases
+    from tests.conftest import frame_sha256
+    out = {}
+    # config 2: 1280x720 Baseline CAVLC, I slices only (intra + IDCT path), 30 pictures x 256 streams
+    pics = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes("cfg2_720p_intra"))
+    fps, digest = run_batched(lib, pics, 256, 80, 45, 2)
+    out["config2_720p_intra_only"] = {"value": round(fps, 1), "unit": "frames/s", "streams": 256, "pictures_per_stream": len(pics),
+                                       "last_picture_matches_reference": digest == synth_cases.golden("cfg2_720p_intra")[1][-1]}
+    # config 3 as specified: I+P, GOP 30, 60 pictures x 256 streams
+    pics = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes("cfg3_1080p_ip"))
+    fps, digest = run_batched(lib, pics, 256, MB_W, MB_H, 2)
+    out["config3_1080p_i_plus_p_gop30"] = {"value": round(fps, 1), "unit": "frames/s", "streams": 256, "pictures_per_stream": len(pics),
+                                            "last_picture_matches_reference": digest == synth_cases.golden("cfg3_1080p_ip")[1][-1]}
+    # end to end: Annex-B bytes in host memory -> pictures in HBM, host CAVLC parse and PCIe uploads included
+    try:
+        from p264decoder_amd import Pipeline
+        threads = min(os.cpu_count() or 8, 16)
+        distinct = [open(synth_cases.generate(synth_args(24, 1000 + g)), "rb").read() for g in range(4)]
+        pipe = Pipeline([distinct[i % 4] for i in range(64)], threads=threads, device=0, lib=lib)
+        pipe.run(max_pictures=2)
+        pipe.close()
+        pipe = Pipeline([distinct[i % 4] for i in range(64)], threads=threads, device=0, lib=lib)
+        st = pipe.run()
+        pipe.close()
+        out["end_to_end_pipeline"] = {"value": round(st["pictures"] / st["seconds"], 1), "unit": "frames/s", "streams": 64, "host_threads": st["threads"],
+                                      "what": "Annex-B in host memory -> CAVLC parse on the host threads -> pinned uploads -> batched reconstruction; pictures stay in HBM"}
+    except Exception as e:                                    # never let an extra take the metric down
+        out["end_to_end_pipeline"] = {"error": str(e)}
+    # the drop-in API, one stream, picture by picture with the I420 download (p264_decoder_decode)
+    try:
+        data = synth_cases.stream_bytes("cfg3_1080p_ip")
+        dec = Decoder(lib=lib)
+        t0 = time.perf_counter()
+        n = sum(1 for _ in dec.decode_annexb(data))
+        dt = time.perf_counter() - t0
+        dec.close()
+        out["single_stream_dropin_api"] = {"value": round(n / dt, 1), "unit": "frames/s", "pictures": n,
+                                           "what": "p264_nal_decode + p264_decoder_decode per NAL, host parse, upload, reconstruction and I420 download per picture"}
+    except Exception as e:
+        out["single_stream_dropin_api"] = {"error": str(e)}
+    return out
+
+
 def cpu_baseline(stream_path, n_pictures):
     """The reference's own CPU path on the host cores of this box, 1 core (it is single-threaded),
     on a bounded sample of the same workload.  kind = "reference" when oracle/_ref (the real
@@ -69,7 +156,7 @@ def cpu_baseline(stream_path, n_pictures):
         try:
             out = subprocess.run([driver, "time", stream_path, str(loops)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                  text=True, timeout=600).stdout.split()
-            return {"value": round(float(out[out.index("fps") + 1]), 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+            return {"value": round(float(out[out.index("fps") + 1]), 3), "unit": "frames/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model(),
                     "sample": "%d-picture 1920x1088 all-P stream decoded %dx by the reference decoder (parse + reconstruction)" % (n_pictures, loops)}
         except Exception:
             pass
@@ -84,7 +171,7 @@ def cpu_baseline(stream_path, n_pictures):
         for p in pics:
             oracle_bind.reconstruct(ora, store, p)
             n += 1
-    return {"value": round(n / (time.time() - t0), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": round(n / (time.time() - t0), 3), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d 1920x1088 pictures through the scalar oracle (reconstruction only, parse excluded)" % n}
 
 
@@ -116,6 +203,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=1024, help="independent 1080p streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
     args = ap.parse_args()
 
     import torch
@@ -133,11 +221,15 @@ def main():
     S, K, Wm = args.streams, args.steps, args.warmup
     T = 1 + Wm + K                                        # pictures per stream: IDR + warm-up + timed
     # ---- set-up (untimed): write + parse DISTINCT streams, make every stream's inputs resident ----
+    # Stream 0 of every rank is the golden all-P stream (tests/golden/synth_cfg3_1080p_allp.sha256: per-picture hashes of
+    # the REAL reference decoder) as long as it is long enough: its timed output is checked against those hashes below.
+    golden_hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    use_golden = T <= len(golden_hashes)
     paths, parsed = [], []
     for g in range(DISTINCT):
-        path = synth_cases.generate(synth_args(T, 1000 + 16 * rank + g))
+        path = synth_cases.generate("cfg3_1080p_allp") if (g == 0 and use_golden) else synth_cases.generate(synth_args(T, 1000 + 16 * rank + g))
         paths.append(path)
-        pics = Parser(quiet=True, lib=lib).parse_stream(open(path, "rb").read())
+        pics = Parser(quiet=True, lib=lib).parse_stream(open(path, "rb").read(), limit=T)
         assert len(pics) == T and all(p.desc.slice_type == 0 for p in pics[1:])
         parsed.append(pics)
     hip = HipReconstructor(MB_W, MB_H, n_streams=S, slots=2, max_pictures=S * T, device=local_rank, lib=lib)
@@ -171,14 +263,19 @@ def main():
     timing = hip.timing_read()
     hip.timing_enable(False)
 
-    # ---- spot-check of the timed output against the oracle (size-independent property: the last
-    #      picture of stream 0 and of a cloned stream must equal the CPU oracle's) is done in tests;
-    #      here: cloned streams must agree with their source stream bit for bit ----
-    if S > DISTINCT:
-        import numpy as np
-        last_slot = parsed[0][-1].desc.dst_slot
-        a, b = hip.read_frame(0, last_slot), hip.read_frame(DISTINCT, last_slot)
-        assert all(np.array_equal(x, y) for x, y in zip(a, b)), "stream copies diverged"
+    # ---- the timed output against the real reference decoder: the last picture of stream 0 and of its last clone must
+    #      hash to what the reference produced for that picture of the golden stream (committed fixture) ----
+    from tests.conftest import frame_sha256
+    last = parsed[0][-1].desc.dst_slot
+    golden_check = {"stream": "cfg3_1080p_allp", "picture": T - 1, "checked": False}
+    if use_golden:
+        clone = S - 1 - (S - 1) % DISTINCT                  # the last stream that decodes stream 0's pictures
+        for s in sorted({0, clone}):
+            got = frame_sha256(*hip.read_frame(s, last))
+            if got != golden_hashes[T - 1]:
+                raise SystemExit("bench.py: stream %d picture %d differs from the reference decoder (%s != %s)" % (s, T - 1, got[:16], golden_hashes[T - 1][:16]))
+        golden_check.update(checked=True, streams_checked=sorted({0, clone}), sha256=golden_hashes[T - 1][:16] + "...",
+                            source="tests/golden/synth_cfg3_1080p_allp.sha256 (oracle/_ref, the real reference decoder)")
 
     copy_gbps = measured_copy_bandwidth(torch) if rank == 0 else None
     if rank == 0:
@@ -190,14 +287,19 @@ def main():
             ms, cnt = timing[name]
             if cnt:
                 avg = ms / cnt
-                kernels[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "algorithmic_bytes": alg[name],
-                                 "GBps": round(alg[name] / (avg * 1e-3) / 1e9, 1)}
+                gbps = alg[name] / (avg * 1e-3) / 1e9
+                kernels[name] = {"kernels": STAGE_KERNELS[name], "avg_ms": round(avg, 4), "launches": int(cnt), "algorithmic_bytes": alg[name],
+                                 "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4)}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        traffic = None
+        # HBM traffic cannot be counted inside this run (PMC counters need rocprofv3 passes of their own): it is replayed from
+        # the committed summary of the same command profiled on the same code (profiles/collect.sh), and says so
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom)
+                traffic_source = "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
             except Exception:
                 traffic = None
         out = {
@@ -208,17 +310,21 @@ def main():
                                    "reconstruction hot path (MC + residual, intra, deblock), parsed inputs resident in HBM",
                        "streams_per_gpu": S, "pictures_per_step": S * world, "mb_per_picture": N_MB, "parallelism": "stream-parallel x%d" % world},
             "macroblocks_per_s": round(fps * N_MB, 0),
-            "roofline": {"kernel": {"inter": "k_inter + k_inter_quads", "intra": "k_intra", "deblock": "k_deblock_bs + k_deblock"}[dom], "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
+            "roofline": {"kernel": STAGE_KERNELS[dom], "stage": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
                          "measured_copy_GBps": copy_gbps},
             "kernels": kernels,
             "reconstruct_call_ms": round(timing["reconstruct"][0] / max(timing["reconstruct"][1], 1), 4),
+            "golden_check": golden_check,
         }
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: a reported baseline, not part of the scaling runs
             out["cpu_baseline"] = cpu_baseline(paths[0], T)
-        print(json.dumps(out), flush=True)
     hip.close()
+    if rank == 0:
+        if not args.no_extras and world == 1:
+            out["extras"] = extras(lib)
+        print(json.dumps(out), flush=True)
     shard.barrier()
     if world > 1:
         import torch.distributed as dist

@@ -66,12 +66,9 @@ typedef struct p264hip_mb {
     uint8_t  avail;        /* P264_AVAIL_*: neighbouring MBs usable for intra prediction
                               (core/macroblock.c:926-1033; picture border / slice membership) */
     uint8_t  edges;        /* P264_EDGE_*: which MB edges the loop filter touches (core/frame.c:524) */
-    uint16_t flags;        /* P264_MBF_* */
+    uint16_t flags;        /* reserved, 0 */
 } p264hip_mb_t;
 
-/* flags */
-#define P264_MBF_QUADS      1   /* inter MB with one vector per 8x8 quadrant whose four quadrants are listed in
-                                   p264hip_picture_t.quads: motion-compensated quadrant by quadrant (sorted by phase) */
 #define P264_AVAIL_LEFT     1
 #define P264_AVAIL_TOP      2
 #define P264_AVAIL_TOPRIGHT 4
@@ -101,10 +98,8 @@ typedef struct p264hip_picture {
     const int8_t       *ref_idx;    /* [mb][4] per 8x8 (raster), -1 for intra */
     const uint8_t      *i4modes;    /* [mb][16] Intra4x4PredMode per block in decode order (0..8) */
     const int16_t      *coefs;      /* [n_coef_blocks][16] */
-    /* Optional (NULL / 0: every inter MB takes the per-macroblock kernel).  The 8x8 quadrants of the macroblocks flagged
-     * P264_MBF_QUADS as (mb_index << 2 | quadrant), sorted by the quarter-pel phase (mvy&3)*4 + (mvx&3) of the quadrant's
-     * vector, each phase class padded to a multiple of four entries with 0xffffffff: the GPU works on four quadrants of one
-     * phase at a time, whatever macroblocks they come from.  p264parse fills it; n_quads counts the padding. */
+    /* Reserved, ignored (an earlier version carried a host-built work list here; the motion-compensation work lists are
+     * built on the device now).  Kept so that the structure layout stays what callers were compiled against. */
     const uint32_t     *quads;
     uint32_t            n_quads;
     uint32_t            reserved;

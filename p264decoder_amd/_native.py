@@ -20,7 +20,6 @@ COEF_LUMA_DC = 1 << 24
 COEF_CHROMA_DC = 1 << 25
 AVAIL_LEFT, AVAIL_TOP, AVAIL_TOPRIGHT, AVAIL_TOPLEFT = 1, 2, 4, 8
 EDGE_LEFT, EDGE_TOP, EDGE_INNER = 1, 2, 4
-MBF_QUADS = 1
 
 
 class MbInfo(C.Structure):

@@ -51,7 +51,6 @@ typedef struct { int used, frame_num, pic_num; } dpb_frame_t;
 
 typedef struct {
     p264hip_mb_t *mb; int16_t *mv; int8_t *ref; uint8_t *i4; int16_t *coef;
-    uint32_t *quads; size_t quads_n;                   /* quadrant list of the picture (p264hip.h) */
     size_t coef_cap, coef_n;
     void *(*alloc)(size_t); void (*release)(void *);   /* where the arrays live (p264parse_set_allocator) */
 } picbuf_t;
@@ -174,7 +173,7 @@ static void free_context(p264parse *p)
 {
     for (int i = 0; i < 2; i++) {
         picbuf_t *q = &p->buf[i];
-        if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); q->release(q->quads); }
+        if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); }
         memset(q, 0, sizeof *q);
     }
     free(p->nnz); p->nnz = NULL;
@@ -199,8 +198,7 @@ static int init_context(p264parse *p, int sps_id, int pps_id)
         q->i4  = (uint8_t *)q->alloc(n * 16);
         q->coef_cap = n * 4 + 64;
         q->coef = (int16_t *)q->alloc(q->coef_cap * 16 * sizeof(int16_t));
-        q->quads = (uint32_t *)q->alloc((n * 4 + 64) * sizeof(uint32_t));
-        if (!q->mb || !q->mv || !q->ref || !q->i4 || !q->coef || !q->quads) return -1;
+        if (!q->mb || !q->mv || !q->ref || !q->i4 || !q->coef) return -1;
         memset(q->mb, 0, n * sizeof(p264hip_mb_t)); memset(q->mv, 0, n * 32 * sizeof(int16_t));
         memset(q->ref, 0, n * 4); memset(q->i4, 0, n * 16);
     }
@@ -662,51 +660,6 @@ static long rbsp_stop_bit(const uint8_t *buf, int size)
 }
 
 /* ---------------------------------------------------------------- slice ------------------ */
-/* The quadrant list of p264hip.h: inter macroblocks that carry more than one vector but one per 8x8 quadrant (16x8, 8x16,
- * P_8x8 with 8x8 sub-blocks) are handed to the GPU quadrant by quadrant, counting-sorted by quarter-pel phase so that a
- * wavefront works on four quadrants of the same phase.  Macroblocks with a single vector stay whole; sub-8x8 partitions
- * with differing vectors stay with the per-macroblock kernel. */
-static void build_quads(p264parse *p, picbuf_t *q)
-{
-    q->quads_n = 0;
-    if (p->sh0.type != P264_SLICE_P) return;
-    unsigned count[16] = { 0 }, start[17];
-    const int n = p->n_mb;
-    for (int pass = 0; pass < 2; pass++) {
-        for (int i = 0; i < n; i++) {
-            p264hip_mb_t *m = &q->mb[i];
-            if (pass == 0) m->flags &= (uint16_t)~P264_MBF_QUADS;
-            if (P264_MB_IS_INTRA(m->mb_type) || m->mb_type == P264_MB_P_SKIP) continue;
-            const int32_t *mv = (const int32_t *)(q->mv + (size_t)i * 32);      /* 16 packed (x,y) pairs */
-            const int8_t *rf = q->ref + (size_t)i * 4;
-            if (pass == 0) {
-                int same = rf[0] == rf[1] && rf[0] == rf[2] && rf[0] == rf[3], uniform = 1;
-                for (int k = 1; k < 16 && same; k++) same = mv[k] == mv[0];
-                for (int qd = 0; qd < 4 && uniform; qd++) {
-                    const int b0 = (qd >> 1) * 8 + (qd & 1) * 2;
-                    uniform = mv[b0] == mv[b0 + 1] && mv[b0] == mv[b0 + 4] && mv[b0] == mv[b0 + 5];
-                }
-                if (same || !uniform) continue;
-                m->flags |= P264_MBF_QUADS;
-            } else if (!(m->flags & P264_MBF_QUADS)) continue;
-            for (int qd = 0; qd < 4; qd++) {
-                const int b0 = (qd >> 1) * 8 + (qd & 1) * 2;
-                const int16_t *v = q->mv + ((size_t)i * 16 + b0) * 2;
-                const int cls = (v[1] & 3) * 4 + (v[0] & 3);
-                if (pass == 0) count[cls]++;
-                else q->quads[start[cls]++] = ((uint32_t)i << 2) | (uint32_t)qd;
-            }
-        }
-        if (pass == 0) {
-            unsigned at = 0;
-            for (int c = 0; c < 16; c++) { start[c] = at; at += (count[c] + 3) & ~3u; }
-            start[16] = at;
-            q->quads_n = at;
-            for (unsigned k = 0; k < at; k++) q->quads[k] = 0xffffffffu;
-        }
-    }
-}
-
 static void publish_picture(p264parse *p)
 {
     picbuf_t *q = &p->buf[p->cur];
@@ -724,8 +677,6 @@ static void publish_picture(p264parse *p)
     d->n_coef_blocks = (uint32_t)q->coef_n;
     d->frame_num = (uint32_t)p->sh0.frame_num;
     d->mb = q->mb; d->mv = q->mv; d->ref_idx = q->ref; d->i4modes = q->i4; d->coefs = q->coef;
-    build_quads(p, q);
-    d->quads = q->quads; d->n_quads = (uint32_t)q->quads_n;
 }
 
 /* decoder/decoder.c:502-593,598-664 */

@@ -23,11 +23,10 @@ class ParsedPicture:
         self.i4modes = np.ctypeslib.as_array(desc.i4modes, (n * 16,)).copy()
         nc = int(desc.n_coef_blocks)
         self.coefs = np.ctypeslib.as_array(desc.coefs, (nc * 16,)).copy() if nc else np.zeros(16, np.int16)
-        nq = int(desc.n_quads)
-        self.quads = np.ctypeslib.as_array(desc.quads, (nq,)).copy() if nq else np.zeros(4, np.uint32)
         d = N.Picture()
         C.memmove(C.byref(d), C.byref(desc), C.sizeof(N.Picture))
-        d.quads = C.cast(self.quads.ctypes.data, C.POINTER(C.c_uint32))
+        d.quads = C.POINTER(C.c_uint32)()              # reserved fields of p264hip_picture_t
+        d.n_quads = 0
         d.mb = C.cast(self.mb.ctypes.data, C.POINTER(N.MbInfo))
         d.mv = C.cast(self.mv.ctypes.data, C.POINTER(C.c_int16))
         d.ref_idx = C.cast(self.ref_idx.ctypes.data, C.POINTER(C.c_int8))

@@ -7,7 +7,7 @@ tag=${1:-quick}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BENCH="bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+BENCH="bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $BENCH > $out/trace.log 2>&1 || { echo "trace failed"; tail -5 $out/trace.log; exit 1; }
 python3 - $out <<'PY' | tee $out/stats.txt
 import csv, glob, sys
@@ -24,7 +24,7 @@ for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES"; do
   i=$((i+1))
   echo "[quick] pmc pass $i: $ctr" >> $out/progress.log
-  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $out/pmc$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed: $ctr"; grep -m2 "Missing\|rror" $out/pmc$i.log; }
+  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $out/pmc$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed: $ctr"; grep -m2 "Missing\|rror" $out/pmc$i.log; }
 done
 python3 - $out <<'PY' | tee $out/pmc.txt
 import csv, glob, sys, collections

@@ -28,12 +28,12 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("k_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-# steady state only: the first launch of k_intra / k_deblock* is the IDR picture (all intra), k_inter has none for it
+# steady state only: the first launch of k_intra / k_deblock* is the IDR picture (all intra), the k_mc_* kernels have none for it
 pmc = {}
 for k, ctrs in agg.items():
     pmc[k] = {}
     for c, v in ctrs.items():
-        vals = v[1:] if k != "k_inter" and len(v) > 1 else v
+        vals = v[1:] if not k.startswith("k_mc") and len(v) > 1 else v
         pmc[k][c] = round(sum(vals) / len(vals))
     pmc[k]["launches_averaged"] = len(vals)
 note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
@@ -42,7 +42,7 @@ json.dump({"note": note, **pmc}, open(os.path.join(here, tag + "_pmc.json"), "w"
 
 def hbm(k):
     return int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
-traffic = {"inter": hbm("k_inter") + (hbm("k_inter_quads") if "k_inter_quads" in pmc else 0), "intra": hbm("k_intra"), "deblock": hbm("k_deblock") + hbm("k_deblock_bs"),
+traffic = {"inter": sum(hbm(k) for k in pmc if k.startswith("k_mc_")), "intra": hbm("k_intra"), "deblock": hbm("k_deblock") + hbm("k_deblock_bs"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
 json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(traffic))

@@ -28,7 +28,6 @@ class SeamPicture:
         self.ref_idx = np.zeros(n * 4, np.int8)
         self.i4modes = np.full(n * 16, 2, np.uint8)
         self.coefs = np.zeros(16, np.int16)
-        self.quads = np.zeros(4, np.uint32)
         self.desc = N.Picture()
         self.desc.mb_w, self.desc.mb_h = mb_w, mb_h
 
@@ -40,7 +39,6 @@ class SeamPicture:
         d.ref_idx = C.cast(self.ref_idx.ctypes.data, C.POINTER(C.c_int8))
         d.i4modes = C.cast(self.i4modes.ctypes.data, C.POINTER(C.c_uint8))
         d.coefs = C.cast(self.coefs.ctypes.data, C.POINTER(C.c_int16))
-        d.quads = C.cast(self.quads.ctypes.data, C.POINTER(C.c_uint32))
         return self
 
     @property
@@ -77,7 +75,7 @@ def _levels(rng, n, style):
 
 
 def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=0, level_style="small", qp_mode="random",
-                 mv_range=80, sub8x8=True, intra_share=0.15, slices=1, with_quads=False, deblock_offsets=True):
+                 mv_range=80, sub8x8=True, intra_share=0.15, slices=1, deblock_offsets=True):
     """Draw one picture.  qp_mode: 'random' (0..51 per macroblock), 'two' (two values), or an int (constant)."""
     pic = SeamPicture(mb_w, mb_h)
     d = pic.desc
@@ -227,36 +225,7 @@ def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=
     d.n_coef_blocks = len(blocks)
     if blocks:
         pic.coefs = np.concatenate(blocks).astype(np.int16)
-    if with_quads and p_picture:
-        build_quads(pic)
     return pic.seal()
-
-
-def build_quads(pic):
-    """The optional quadrant list of p264hip.h, as the parser builds it (csrc/host/parser.c build_quads)."""
-    n = pic.n_mb
-    mv = pic.mv.reshape(n, 16, 2)
-    ref = pic.ref_idx.reshape(n, 4)
-    per_class = [[] for _ in range(16)]
-    for m in range(n):
-        t = pic.rec["mb_type"][m]
-        if t <= N.MB_IPCM or t == N.MB_P_SKIP:
-            continue
-        v = mv[m].reshape(4, 4, 2)
-        same = (ref[m] == ref[m, 0]).all() and (v == v[0, 0]).all()
-        uniform = all((v[qy:qy + 2, qx:qx + 2] == v[qy, qx]).all() for qy in (0, 2) for qx in (0, 2))
-        if same or not uniform:
-            continue
-        pic.rec["flags"][m] |= N.MBF_QUADS
-        for q in range(4):
-            vx, vy = v[(q >> 1) * 2, (q & 1) * 2]
-            per_class[(int(vy) & 3) * 4 + (int(vx) & 3)].append((m << 2) | q)
-    out = []
-    for c in per_class:
-        out += c + [0xffffffff] * (-len(c) % 4)
-    if out:
-        pic.quads = np.array(out, np.uint32)
-        pic.desc.n_quads = len(out)
 
 
 def random_frame(rng, mb_w, mb_h, kind="noise"):

@@ -56,28 +56,3 @@ def test_vectors_far_outside_the_picture(lib, oracle):
         for plane, (a, b) in enumerate(zip(got, want)):
             assert np.array_equal(a, b), "picture %d plane %d differs" % (i, plane)
     hip.close()
-
-
-def test_without_quadrant_lists(lib, oracle):
-    """The quadrant list is optional: with the list dropped and the flags cleared, every inter macroblock goes through
-    k_inter (its multi-vector path), and the result is the same."""
-    import ctypes as C
-    from p264decoder_amd import _native as N
-    parser = Parser(quiet=True, lib=lib)
-    pics = parser.parse_stream(synth_cases.stream_bytes("cif_ip"))[:10]
-    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
-    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
-    hip = HipReconstructor(mb_w, mb_h, n_streams=1, slots=parser.slots, max_pictures=1, lib=lib)
-    seen = 0
-    for i, p in enumerate(pics):
-        seen += int((p.mb_records()["flags"] & N.MBF_QUADS).sum())
-        p.mb_records()["flags"][:] = 0
-        p.desc.quads = C.POINTER(C.c_uint32)()
-        p.desc.n_quads = 0
-        want = oracle_bind.reconstruct(oracle, store, p)
-        hip.submit(0, p)
-        got = hip.read_frame(0, p.desc.dst_slot)
-        for plane, (a, b) in enumerate(zip(got, want)):
-            assert np.array_equal(a, b), "picture %d plane %d differs" % (i, plane)
-    assert seen > 0
-    hip.close()

@@ -18,7 +18,7 @@ CONFIGS = [
     ("mixed_levels_3refs", 8, 6, 8, dict(level_style="mixed", qp_mode="random", n_ref=3, slots=4, slices=3)),
     ("two_qps_smooth", 10, 6, 6, dict(level_style="small", qp_mode="two", n_ref=2, slots=3, mv_range=12)),
     ("far_vectors", 6, 5, 5, dict(level_style="small", qp_mode=30, n_ref=1, slots=2, mv_range=600)),
-    ("with_quadrant_list", 9, 6, 6, dict(level_style="large", qp_mode="random", n_ref=2, slots=3, with_quads=True, sub8x8=False)),
+    ("quadrant_partitions_only", 9, 6, 6, dict(level_style="large", qp_mode="random", n_ref=2, slots=3, sub8x8=False)),
     ("sliced_single_column", 1, 9, 5, dict(level_style="mixed", qp_mode="random", n_ref=1, slots=2, slices=4)),
     ("single_row", 11, 1, 5, dict(level_style="mixed", qp_mode="random", n_ref=1, slots=2, slices=3)),
     ("wide_picture", 67, 3, 4, dict(level_style="small", qp_mode="random", n_ref=2, slots=3)),
@@ -107,7 +107,7 @@ def test_seam_fuzz_1080p_batch(lib, oracle):
             hip.write_frame(s, slot, *f)
     for i in range(2):
         pics = [seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=True, dst_slot=i % 2, level_style="mixed" if s == 0 else "small",
-                                       qp_mode="random" if s != 1 else "two", intra_share=0.05, with_quads=(s == 2), sub8x8=(s != 2))
+                                       qp_mode="random" if s != 1 else "two", intra_share=0.05, sub8x8=(s != 2))
                 for s in range(S)]
         hip.upload(0, pics)
         hip.reconstruct(list(range(S)), list(range(S)))

@@ -15,7 +15,7 @@ def run(oracle, seed):
             dst[:] = src
     out = []
     for i in range(4):
-        pic = seam_fuzz.make_picture(rng, 7, 5, p_picture=(i != 1), n_ref=2, slots=3, dst_slot=i % 3, level_style="mixed", slices=2, with_quads=True)
+        pic = seam_fuzz.make_picture(rng, 7, 5, p_picture=(i != 1), n_ref=2, slots=3, dst_slot=i % 3, level_style="mixed", slices=2)
         rec = pic.rec
         # coefficient stream: indices are consecutive, block counts match the masks
         want_index = 0

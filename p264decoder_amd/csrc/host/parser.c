@@ -63,6 +63,7 @@ struct p264parse {
     int mb_w, mb_h, n_mb, slots;
 
     picbuf_t buf[2]; int cur;                 /* cur: being built; 1-cur: last completed */
+    picbuf_t retired[2];                      /* the buffers of the previous context: released at the NEXT re-init (see free_context) */
     void *(*alloc)(size_t); void (*release)(void *);
     p264hip_picture_t desc[2];
     uint8_t  *nnz;                            /* [n_mb][24] total_coeff per 4x4 block */
@@ -72,6 +73,7 @@ struct p264parse {
     int pic_is_idr, pic_ref_idc;
     slice_t sh;                               /* current slice */
     slice_t sh0;                              /* first slice of the picture */
+    int pic_deblock, pic_alpha, pic_beta;     /* loop filter of the picture: on if any slice enables it, offsets of the first such slice */
     int list0[P264HIP_MAX_REFS], n_list0;
 
     dpb_frame_t dpb[P264HIP_MAX_REFS + 1];
@@ -128,7 +130,14 @@ static int parse_sps(p264parse *p, bitrd_t *b)
     if (br_u1(b)) for (int i = 0; i < 4; i++) s->crop[i] = (int)br_ue(b);   /* parsed, never applied (A-Q1) */
     br_u1(b);                                       /* vui_parameters_present: not parsed, like set.c:136-144 */
     if (br_eof(b)) { ERR(p, "incomplete SPS"); return -1; }
-    if (s->log2_max_frame_num > 16 || s->mb_w > 1024 || s->mb_h > 1024 || s->num_ref_frames > 16) return -1;
+    /* untrusted input: H.264 7.4.2.1 ranges (the slice header reads fields of these widths; sizes drive every allocation) */
+    if (s->log2_max_frame_num < 4 || s->log2_max_frame_num > 16 || (s->poc_type == 0 && (s->log2_max_poc_lsb < 4 || s->log2_max_poc_lsb > 16)) ||
+        s->mb_w < 1 || s->mb_w > 1024 || s->mb_h < 1 || s->mb_h > 512 || s->num_ref_frames < 0 || s->num_ref_frames > 16) {
+        ERR(p, "SPS field out of range (frame_num bits %d, poc bits %d, %dx%d macroblocks, %d reference frames)",
+            s->log2_max_frame_num, s->log2_max_poc_lsb, s->mb_w, s->mb_h, s->num_ref_frames);
+        *s = old;                                   /* keep the set we had */
+        return -1;
+    }
     s->valid = 1;
     if ((int)id == p->active_sps && (old.mb_w != s->mb_w || old.mb_h != s->mb_h || old.num_ref_frames != s->num_ref_frames))
         p->active_sps = -1;                         /* same id, new geometry: force a context re-init */
@@ -145,13 +154,14 @@ static int parse_pps(p264parse *p, bitrd_t *b)
     pps_t *q = &p->pps[id];
     memset(q, 0, sizeof *q);
     q->sps_id = (int)br_ue(b);
-    if (q->sps_id >= 32) return -1;
+    if (q->sps_id < 0 || q->sps_id >= 32) return -1;
     q->cabac = (int)br_u1(b);
     q->pic_order_present = (int)br_u1(b);
     q->num_slice_groups = (int)br_ue(b) + 1;
     if (q->num_slice_groups > 1) { ERR(p, "FMO unsupported"); return -1; }
     q->num_ref_idx_l0 = (int)br_ue(b) + 1;
     q->num_ref_idx_l1 = (int)br_ue(b) + 1;
+    if (q->num_ref_idx_l0 < 1 || q->num_ref_idx_l0 > 32 || q->num_ref_idx_l1 < 1 || q->num_ref_idx_l1 > 32) { ERR(p, "pps: num_ref_idx out of range"); return -1; }
     q->weighted_pred = (int)br_u1(b);
     q->weighted_bipred = (int)br_u(b, 2);
     q->pic_init_qp = br_se(b) + 26;
@@ -169,12 +179,20 @@ static int parse_pps(p264parse *p, bitrd_t *b)
 }
 
 /* ---------------------------------------------------------------- context --------------- */
-static void free_context(p264parse *p)
+static void release_bufs(picbuf_t *q)
+{
+    if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); }
+    memset(q, 0, sizeof *q);
+}
+/* A caller may still be reading the last completed picture's arrays when the next slice re-initialises the context (the
+ * pipeline issues its asynchronous uploads while the parser threads are already on the next picture), so a re-init only
+ * RETIRES the current buffers; they are released by the re-init after that, or by close. */
+static void free_context(p264parse *p, int final)
 {
     for (int i = 0; i < 2; i++) {
-        picbuf_t *q = &p->buf[i];
-        if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); }
-        memset(q, 0, sizeof *q);
+        release_bufs(&p->retired[i]);
+        if (final) release_bufs(&p->buf[i]);
+        else { p->retired[i] = p->buf[i]; memset(&p->buf[i], 0, sizeof p->buf[i]); }
     }
     free(p->nnz); p->nnz = NULL;
     free(p->slice_of); p->slice_of = NULL;
@@ -184,7 +202,7 @@ static void free_context(p264parse *p)
 static int init_context(p264parse *p, int sps_id, int pps_id)
 {
     const sps_t *s = &p->sps[sps_id];
-    free_context(p);
+    free_context(p, 0);
     p->mb_w = s->mb_w; p->mb_h = s->mb_h; p->n_mb = s->mb_w * s->mb_h;
     p->slots = s->num_ref_frames + 1;
     if (p->slots < 2) p->slots = 2;
@@ -223,7 +241,7 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
     sh->type = (int)br_ue(b);
     if (sh->type >= 5) sh->type -= 5;
     sh->pps_id = (int)br_ue(b);
-    if (br_eof(b) || sh->pps_id >= 256 || !p->pps[sh->pps_id].valid) {
+    if (br_eof(b) || sh->pps_id < 0 || sh->pps_id >= 256 || !p->pps[sh->pps_id].valid) {
         ERR(p, "invalid pps_id %d in slice header", sh->pps_id); return -1;
     }
     const pps_t *pps = &p->pps[sh->pps_id];
@@ -247,7 +265,7 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
     if (sh->type == P264_SLICE_P) {
         sh->num_ref_idx = pps->num_ref_idx_l0;
         if (br_u1(b)) sh->num_ref_idx = (int)br_ue(b) + 1;
-        if (sh->num_ref_idx > P264HIP_MAX_REFS) { ERR(p, "num_ref_idx_l0_active %d too large", sh->num_ref_idx); return -1; }
+        if (sh->num_ref_idx < 1 || sh->num_ref_idx > P264HIP_MAX_REFS) { ERR(p, "num_ref_idx_l0_active %d too large", sh->num_ref_idx); return -1; }
         if (br_u1(b)) {                                           /* ref_pic_list_reordering_flag_l0 */
             for (;;) {
                 unsigned idc = br_ue(b);
@@ -669,8 +687,8 @@ static void publish_picture(p264parse *p)
     d->mb_w = p->mb_w; d->mb_h = p->mb_h;
     d->slice_type = p->sh0.type;
     d->chroma_qp_offset = pps->chroma_qp_offset;
-    d->deblock = (!pps->deblock_ctrl || p->sh0.disable_deblock != 1) ? 1 : 0;
-    d->alpha_c0_offset = p->sh0.alpha_off; d->beta_offset = p->sh0.beta_off;
+    d->deblock = (!pps->deblock_ctrl || p->pic_deblock) ? 1 : 0;     /* per-macroblock `edges` gate the slices that switch it off */
+    d->alpha_c0_offset = p->pic_alpha; d->beta_offset = p->pic_beta;
     d->dst_slot = p->cur_slot;
     d->n_ref = p->n_list0;
     for (int i = 0; i < p->n_list0; i++) d->ref_slot[i] = p->list0[i];
@@ -689,8 +707,17 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
     if (rc < 0) { ERR(p, "slice header decode failed"); return -1; }
     if (rc > 0) return 0;
     const pps_t *pps = &p->pps[sh.pps_id];
-    if (p->active_sps < 0 || p->active_sps != pps->sps_id || p->active_pps != sh.pps_id || !p->buf[0].mb)
-        if (init_context(p, pps->sps_id, sh.pps_id) < 0) { ERR(p, "out of memory"); return -1; }
+    /* A new context (buffers, frame store) only when the picture geometry or the frame-store size changes; switching
+     * between parameter sets of the same geometry just activates them (H.264 7.4.1.2.1: the frame store lives on.  The
+     * reference loops forever in its context switch here, decoder/decoder.c:380-396, so there is nothing to match). */
+    {
+        const sps_t *sps = &p->sps[pps->sps_id];
+        int slots = sps->num_ref_frames + 1;
+        if (slots < 2) slots = 2;
+        if (p->active_sps < 0 || !p->buf[0].mb || sps->mb_w != p->mb_w || sps->mb_h != p->mb_h || slots != p->slots) {
+            if (init_context(p, pps->sps_id, sh.pps_id) < 0) { ERR(p, "out of memory"); return -1; }
+        } else { p->active_sps = pps->sps_id; p->active_pps = sh.pps_id; }
+    }
 
     if (sh.first_mb == 0 || !p->pic_open) {
         /* first slice of a new picture */
@@ -702,18 +729,25 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
             p->cur_slot = 0;
         }
         p->sh0 = sh;
+        p->pic_deblock = 0; p->pic_alpha = p->pic_beta = 0;
         p->buf[p->cur].coef_n = 0;
         memset(p->slice_of, 0xff, (size_t)p->n_mb * sizeof(uint16_t));
         p->n_list0 = 0;
     } else {
         if (sh.first_mb != p->next_mb) { ERR(p, "slice starts at MB %d, expected %d", sh.first_mb, p->next_mb); return -1; }
-        if (sh.disable_deblock != p->sh0.disable_deblock || sh.alpha_off != p->sh0.alpha_off || sh.beta_off != p->sh0.beta_off)
-            if (!(sh.disable_deblock == 1 || p->sh0.disable_deblock == 1)) { ERR(p, "per-slice deblocking offsets unsupported"); return -1; }
         p->slice_no++;
+    }
+    if (sh.disable_deblock != 1) {                /* the filter parameters are per picture on the device */
+        if (!p->pic_deblock) { p->pic_deblock = 1; p->pic_alpha = sh.alpha_off; p->pic_beta = sh.beta_off; }
+        else if (sh.alpha_off != p->pic_alpha || sh.beta_off != p->pic_beta) { ERR(p, "per-slice deblocking offsets unsupported"); return -1; }
     }
     p->sh = sh;
     if (sh.type == P264_SLICE_P) {
+        int prev[P264HIP_MAX_REFS], n_prev = p->n_list0;
+        memcpy(prev, p->list0, sizeof prev);
         if (build_list0(p, &sh) < 0) return -1;
+        /* reference indices are resolved through ONE list per picture on the device */
+        if (n_prev && (n_prev != p->n_list0 || memcmp(prev, p->list0, sizeof(int) * (size_t)n_prev))) { ERR(p, "slices of one picture with different reference lists unsupported"); return -1; }
         p->sh0.type = P264_SLICE_P;               /* a picture with any P slice is reconstructed as P */
     }
     p->qp_pred = sh.qp;
@@ -768,7 +802,7 @@ void p264parse_set_allocator(p264parse *p, void *(*alloc)(size_t bytes), void (*
 void p264parse_close(p264parse *p)
 {
     if (!p) return;
-    free_context(p);
+    free_context(p, 1);
     free(p);
 }
 

@@ -24,6 +24,8 @@
  *            [--reorder]     with --refs 2: some P slices swap the two entries of list 0 (ref_pic_list_reordering; ignored by
  *                            the reference, decoder/lists.c:146-149)
  *            [--dump-mv f]   additionally records, per picture, one byte: 1 when list 0 was reordered
+ *            [--pps-alt]     two identical PPS (ids 0 and 1), pictures alternate between them: every picture re-activates a
+ *                            parameter set (context re-initialisation in the decoder, decoder/decoder.c:304-343)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -94,6 +96,7 @@ static uint8_t *nnz;                        /* [mb][24] */
 static int8_t  *i4m;                        /* [mb][16], 2 for non-I4x4 */
 static int cur;                             /* current MB index */
 
+static int opt_pps_alt = 0, cur_pps = 0;
 static int opt_qpdelta = 0, opt_alpha = 0, opt_beta = 0, opt_sub8x8 = 0, opt_reorder = 0, slice_reordered;
 static int opt_idc = 0;                     /* --deblock-idc 2: no filtering across slice boundaries */
 static int opt_slices = 1, slice_first;     /* --slices: equal runs of macroblocks; slice_first = first MB of the current slice */
@@ -440,7 +443,7 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         bw_t b = { 0 };
         bw_ue(&b, (uint32_t)first);                 /* first_mb_in_slice */
         bw_ue(&b, is_p ? 5 : 7);                    /* slice_type: all slices of the picture alike */
-        bw_ue(&b, 0);                               /* pps id */
+        bw_ue(&b, (uint32_t)cur_pps);               /* pps id */
         bw_put(&b, log2_fn, (uint32_t)frame_num);
         if (idr) bw_ue(&b, (uint32_t)idr_id);
         if (is_p) {
@@ -508,6 +511,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--deblock-offsets")) { opt_alpha = v; opt_beta = i + 2 < argc ? atoi(argv[i + 2]) : 0; i += 2; }
         else if (!strcmp(a, "--sub8x8")) opt_sub8x8 = 1;
         else if (!strcmp(a, "--reorder")) opt_reorder = 1;
+        else if (!strcmp(a, "--pps-alt")) opt_pps_alt = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
     if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > 2 || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
@@ -530,9 +534,9 @@ int main(int argc, char **argv)
         bw_trailing(&b);
         write_nal(f, 3, 7, &b); free(b.buf);
     }
-    {   /* PPS: CAVLC, deblocking control present */
+    for (int pps = 0; pps <= opt_pps_alt; pps++) {   /* PPS: CAVLC, deblocking control present */
         bw_t b = { 0 };
-        bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 1, 0); bw_ue(&b, 0);
+        bw_ue(&b, (uint32_t)pps); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 1, 0); bw_ue(&b, 0);
         bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 2, 0);
         bw_se(&b, opt_qp - 26); bw_se(&b, 0); bw_se(&b, opt_cqo);
         bw_put(&b, 1, 1); bw_put(&b, 1, 0); bw_put(&b, 1, 0);
@@ -543,6 +547,7 @@ int main(int argc, char **argv)
     for (int n = 0; n < frames; n++) {
         int idr = intra_only || n == 0 || (gop > 0 && n % gop == 0);
         if (idr) { frame_num = 0; since_idr = 0; }
+        cur_pps = opt_pps_alt ? (n & 1) : 0;
         put_slice(f, idr, !idr, frame_num, idr_id, log2_fn, since_idr);   /* since_idr = reference pictures available (sliding window) */
         since_idr++;
         if (idr) idr_id = (idr_id + 1) & 0xffff;

@@ -73,3 +73,64 @@ def test_parser_allocator_hook(lib, f26):
     assert total[0] >= 10                                               # 2 buffers x 5 arrays
     lib.p264parse_close(h)
     assert not live                                                     # everything given back
+
+
+def test_parameter_set_switches(lib):
+    """(1) A stream that alternates between two PPS ids of one SPS keeps its context and its frame store (H.264: activating
+    another PPS changes nothing else; P pictures still find their reference).  (2) A stream whose picture size changes
+    re-initialises the context; the buffers of the picture handed out just before must survive that (the pipeline is
+    still uploading from them): a re-init only retires them.  Under tests/tools/asan_host.sh both are use-after-free checks."""
+    import numpy as np
+    args = "--mbw 6 --mbh 5 --frames 12 --gop 6 --seed 61 --coded 20 --maxlevel 6"
+    one = open(synth_cases.generate(args), "rb").read()
+    alt = open(synth_cases.generate(args + " --pps-alt"), "rb").read()
+    pa = Parser(quiet=True, lib=lib).parse_stream(one)
+    b = Parser(quiet=True, lib=lib)
+    pb = b.parse_stream(alt)
+    assert len(pa) == len(pb) == 12 and lib.p264parse_generation(b.h) == 1
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x.mb, y.mb) and np.array_equal(x.mv, y.mv) and np.array_equal(x.coefs, y.coefs)
+    # picture size change in the middle of a stream
+    other = open(synth_cases.generate("--mbw 8 --mbh 6 --frames 6 --gop 3 --seed 62 --coded 20 --maxlevel 6"), "rb").read()
+    c = Parser(quiet=True, lib=lib)
+    held = []
+    for typ, idc, rbsp in N.split_annexb(lib, one + other + one):
+        pic = C.POINTER(N.Picture)()
+        buf = (C.c_uint8 * max(len(rbsp), 1)).from_buffer_copy(rbsp if len(rbsp) else b"\0")
+        rc = lib.p264parse_nal(c.h, typ, idc, buf, len(rbsp), C.byref(pic))
+        assert rc >= 0
+        if held and rc == 0:                                         # the last picture's arrays are still readable and unchanged,
+            ptr, n, copy = held[-1][1:]                              # also right after a re-initialisation
+            assert np.array_equal(np.ctypeslib.as_array(ptr, (n,)), copy)
+        if rc == 1:
+            d = pic.contents
+            n = d.mb_w * d.mb_h * 32
+            held.append((d.mb_w, d.mv, n, np.ctypeslib.as_array(d.mv, (n,)).copy()))
+    assert len(held) == 30 and lib.p264parse_generation(c.h) == 3
+    assert [h[0] for h in held[10:14]] == [6, 6, 8, 8]
+    ref_other = Parser(quiet=True, lib=lib).parse_stream(other)
+    assert np.array_equal(held[12 + 5][3], ref_other[5].mv)
+    pipe = Pipeline([alt, one, alt], threads=3, device=-1, lib=lib)
+    st = pipe.run()
+    assert st["pictures"] == 36
+    pipe.close()
+
+
+@pytest.mark.parametrize("field,value", [("log2_max_frame_num", 40), ("poc_lsb", 60), ("mb_w", 5000), ("num_ref_frames", 99), ("mb_h", 100000)])
+def test_sps_fields_out_of_range_are_rejected(lib, field, value):
+    """parse_sps validates the H.264 ranges before the set can be activated (shift widths, allocation sizes)."""
+    from tests.tools.bitwriter import BitWriter
+    w = BitWriter()
+    w.u(8, 66); w.u(8, 0xc0); w.u(8, 40)
+    w.ue(0)                                                         # sps id
+    w.ue(value - 4 if field == "log2_max_frame_num" else 4)
+    w.ue(0)                                                         # poc type 0
+    w.ue(value - 4 if field == "poc_lsb" else 4)
+    w.ue(value if field == "num_ref_frames" else 1); w.u(1, 0)
+    w.ue(value - 1 if field == "mb_w" else 5); w.ue(value - 1 if field == "mb_h" else 4)
+    w.u(1, 1); w.u(1, 1); w.u(1, 0); w.u(1, 0)
+    w.trailing()
+    p = Parser(quiet=True, lib=lib)
+    with pytest.raises(Exception):
+        p.feed(7, 3, w.bytes())
+    assert lib.p264parse_mb_width(p.h) == 0

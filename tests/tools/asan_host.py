@@ -6,8 +6,8 @@ from tests import synth_cases
 data = open(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'golden', 'f26.264'),'rb').read()
 pics = Parser(quiet=True, lib=lib).parse_stream(data)
 print("f26 pictures", len(pics))
-for name in ["cif_ip","tiny_1x1","row_1xN","col_Nx1","wide_70","qp51","dense","mv_far","cqo_neg"]:
-    p = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes(name))
+for name in ["cif_ip","--mbw 6 --mbh 5 --frames 12 --gop 6 --seed 61 --coded 20 --maxlevel 6 --pps-alt","tiny_1x1","row_1xN","col_Nx1","wide_70","qp51","dense","mv_far","cqo_neg"]:
+    p = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes(name) if name in synth_cases.CASES else open(synth_cases.generate(name), "rb").read())
     print(name, len(p))
 # truncated / corrupted streams must not crash
 import random
@@ -38,5 +38,28 @@ for trial in range(40):
     except RuntimeError:
         pass
 print("pipeline fuzz ok")
+# picture size changing in mid-stream: the context is rebuilt while the previous picture's buffers are still held
+a = open(synth_cases.generate("--mbw 6 --mbh 5 --frames 12 --gop 6 --seed 61 --coded 20 --maxlevel 6"), "rb").read()
+b = open(synth_cases.generate("--mbw 8 --mbh 6 --frames 6 --gop 3 --seed 62 --coded 20 --maxlevel 6"), "rb").read()
+print("size switch", len(Parser(quiet=True, lib=lib).parse_stream(a + b + a + b)))
+pipe = Pipeline([a + a, b + b, a], threads=3, device=-1, lib=lib)
+print(pipe.run()["pictures"]); pipe.close()
+# crafted parameter sets with fields far outside their ranges
+from tests.tools.bitwriter import BitWriter
+for frame_bits, poc_bits, w_mb, h_mb, refs in [(60, 4, 6, 5, 1), (4, 70, 6, 5, 1), (4, 4, 1 << 20, 5, 1), (4, 4, 6, 1 << 25, 1), (4, 4, 6, 5, 1 << 30), (4, 4, 0xffffffff, 0xffffffff, 0xffffffff)]:
+    w = BitWriter()
+    w.u(8, 66); w.u(8, 0xc0); w.u(8, 40); w.ue(0); w.ue(frame_bits - 4); w.ue(0); w.ue(poc_bits - 4); w.ue(refs); w.u(1, 0)
+    w.ue((w_mb - 1) & 0xffffffff); w.ue((h_mb - 1) & 0xffffffff); w.u(1, 1); w.u(1, 1); w.u(1, 0); w.u(1, 0); w.trailing()
+    p = Parser(quiet=True, lib=lib)
+    try:
+        p.feed(7, 3, w.bytes())
+    except Exception:
+        pass
+    for typ, idc, rbsp in list(N.split_annexb(lib, synth_cases.stream_bytes("cif_ip")))[1:4]:      # PPS + slices against the bad SPS
+        try:
+            p.feed(typ, idc, rbsp)
+        except Exception:
+            pass
+print("crafted SPS ok")
 pipe = Pipeline([data, synth_cases.stream_bytes("cif_ip")]*3, threads=4, device=-1, lib=lib)
 print(pipe.run()); pipe.close()

@@ -1,0 +1,82 @@
+/* p264fan.h - C ABI of the stream fan-out (BASELINE.json configs[4], SURVEY 8e "Collective").
+ *
+ * One rank - the ROOT, rank 0 - owns the Annex-B inputs and the I420 outputs, as the reference's CLI does for its single
+ * stream (p264decoder.c:164-381: read file, decode, write_frame).  It runs the CAVLC parsers and SCATTERS every parsed
+ * picture (the arrays of p264hip_picture_t, typically ~1.5 MB for 1080p) to the rank that owns the picture's stream -
+ * stream s lives on rank s % world with its own frame store, because P pictures need the stream's previous pictures - and
+ * GATHERS the reconstructed picture (3 133 440 bytes of MB-aligned I420 for 1080p) back.  There is no counterpart in the
+ * reference: it is single-threaded and single-stream (core/core.c:48; core/core.h:239 is never populated).
+ *
+ * The exchange is point to point - RCCL has no scatter / gather primitive - through a small transport interface:
+ *   rccl  grouped ncclSend / ncclRecv over xGMI, one process per GPU (librccl is loaded on demand); the host buffers of
+ *         this interface are staged through device memory on both ends
+ *   tcp   blocking sockets (127.0.0.1 or any host): the same protocol without RCCL - world-size-2 tests on CPUs,
+ *         or ranks on different machines
+ * and the reconstruction of a picture goes through a backend interface whose default is this library's MI355X path
+ * (p264hip_create / p264hip_submit / p264hip_read_frame on the rank's device).  A rank without a HIP device fails
+ * loudly: there is no CPU reconstruction in the product (tests plug the CPU oracle in through the backend interface).
+ *
+ * Per round the root sends every worker ONE control block (how many pictures, their sizes, or "finished") and then the
+ * pictures; the worker reconstructs them and sends the planes back.  All sends and receives of a step are posted between
+ * group_begin / group_end (ncclGroupStart / ncclGroupEnd).
+ */
+#ifndef P264FAN_H
+#define P264FAN_H
+#include <stdint.h>
+#include <stddef.h>
+#include "p264hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct p264fan p264fan;
+
+/* Point-to-point transport between ranks.  Buffers are host memory; a call may return before the transfer has happened
+ * when it is issued inside group_begin / group_end, which completes everything posted in between.  0 = ok. */
+typedef struct p264fan_transport {
+    void *ctx;
+    int (*send)(void *ctx, int peer, const void *buf, size_t bytes);
+    int (*recv)(void *ctx, int peer, void *buf, size_t bytes);
+    int (*group_begin)(void *ctx);
+    int (*group_end)(void *ctx);
+    void (*close)(void *ctx);
+    const char *name;
+} p264fan_transport_t;
+
+/* Reconstruction of one picture of one local stream; i420 receives the MB-aligned planes Y, U, V back to back. */
+typedef struct p264fan_backend {
+    void *ctx;
+    int (*open)(void **ctx, int device, int mb_w, int mb_h, int n_local_streams, int slots);
+    int (*reconstruct)(void *ctx, int local_stream, const p264hip_picture_t *pic, uint8_t *i420);
+    void (*close)(void *ctx);
+} p264fan_backend_t;
+
+typedef struct {
+    int64_t pictures, pictures_remote;   /* decoded in total / on other ranks */
+    int64_t bytes_scattered, bytes_gathered;
+    double  seconds, parse_seconds, exchange_seconds;
+    int     rounds, world;
+} p264fan_stats_t;
+
+/* called on the root for every reconstructed picture, in decode order per stream */
+typedef void (*p264fan_frame_cb)(void *user, int stream, int64_t picture, int width, int height, const uint8_t *i420);
+
+/* transports */
+int  p264fan_tcp_transport(p264fan_transport_t *t, int rank, int world, const char *root_host, int port);
+int  p264fan_rccl_unique_id(uint8_t id[128]);                                      /* on one rank; hand the bytes to all */
+int  p264fan_rccl_transport(p264fan_transport_t *t, int rank, int world, const uint8_t id[128], int device);
+
+/* backend = NULL: the MI355X path of this library on `device` */
+p264fan *p264fan_open(int rank, int world, const p264fan_transport_t *t, const p264fan_backend_t *backend, int device);
+/* rank 0: decode n_streams Annex-B streams (all of one picture size) to their end or max_pictures each (0 = all) */
+int  p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, const int64_t *sizes, int max_pictures,
+                      p264fan_frame_cb on_frame, void *user, p264fan_stats_t *stats);
+/* every other rank: serve the root until it says "finished" */
+int  p264fan_worker_run(p264fan *f);
+void p264fan_close(p264fan *f);           /* closes the transport too */
+const char *p264fan_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -18,8 +18,8 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libp264amd.so")
 TOOLS_DIR = os.path.join(HERE, "tools")
 
-HOST_SRCS = ["parser.c", "vlc.c", "dropin.c", "pipeline.c"]
-HIP_SRCS = ["p264hip.hip"]
+HOST_SRCS = ["parser.c", "vlc.c", "dropin.c", "pipeline.c", "fanout.c"]
+HIP_SRCS = ["p264hip.hip", "fan_rccl.hip"]
 HIP_ARCH = "gfx950"
 
 
@@ -74,7 +74,7 @@ def build(force=False, verbose=False):
                 print(out)
         objs.append(obj)
     if force or _newer(LIB, objs):
-        _run([hipcc, "--offload-arch=" + HIP_ARCH, "-shared", "-o", LIB] + objs + ["-lpthread"])
+        _run([hipcc, "--offload-arch=" + HIP_ARCH, "-shared", "-o", LIB] + objs + ["-lpthread", "-ldl"])
     build_tools(force=force)
     return LIB
 

@@ -1,0 +1,123 @@
+// fan_rccl.hip - the RCCL transport of the stream fan-out (include/p264fan.h): grouped ncclSend / ncclRecv over xGMI,
+// one process per GPU.  librccl is loaded on demand (dlopen), so the library itself does not depend on it.  The
+// interface hands over host buffers; they are staged through device memory on both ends (a send copies host -> device
+// and posts ncclSend, a receive posts ncclRecv and copies device -> host when the group ends).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "p264fan.h"
+
+namespace {
+struct Uid { char internal[128]; };                       // ncclUniqueId (rccl.h:43)
+typedef void *Comm;
+typedef int (*fn_uid)(Uid *);
+typedef int (*fn_init)(Comm *, int, Uid, int);
+typedef int (*fn_sr)(void *, size_t, int, int, Comm, hipStream_t);
+typedef int (*fn_v)();
+typedef int (*fn_destroy)(Comm);
+typedef const char *(*fn_err)(int);
+struct Api { void *lib = nullptr; fn_uid uid; fn_init init; fn_sr send, recv; fn_v gstart, gend; fn_destroy destroy; fn_err err; };
+Api g_api;
+bool load_api()
+{
+    if (g_api.lib) return true;
+    // an RCCL that is already part of the process (PyTorch brings its own) first: two instances must not be mixed
+    void *l = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!l) l = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!l) l = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!l) l = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!l) { fprintf(stderr, "p264fan: cannot load librccl.so: %s\n", dlerror()); return false; }
+    g_api.uid = (fn_uid)dlsym(l, "ncclGetUniqueId"); g_api.init = (fn_init)dlsym(l, "ncclCommInitRank");
+    g_api.send = (fn_sr)dlsym(l, "ncclSend"); g_api.recv = (fn_sr)dlsym(l, "ncclRecv");
+    g_api.gstart = (fn_v)dlsym(l, "ncclGroupStart"); g_api.gend = (fn_v)dlsym(l, "ncclGroupEnd");
+    g_api.destroy = (fn_destroy)dlsym(l, "ncclCommDestroy"); g_api.err = (fn_err)dlsym(l, "ncclGetErrorString");
+    if (!g_api.uid || !g_api.init || !g_api.send || !g_api.recv || !g_api.gstart || !g_api.gend || !g_api.destroy) { dlclose(l); fprintf(stderr, "p264fan: librccl.so lacks a symbol\n"); return false; }
+    g_api.lib = l;
+    return true;
+}
+struct Pending { void *host; void *dev; size_t bytes; };    // a receive whose data still sits in its staging buffer
+struct Rccl {
+    Comm comm = nullptr; int device = 0; hipStream_t stream = nullptr;
+    std::vector<void *> stage; std::vector<size_t> cap; size_t used = 0;      // staging buffers of the current group
+    std::vector<Pending> pending;
+    bool in_group = false;
+};
+void *stage_buf(Rccl *r, size_t bytes)
+{
+    if (r->used == r->stage.size()) { r->stage.push_back(nullptr); r->cap.push_back(0); }
+    if (r->cap[r->used] < bytes) {
+        if (r->stage[r->used]) (void)hipFree(r->stage[r->used]);
+        r->stage[r->used] = nullptr; r->cap[r->used] = 0;
+        if (hipMalloc(&r->stage[r->used], bytes + bytes / 4) != hipSuccess) return nullptr;
+        r->cap[r->used] = bytes + bytes / 4;
+    }
+    return r->stage[r->used++];
+}
+int finish(Rccl *r)
+{
+    if (hipStreamSynchronize(r->stream) != hipSuccess) return -1;
+    for (auto &p : r->pending) if (hipMemcpy(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    r->pending.clear(); r->used = 0;
+    return 0;
+}
+int rc_send(void *c, int peer, const void *buf, size_t n)
+{
+    Rccl *r = (Rccl *)c;
+    (void)hipSetDevice(r->device);
+    void *d = stage_buf(r, n);
+    if (!d || hipMemcpyAsync(d, buf, n, hipMemcpyHostToDevice, r->stream) != hipSuccess) return -1;
+    if (g_api.send(d, n, 1 /* ncclUint8 */, peer, r->comm, r->stream)) return -1;
+    return r->in_group ? 0 : finish(r);
+}
+int rc_recv(void *c, int peer, void *buf, size_t n)
+{
+    Rccl *r = (Rccl *)c;
+    (void)hipSetDevice(r->device);
+    void *d = stage_buf(r, n);
+    if (!d || g_api.recv(d, n, 1, peer, r->comm, r->stream)) return -1;
+    r->pending.push_back({ buf, d, n });
+    return r->in_group ? 0 : finish(r);
+}
+int rc_begin(void *c) { Rccl *r = (Rccl *)c; r->in_group = true; return g_api.gstart() ? -1 : 0; }
+int rc_end(void *c) { Rccl *r = (Rccl *)c; r->in_group = false; if (g_api.gend()) return -1; return finish(r); }
+void rc_close(void *c)
+{
+    Rccl *r = (Rccl *)c;
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->comm) g_api.destroy(r->comm);
+    for (void *p : r->stage) if (p) (void)hipFree(p);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+}  // namespace
+
+extern "C" int p264fan_rccl_unique_id(uint8_t id[128])
+{
+    if (!id || !load_api()) return -1;
+    Uid u;
+    if (g_api.uid(&u)) return -1;
+    memcpy(id, u.internal, 128);
+    return 0;
+}
+
+extern "C" int p264fan_rccl_transport(p264fan_transport_t *t, int rank, int world, const uint8_t id[128], int device)
+{
+    if (!t || !id || world < 1 || rank < 0 || rank >= world || !load_api()) return -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { fprintf(stderr, "p264fan: no HIP device %d for the RCCL transport\n", device); return -1; }
+    Rccl *r = new Rccl();
+    r->device = device;
+    Uid u; memcpy(u.internal, id, 128);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess || g_api.init(&r->comm, world, u, rank)) {
+        fprintf(stderr, "p264fan: ncclCommInitRank failed (rank %d of %d, device %d)\n", rank, world, device);
+        rc_close(r);
+        return -1;
+    }
+    t->ctx = r; t->send = rc_send; t->recv = rc_recv; t->group_begin = rc_begin; t->group_end = rc_end; t->close = rc_close; t->name = "rccl";
+    return 0;
+}

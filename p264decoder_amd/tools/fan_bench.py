@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""One rank of a fan-out run (include/p264fan.h) over RCCL or TCP: rank 0 owns `--streams` copies of the config-3 stream,
+parses them, scatters the parsed pictures to the ranks owning the streams, gathers the I420 planes and checks every
+picture against the reference decoder's committed hash.  bench.py starts one of these per GPU (as child processes, so
+that a transport problem can never take the timed bench down); also usable by hand:
+
+  python -m p264decoder_amd.tools.fan_bench --rank R --world N --transport rccl --uid <hex> --device D [--streams 8] [--pictures 6]
+  python -m p264decoder_amd.tools.fan_bench --rank R --world N --transport tcp --port 29555
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--transport", default="rccl")
+    ap.add_argument("--uid", default="")
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=29555)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0, help="default: one per rank")
+    ap.add_argument("--pictures", type=int, default=6)
+    a = ap.parse_args()
+    from p264decoder_amd import FanOut, _native
+    from tests import synth_cases
+    lib = _native.load()
+    tr = ("rccl", bytes.fromhex(a.uid)) if a.transport == "rccl" else ("tcp", a.host, a.port)
+    fan = FanOut(a.rank, a.world, tr, device=a.device, lib=lib)
+    if a.rank:
+        fan.worker()
+        fan.close()
+        return
+    n = a.streams or a.world
+    data = synth_cases.stream_bytes("cfg3_1080p_allp")
+    hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    bad = []
+
+    def on_frame(s, i, y, u, v):
+        h = hashlib.sha256()
+        for p in (y, u, v):
+            h.update(p.tobytes())
+        if h.hexdigest() != hashes[i]:
+            bad.append((s, i))
+    st = fan.root([data] * n, max_pictures=a.pictures, on_frame=on_frame)
+    fan.close()
+    out = {"transport": a.transport, "world": a.world, "streams": n, "pictures": st["pictures"], "pictures_on_other_ranks": st["pictures_remote"],
+           "frames_per_s": round(st["pictures"] / st["seconds"], 1), "seconds": round(st["seconds"], 3),
+           "root_parse_seconds": round(st["parse_seconds"], 3), "exchange_seconds": round(st["exchange_seconds"], 3),
+           "scattered_MB": round(st["bytes_scattered"] / 1e6, 2), "gathered_MB": round(st["bytes_gathered"] / 1e6, 2),
+           "all_pictures_match_reference": not bad,
+           "what": "rank 0 parses every stream (single host thread), scatters parsed pictures, gathers I420; bound by the root's parse"}
+    print("FANOUT " + json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""Stream fan-out (include/p264fan.h, BASELINE config 5 / SURVEY 8e) on CPUs: rank 0 owns the Annex-B inputs and the
+I420 outputs, parses, scatters the parsed pictures to the ranks that own the streams and gathers the planes - here over
+the TCP transport with world sizes 1, 2 and 3, the reconstruction behind the backend interface being the CPU oracle
+(no GPU in this suite; the product backend is exercised by tests/test_gpu_fanout.py).  Every gathered picture must hash
+to what the REAL reference decoder produced for it (committed golden hashes)."""
+import os
+
+import pytest
+
+from tests import fan_helpers, synth_cases
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_fanout_tcp_world(lib, f26, f26_hashes, world):
+    cif = synth_cases.stream_bytes("cif_ip")
+    cif_h = synth_cases.golden("cif_ip")[1]
+    qpd = synth_cases.stream_bytes("qpdelta")                   # 11x9 MBs: a different size is a different job
+    streams = [cif, cif, cif, cif, cif]                          # 5 streams over 1..3 ranks: uneven shares
+    got, st = fan_helpers.run_job(world, streams, 10, True, 29500 + world + (os.getpid() % 500))
+    assert st["pictures"] == 50 and st["world"] == world and st["rounds"] == 10
+    assert st["pictures_remote"] == sum(10 for s in range(5) if s % world)
+    assert st["bytes_gathered"] == st["pictures_remote"] * 352 * 288 * 3 // 2
+    for s in range(5):
+        for i in range(10):
+            assert got[(s, i)] == cif_h[i], "stream %d picture %d differs from the reference decoder" % (s, i)
+
+
+def test_fanout_streams_of_different_length(lib, f26, f26_hashes):
+    cif = synth_cases.stream_bytes("cif_ip")                    # 24 pictures, 352x288 like f26
+    cif_h = synth_cases.golden("cif_ip")[1]
+    got, st = fan_helpers.run_job(2, [f26, cif, cif], 0, True, 29600 + (os.getpid() % 300))
+    assert st["pictures"] == 300 + 24 + 24 and st["rounds"] == 300
+    assert all(got[(0, i)] == f26_hashes[i] for i in range(300))
+    assert all(got[(1, i)] == cif_h[i] and got[(2, i)] == cif_h[i] for i in range(24))
+
+
+def test_fanout_symbols_and_errors(lib):
+    from p264decoder_amd.fanout import FanOut
+    for sym in ("p264fan_open", "p264fan_root_run", "p264fan_worker_run", "p264fan_close", "p264fan_tcp_transport",
+                "p264fan_rccl_unique_id", "p264fan_rccl_transport", "p264fan_last_error"):
+        assert hasattr(lib, sym)
+    with pytest.raises(RuntimeError):
+        FanOut(1, 2, ("tcp", "not-an-address", 1), lib=lib)

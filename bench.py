@@ -146,6 +146,45 @@ def extras(lib):
     return out
 
 
+def fanout_leg(rank, local_rank, world, lib):
+    """BASELINE config 5 (one rank owns inputs and outputs, RCCL send / recv over xGMI): every rank starts ONE child process
+    on its GPU (python -m p264decoder_amd.tools.fan_bench) with a communicator of its own and waits for it with a time
+    limit - whatever happens in there cannot disturb the timed result above.  Rank 0 returns the root child's report."""
+    import torch.distributed as dist
+    from p264decoder_amd import fanout
+    uid = [None]
+    if rank == 0:
+        try:
+            uid[0] = fanout.rccl_unique_id(lib).hex()
+        except Exception as e:
+            uid[0] = "error: %s" % e
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0].startswith("error"):
+        return {"error": uid[0]}
+    cmd = [sys.executable, "-m", "p264decoder_amd.tools.fan_bench", "--rank", str(rank), "--world", str(world), "--transport", "rccl",
+           "--uid", uid[0], "--device", str(local_rank), "--streams", str(world), "--pictures", "6"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    res = {"error": "no report"}
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+        try:
+            out, err = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+            res = {"error": "rank %d: fan-out child timed out" % rank}
+        for line in out.splitlines():
+            if line.startswith("FANOUT "):
+                res = json.loads(line[7:])
+        if "error" in res and p.returncode not in (0, None) and rank == 0:
+            res = {"error": "root child exited with %s: %s" % (p.returncode, err.strip().splitlines()[-1] if err.strip() else "")}
+    except Exception as e:                                    # noqa: BLE001
+        res = {"error": "rank %d: %r" % (rank, e)}
+    return res
+
+
 def cpu_baseline(stream_path, n_pictures):
     """The reference's own CPU path on the host cores of this box, 1 core (it is single-threaded),
     on a bounded sample of the same workload.  kind = "reference" when oracle/_ref (the real
@@ -204,6 +243,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1024, help="independent 1080p streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
+    ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0)")
     args = ap.parse_args()
 
     import torch
@@ -321,9 +361,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: a reported baseline, not part of the scaling runs
             out["cpu_baseline"] = cpu_baseline(paths[0], T)
     hip.close()
+    fan = None
+    if world > 1 and not args.no_fanout and os.environ.get("P264AMD_BENCH_FANOUT", "1") != "0":
+        fan = fanout_leg(rank, local_rank, world, lib)       # after the timed region, in child processes, never `value`
     if rank == 0:
         if not args.no_extras and world == 1:
             out["extras"] = extras(lib)
+        if fan is not None:
+            out.setdefault("extras", {})["fanout_config5"] = fan
         print(json.dumps(out), flush=True)
     shard.barrier()
     if world > 1:

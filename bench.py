@@ -251,8 +251,13 @@ def main():
     rank, local_rank, world = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the reconstruction path")
+    # (rehearsal knobs for a box with fewer GPUs than ranks: P264AMD_BENCH_DEVICE pins every rank to one GPU,
+    # P264AMD_BENCH_BACKEND=gloo replaces RCCL for the barrier and the clock; the driver's runs use neither)
+    if os.environ.get("P264AMD_BENCH_DEVICE"):
+        local_rank = int(os.environ["P264AMD_BENCH_DEVICE"])
+    backend = os.environ.get("P264AMD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    shard.init("nccl", torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm; barrier + clock only
+    shard.init(backend, torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm; barrier + clock only
 
     from p264decoder_amd import HipReconstructor, Parser, _native
     from tests import synth_cases
@@ -299,7 +304,7 @@ def main():
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
     timing = hip.timing_read()
     hip.timing_enable(False)
 

@@ -30,7 +30,10 @@ extern "C" {
 typedef struct p264_t p264_t;
 
 #define P264_CSP_I420   0x0001
-#define P264_LOG_INFO   2
+#define P264_LOG_ERROR   0
+#define P264_LOG_WARNING 1
+#define P264_LOG_INFO    2
+#define P264_LOG_DEBUG   3
 #define P264_CQM_FLAT   0
 
 enum { NAL_UNKNOWN = 0, NAL_SLICE = 1, NAL_SLICE_DPA = 2, NAL_SLICE_DPB = 3, NAL_SLICE_DPC = 4,
@@ -83,6 +86,8 @@ int     p264_nal_decode(p264_nal_t *nal, void *buf, int size);
 p264_t *p264_decoder_open(p264_param_t *param);
 int     p264_decoder_decode(p264_t *h, p264_picture_t **pp_pic, p264_nal_t *nal);
 void    p264_decoder_close(p264_t *h);
+void p264_picture_alloc(p264_picture_t *pic, int i_csp, int i_width, int i_height);     /* p264.h:300, core/core.c:181-259 */
+void p264_picture_clean(p264_picture_t *pic);                                          /* p264.h:305, core/core.c:266-272 */
 int64_t p264_mdate(void);            /* microsecond clock used by the reference CLI (core/mdate.c:40-52) */
 
 /* Extension (not in the reference): environment knobs read by p264_decoder_open -

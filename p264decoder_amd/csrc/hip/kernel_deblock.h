@@ -366,8 +366,11 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             }
             // Everything this wave has issued is complete here (the prefetch was issued before the previous
             // iteration's horizontal pass, its stores before that): macroblocks 0 .. x-2 of this row are in memory.
+            // Publish with RELEASE semantics at workgroup scope: the band below reads these macroblocks' pixels through global
+            // memory on the same CU.  (The explicit wait drains the WHOLE wave's stores - the publisher lane speaks for all
+            // eight octets of its wave, and a release fence only orders the publishing lane's own view.)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (publisher) __hip_atomic_store(my_progress, min(max(x - 1, 0), g.mb_w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (publisher) __hip_atomic_store(my_progress, min(max(x - 1, 0), g.mb_w), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             wave_lds_fence();
             // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
             if (flush && top_exists && !EXPD_NOSTORE) {
@@ -507,7 +510,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             wave_lds_fence();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (publisher) __hip_atomic_store(my_progress, g.mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (publisher) __hip_atomic_store(my_progress, g.mb_w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         wave_lds_fence();
     }
 }

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <stdarg.h>
 #include "p264_dropin.h"
 #include "p264parse.h"
 #include "p264hip.h"
@@ -28,12 +29,23 @@ struct p264_t {
     int          device;
 };
 
-/* core/core.c:41-137.  Only the fields a decoder (or its caller) reads are meaningful; the
- * encoder-only tuning defaults are left zero. */
+/* core/core.c:153-176 */
+static void log_default(void *unused, int i_level, const char *psz_fmt, va_list arg)
+{
+    (void)unused;
+    const char *prefix = i_level == P264_LOG_ERROR ? "error" : i_level == P264_LOG_WARNING ? "warning" : i_level == P264_LOG_INFO ? "info" :
+                         i_level == P264_LOG_DEBUG ? "debug" : "unknown";
+    fprintf(stderr, "p264 [%s]: ", prefix);
+    vfprintf(stderr, psz_fmt, arg);
+}
+
+/* core/core.c:41-137, field for field (tests/test_abi.py compares every value with the reference's own function).  The two
+ * fields that cannot be equal: cpu (p264_cpu_detect() is 0 without the x86 paths) and pf_log (a function of ours with the
+ * reference's behaviour). */
 void p264_param_default(p264_param_t *param)
 {
     memset(param, 0, sizeof *param);
-    param->cpu = 0;                                /* no x86 SIMD here: p264_cpu_detect() -> 0 */
+    param->cpu = 0;
     param->i_threads = 1;
     param->i_csp = P264_CSP_I420;
     param->vui.i_vidformat = 5; param->vui.i_colorprim = 2; param->vui.i_transfer = 2; param->vui.i_colmatrix = 2;
@@ -44,13 +56,74 @@ void p264_param_default(p264_param_t *param)
     param->i_scenecut_threshold = 40; param->b_bframe_adaptive = 1;
     param->b_deblocking_filter = 1;
     param->b_cabac = 1;
+    param->rc.i_bitrate = 1000; param->rc.f_rate_tolerance = 1.0f; param->rc.f_vbv_buffer_init = 0.9f;
     param->rc.i_qp_constant = 26; param->rc.i_qp_min = 10; param->rc.i_qp_max = 51; param->rc.i_qp_step = 4;
+    param->rc.f_ip_factor = 1.4f; param->rc.f_pb_factor = 1.3f;
+    param->rc.psz_stat_out = "p264_2pass.log"; param->rc.psz_stat_in = "p264_2pass.log";
+    param->rc.psz_rc_eq = "blurCplx^(1-qComp)";
+    param->rc.f_qcompress = 0.6f; param->rc.f_qblur = 0.5f; param->rc.f_complexity_blur = 20;
+    param->pf_log = log_default;
     param->i_log_level = P264_LOG_INFO;
+    param->analyse.intra = 0x0001 | 0x0002;                       /* P264_ANALYSE_I4x4 | I8x8 (p264.h:59-60) */
+    param->analyse.inter = 0x0001 | 0x0002 | 0x0010 | 0x0100;     /* | PSUB16x16 | BSUB16x16 */
+    param->analyse.i_direct_mv_pred = 2;                          /* P264_DIRECT_PRED_TEMPORAL */
+    param->analyse.i_me_method = 1;                               /* P264_ME_HEX */
+    param->analyse.i_me_range = 16; param->analyse.i_subpel_refine = 5; param->analyse.b_chroma_me = 1;
+    param->analyse.i_mv_range = -1; param->analyse.b_fast_pskip = 1; param->analyse.b_psnr = 1;
     param->i_cqm_preset = P264_CQM_FLAT;
     memset(param->cqm_4iy, 16, 16); memset(param->cqm_4ic, 16, 16);
     memset(param->cqm_4py, 16, 16); memset(param->cqm_4pc, 16, 16);
     memset(param->cqm_8iy, 16, 64); memset(param->cqm_8py, 16, 64);
     param->b_repeat_headers = 1;
+}
+
+/* core/core.c:181-259 (the packed and 4:2:2 / 4:4:4 layouts included, as the reference allocates them) */
+void p264_picture_alloc(p264_picture_t *pic, int i_csp, int i_width, int i_height)
+{
+    pic->i_type = 0;                                /* P264_TYPE_AUTO */
+    pic->i_qpplus1 = 0;
+    pic->i_width = i_width; pic->i_height = i_height;
+    pic->img.i_csp = i_csp;
+    const size_t wh = (size_t)i_width * i_height;
+    switch (i_csp & 0x00ff) {                       /* P264_CSP_MASK */
+    case 0x0001: case 0x0004:                       /* I420, YV12 */
+        pic->img.i_plane = 3;
+        pic->img.plane[0] = (uint8_t *)malloc(3 * wh / 2);
+        pic->img.plane[1] = pic->img.plane[0] + wh; pic->img.plane[2] = pic->img.plane[1] + wh / 4;
+        pic->img.i_stride[0] = i_width; pic->img.i_stride[1] = i_width / 2; pic->img.i_stride[2] = i_width / 2;
+        break;
+    case 0x0002:                                    /* I422 */
+        pic->img.i_plane = 3;
+        pic->img.plane[0] = (uint8_t *)malloc(2 * wh);
+        pic->img.plane[1] = pic->img.plane[0] + wh; pic->img.plane[2] = pic->img.plane[1] + wh / 2;
+        pic->img.i_stride[0] = i_width; pic->img.i_stride[1] = i_width / 2; pic->img.i_stride[2] = i_width / 2;
+        break;
+    case 0x0003:                                    /* I444 */
+        pic->img.i_plane = 3;
+        pic->img.plane[0] = (uint8_t *)malloc(3 * wh);
+        pic->img.plane[1] = pic->img.plane[0] + wh; pic->img.plane[2] = pic->img.plane[1] + wh;
+        pic->img.i_stride[0] = i_width; pic->img.i_stride[1] = i_width; pic->img.i_stride[2] = i_width;
+        break;
+    case 0x0005:                                    /* YUYV */
+        pic->img.i_plane = 1; pic->img.plane[0] = (uint8_t *)malloc(2 * wh); pic->img.i_stride[0] = 2 * i_width;
+        break;
+    case 0x0006: case 0x0007:                       /* RGB, BGR */
+        pic->img.i_plane = 1; pic->img.plane[0] = (uint8_t *)malloc(3 * wh); pic->img.i_stride[0] = 3 * i_width;
+        break;
+    case 0x0008:                                    /* BGRA */
+        pic->img.i_plane = 1; pic->img.plane[0] = (uint8_t *)malloc(4 * wh); pic->img.i_stride[0] = 4 * i_width;
+        break;
+    default:
+        fprintf(stderr, "invalid CSP\n");
+        pic->img.i_plane = 0;
+        break;
+    }
+}
+
+void p264_picture_clean(p264_picture_t *pic)
+{
+    free(pic->img.plane[0]);
+    memset(pic, 0, sizeof *pic);                    /* just to be safe (core/core.c:266-272) */
 }
 
 /* core/core.c:310-336, including its loop bound: a 00 00 03 whose 03 lies within the last three

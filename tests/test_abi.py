@@ -109,3 +109,59 @@ def test_cli_builds_and_prints_usage():
     assert os.path.exists(cli)
     r = subprocess.run([cli], stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "-d <test.264> [recon.yuv] [origin.yuv]" in r.stderr
+
+
+def _param_values(p):
+    """Every field of a p264_param_t as comparable Python values (strings by content; `cpu` and `pf_log` left out: the
+    reference detects x86 features and installs its own logger function)."""
+    out = {}
+
+    def walk(prefix, obj):
+        for name, typ in obj._fields_:
+            v = getattr(obj, name)
+            key = prefix + name
+            if key in ("cpu", "pf_log"):
+                continue
+            if hasattr(v, "_fields_"):
+                walk(key + ".", v)
+            elif isinstance(v, C.Array):
+                out[key] = list(v)
+            elif typ is C.c_char_p:
+                out[key] = v
+            elif typ is C.c_void_p or (isinstance(typ, type) and issubclass(typ, C._Pointer)):
+                out[key] = bool(v)
+            else:
+                out[key] = v
+    walk("", p)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libp264ref_kat.so")), reason="oracle/_ref not built")
+def test_param_default_values_match_the_reference(lib):
+    """p264_param_default fills every field with the reference's value (core/core.c:41-137): compared against the REAL
+    function, linked into oracle/_ref/libp264ref_kat.so from the reference's own objects."""
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libp264ref_kat.so"))
+    a, b = D.Param(), D.Param()
+    C.memset(C.byref(a), 0xAA, C.sizeof(a)); C.memset(C.byref(b), 0x55, C.sizeof(b))
+    D._bind(lib)
+    lib.p264_param_default(C.byref(a))
+    ref.p264_param_default(C.byref(b))
+    va, vb = _param_values(a), _param_values(b)
+    assert va.keys() == vb.keys() and len(va) > 60
+    diff = {k: (va[k], vb[k]) for k in va if va[k] != vb[k]}
+    assert not diff, diff
+    assert bool(a.pf_log) and a.cpu == 0
+
+
+def test_picture_alloc_and_clean(lib):
+    """p264_picture_alloc / p264_picture_clean (p264.h:300-305, core/core.c:181-272): plane pointers and strides."""
+    D._bind(lib)
+    pic = D.PictureOut()
+    lib.p264_picture_alloc.argtypes = [C.POINTER(D.PictureOut), C.c_int, C.c_int, C.c_int]
+    lib.p264_picture_clean.argtypes = [C.POINTER(D.PictureOut)]
+    lib.p264_picture_alloc(C.byref(pic), 0x0001, 64, 32)
+    assert pic.i_width == 64 and pic.i_height == 32 and pic.img.i_plane == 3 and list(pic.img.i_stride)[:3] == [64, 32, 32]
+    base = C.cast(pic.img.plane[0], C.c_void_p).value
+    assert C.cast(pic.img.plane[1], C.c_void_p).value == base + 64 * 32 and C.cast(pic.img.plane[2], C.c_void_p).value == base + 64 * 32 * 5 // 4
+    lib.p264_picture_clean(C.byref(pic))
+    assert pic.img.i_plane == 0 and not pic.img.plane[0]

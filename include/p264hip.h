@@ -147,6 +147,12 @@ int  p264hip_read_frame(p264hip_ctx *ctx, int stream, int slot,
                         uint8_t *y, int y_stride, uint8_t *u, uint8_t *v, int c_stride);
 int  p264hip_write_frame(p264hip_ctx *ctx, int stream, int slot,
                          const uint8_t *y, int y_stride, const uint8_t *u, const uint8_t *v, int c_stride);
+/* The asynchronous pair for callers that keep their buffers pinned (p264hip_host_alloc): nothing waits until
+ * p264hip_sync / a marker.  submit_async = upload_async + reconstruct; read_frame_async enqueues the layout conversion and
+ * the three plane copies behind whatever was submitted before.  (The drop-in path uses them: one wait per picture.) */
+int  p264hip_submit_async(p264hip_ctx *ctx, int stream, const p264hip_picture_t *pic);
+int  p264hip_read_frame_async(p264hip_ctx *ctx, int stream, int slot,
+                              uint8_t *y, int y_stride, uint8_t *u, uint8_t *v, int c_stride);
 
 /* Timing hooks used by bench.py: HIP events on the context's own stream.
  * kernel index: 0 inter (MC + residual), 1 intra, 2 deblock, 3 whole reconstruct call. */

@@ -443,6 +443,15 @@ extern "C" int p264hip_submit(p264hip_ctx *c, int stream, const p264hip_picture_
     return p264hip_reconstruct(c, &stream, &stream, 1);
 }
 
+extern "C" int p264hip_submit_async(p264hip_ctx *c, int stream, const p264hip_picture_t *pic)
+{
+    if (!c || !pic || stream < 0 || stream >= c->n_streams || stream >= c->max_pictures)
+        return fail(P264HIP_EINVAL, "p264hip_submit_async: bad argument (stream %d)", stream);
+    int rc = p264hip_upload_async(c, stream, pic);
+    if (rc) return rc;
+    return p264hip_reconstruct(c, &stream, &stream, 1);
+}
+
 static int drain_stamps(p264hip_ctx *c)
 {
     for (auto &s : c->stamps) {
@@ -495,6 +504,24 @@ static int frame_io(p264hip_ctx *c, int stream, int slot, uint8_t *y, int ys, ui
         hipLaunchKernelGGL(k_tile_convert, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, f, s, g, 0);
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    HIPCHK(hipGetLastError());
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_read_frame_async(p264hip_ctx *c, int stream, int slot, uint8_t *y, int ys, uint8_t *u, uint8_t *v, int cs)
+{
+    if (!c || stream < 0 || stream >= c->n_streams || slot < 0 || slot >= c->slots || !y || !u || !v || ys < c->g.w || cs < c->g.cw)
+        return fail(P264HIP_EINVAL, "frame access: bad argument (stream %d slot %d strides %d/%d)", stream, slot, ys, cs);
+    HIPCHK(hipSetDevice(c->device));
+    const Geom &g = c->g;
+    const size_t ysz = (size_t)g.w * g.h, csz = (size_t)g.cw * g.ch;
+    if (!c->d_planar) HIPCHK(hipMalloc((void **)&c->d_planar, ysz + 2 * csz));
+    uint8_t *s = c->d_planar;
+    const int n_dw = g.n_mb * 96;
+    hipLaunchKernelGGL(k_tile_convert, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, frame_ptr(c, stream, slot), s, g, 1);
+    HIPCHK(hipMemcpy2DAsync(y, (size_t)ys, s, (size_t)g.w, (size_t)g.w, (size_t)g.h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpy2DAsync(u, (size_t)cs, s + ysz, (size_t)g.cw, (size_t)g.cw, (size_t)g.ch, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpy2DAsync(v, (size_t)cs, s + ysz + csz, (size_t)g.cw, (size_t)g.cw, (size_t)g.ch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipGetLastError());
     return P264HIP_OK;
 }

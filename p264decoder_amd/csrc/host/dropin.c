@@ -169,13 +169,14 @@ p264_t *p264_decoder_open(p264_param_t *param)
     h->device = d ? atoi(d) : 0;
     h->parser = p264parse_open((q && atoi(q)) ? P264PARSE_OPT_QUIET : 0);
     if (!h->parser) { free(h); return NULL; }
+    { const char *pp = getenv("P264AMD_PINNED_PARSE"); if (!pp || atoi(pp)) p264parse_set_allocator(h->parser, p264hip_host_alloc, p264hip_host_free); }      /* picture arrays in pinned memory */
     return h;
 }
 
 static void drop_device(p264_t *h)
 {
     if (h->hip) { p264hip_destroy(h->hip); h->hip = NULL; }
-    for (int i = 0; i < OUT_BUFS; i++) { free(h->out_mem[i]); h->out_mem[i] = NULL; }
+    for (int i = 0; i < OUT_BUFS; i++) { p264hip_host_free(h->out_mem[i]); h->out_mem[i] = NULL; }
 }
 
 /* decoder/decoder.c:304-343: new geometry -> new frame store (device) and output planes (host) */
@@ -194,8 +195,9 @@ static int ensure_device(p264_t *h)
     int w = h->mb_w * 16, hh = h->mb_h * 16, ys = w + 64, cs = ys / 2;
     size_t ysz = (size_t)ys * (hh + 64), csz = (size_t)cs * (hh / 2 + 32);
     for (int i = 0; i < OUT_BUFS; i++) {
-        h->out_mem[i] = (uint8_t *)calloc(1, ysz + 2 * csz);
+        h->out_mem[i] = (uint8_t *)p264hip_host_alloc(ysz + 2 * csz);      /* pinned: the plane copies are real DMA */
         if (!h->out_mem[i]) return -1;
+        memset(h->out_mem[i], 0, ysz + 2 * csz);
     }
     h->generation = gen;
     h->param.i_width = w; h->param.i_height = hh;
@@ -210,13 +212,16 @@ int p264_decoder_decode(p264_t *h, p264_picture_t **pp_pic, p264_nal_t *nal)
     if (rc < 0) { fprintf(stderr, "p264amd: nal type %d decode failed\n", nal->i_type); return -1; }
     if (rc == 0) return 0;
     if (ensure_device(h) < 0) return -1;
-    if (p264hip_submit(h->hip, 0, pic) != P264HIP_OK) { fprintf(stderr, "p264amd: %s\n", p264hip_last_error()); return -1; }
+    /* one wait per picture: the parser's arrays and the output planes are pinned, so upload, reconstruction, layout
+     * conversion and the plane copies are enqueued back to back and p264hip_sync waits for all of them (the API hands the
+     * planes of THIS picture back from THIS call, decoder/decoder.c:652-657: nothing can be deferred past the return) */
+    if (p264hip_submit_async(h->hip, 0, pic) != P264HIP_OK) { fprintf(stderr, "p264amd: %s\n", p264hip_last_error()); return -1; }
     int w = h->mb_w * 16, hh = h->mb_h * 16, ys = w + 64, cs = ys / 2;
     size_t ysz = (size_t)ys * (hh + 64), csz = (size_t)cs * (hh / 2 + 32);
     uint8_t *base = h->out_mem[h->out_next];
     h->out_next = (h->out_next + 1) % OUT_BUFS;
     uint8_t *y = base + (size_t)ys * 32 + 32, *u = base + ysz + (size_t)cs * 16 + 16, *v = base + ysz + csz + (size_t)cs * 16 + 16;
-    if (p264hip_read_frame(h->hip, 0, pic->dst_slot, y, ys, u, v, cs) != P264HIP_OK) {
+    if (p264hip_read_frame_async(h->hip, 0, pic->dst_slot, y, ys, u, v, cs) != P264HIP_OK || p264hip_sync(h->hip) != P264HIP_OK) {
         fprintf(stderr, "p264amd: %s\n", p264hip_last_error());
         return -1;
     }

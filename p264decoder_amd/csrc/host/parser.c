@@ -45,9 +45,10 @@ typedef struct {
     int num_ref_idx, qp, disable_deblock, alpha_off, beta_off;
     int n_reorder; struct { int idc, arg; } reorder[34];
     int no_output_of_prior, long_term_flag, adaptive_marking;
+    int n_mmco; struct { int op, a, b; } mmco[34];   /* memory_management_control_operation 1..6 and its operands */
 } slice_t;
 
-typedef struct { int used, frame_num, pic_num; } dpb_frame_t;
+typedef struct { int used, frame_num, pic_num, is_long, long_idx; } dpb_frame_t;   /* long_idx = LongTermFrameIdx (= LongTermPicNum for frames) */
 
 typedef struct {
     p264hip_mb_t *mb; int16_t *mv; int8_t *ref; uint8_t *i4; int16_t *coef;
@@ -280,7 +281,23 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
     }
     if (nal_ref_idc != 0) {
         if (nal_type == NAL_SLICE_IDR) { sh->no_output_of_prior = (int)br_u1(b); sh->long_term_flag = (int)br_u1(b); }
-        else if (br_u1(b)) { sh->adaptive_marking = 1; ERR(p, "adaptive ref pic marking unsupported (decoder/lists.c:183-187)"); return -1; }
+        else if (br_u1(b)) {
+            /* dec_ref_pic_marking with adaptive_ref_pic_marking_mode_flag (H.264 7.3.3.3; the reference parses the
+             * commands and then ignores them, decoder/decoder.c:264-297, decoder/lists.c:183-187) */
+            sh->adaptive_marking = 1;
+            for (;;) {
+                const unsigned op = br_ue(b);
+                if (op == 0) break;
+                if (op > 6 || sh->n_mmco >= 33 || br_overrun(b)) { ERR(p, "bad memory_management_control_operation %u", op); return -1; }
+                int a = 0, c = 0;
+                if (op == 1 || op == 3) a = (int)br_ue(b);          /* difference_of_pic_nums_minus1 */
+                if (op == 2) a = (int)br_ue(b);                     /* long_term_pic_num */
+                if (op == 3 || op == 6) c = (int)br_ue(b);          /* long_term_frame_idx */
+                if (op == 4) a = (int)br_ue(b);                     /* max_long_term_frame_idx_plus1 */
+                sh->mmco[sh->n_mmco].op = (int)op; sh->mmco[sh->n_mmco].a = a; sh->mmco[sh->n_mmco].b = c;
+                sh->n_mmco++;
+            }
+        }
     }
     sh->qp = pps->pic_init_qp + br_se(b);
     if (pps->deblock_ctrl) {
@@ -292,19 +309,26 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
 }
 
 /* ---------------------------------------------------------------- frame store ----------- */
-/* List 0 of a P picture: short-term pictures by descending PicNum (decoder/lists.c:72-143),
- * then the slice's reordering commands (H.264 8.2.4.3.1; the reference ignores them,
- * decoder/lists.c:146-149). */
+/* List 0 of a P picture (H.264 8.2.4.2.1, 8.2.4.3): short-term pictures by descending PicNum (decoder/lists.c:72-143),
+ * then long-term pictures by ascending LongTermPicNum, then the slice's reordering commands (short-term: idc 0 / 1,
+ * long-term: idc 2; the reference ignores them, decoder/lists.c:146-149). */
 static int build_list0(p264parse *p, const slice_t *sh)
 {
     const sps_t *sps = &p->sps[p->active_sps];
     int max_fn = 1 << sps->log2_max_frame_num;
-    int idx[P264HIP_MAX_REFS + 1], n = 0;
+    int idx[P264HIP_MAX_REFS + 1], n = 0, n_short;
     for (int i = 0; i < p->slots; i++) {
-        if (!p->dpb[i].used || i == p->cur_slot) continue;
+        if (!p->dpb[i].used || p->dpb[i].is_long || i == p->cur_slot) continue;
         p->dpb[i].pic_num = p->dpb[i].frame_num > sh->frame_num ? p->dpb[i].frame_num - max_fn : p->dpb[i].frame_num;
         int j = n++;
         while (j > 0 && p->dpb[idx[j-1]].pic_num < p->dpb[i].pic_num) { idx[j] = idx[j-1]; j--; }
+        idx[j] = i;
+    }
+    n_short = n;
+    for (int i = 0; i < p->slots; i++) {
+        if (!p->dpb[i].used || !p->dpb[i].is_long || i == p->cur_slot) continue;
+        int j = n++;
+        while (j > n_short && p->dpb[idx[j-1]].long_idx > p->dpb[i].long_idx) { idx[j] = idx[j-1]; j--; }
         idx[j] = i;
     }
     if (n == 0) { ERR(p, "P slice without a reference picture"); return -1; }
@@ -313,13 +337,17 @@ static int build_list0(p264parse *p, const slice_t *sh)
     for (int i = 0; i < len; i++) list[i] = idx[i < n ? i : n - 1];
     int pred = sh->frame_num, at = 0;
     for (int k = 0; k < sh->n_reorder && at < len; k++) {
-        int idc = sh->reorder[k].idc, d = sh->reorder[k].arg + 1;
-        if (idc == 2) { ERR(p, "long-term reference reordering unsupported"); return -1; }
-        pred = idc == 0 ? pred - d : pred + d;
-        if (pred < 0) pred += max_fn;
-        if (pred >= max_fn) pred -= max_fn;
-        int want = pred > sh->frame_num ? pred - max_fn : pred, slot = -1;
-        for (int i = 0; i < n; i++) if (p->dpb[idx[i]].pic_num == want) slot = idx[i];
+        int idc = sh->reorder[k].idc, slot = -1;
+        if (idc == 2) {                                   /* long_term_pic_num */
+            for (int i = n_short; i < n; i++) if (p->dpb[idx[i]].long_idx == sh->reorder[k].arg) slot = idx[i];
+        } else {
+            int d = sh->reorder[k].arg + 1;
+            pred = idc == 0 ? pred - d : pred + d;
+            if (pred < 0) pred += max_fn;
+            if (pred >= max_fn) pred -= max_fn;
+            int want = pred > sh->frame_num ? pred - max_fn : pred;
+            for (int i = 0; i < n_short; i++) if (p->dpb[idx[i]].pic_num == want) slot = idx[i];
+        }
         if (slot < 0) { ERR(p, "reordering names a picture that is not in the frame store"); return -1; }
         for (int i = len; i > at; i--) list[i] = list[i-1];
         list[at++] = slot;
@@ -331,29 +359,72 @@ static int build_list0(p264parse *p, const slice_t *sh)
     return 0;
 }
 
-/* Sliding-window marking and choice of the next slot (decoder/lists.c:152-228). */
+/* Reference picture marking (H.264 8.2.5; the reference implements the sliding window only, decoder/lists.c:152-228) and
+ * the choice of the next slot. */
 static void finish_picture_marking(p264parse *p)
 {
     const sps_t *sps = &p->sps[p->active_sps];
     int max_fn = 1 << sps->log2_max_frame_num;
+    dpb_frame_t *cur = &p->dpb[p->cur_slot];
+    int cur_long = 0, cur_long_idx = 0;
     if (p->pic_is_idr) {
         for (int i = 0; i < p->slots; i++) if (i != p->cur_slot) p->dpb[i].used = 0;
+        if (p->sh0.long_term_flag) { cur_long = 1; cur_long_idx = 0; }
+    } else if (p->pic_ref_idc && p->sh0.adaptive_marking) {
+        /* 8.2.5.4: the commands in order; PicNum relative to the current picture's frame_num */
+        for (int k = 0; k < p->sh0.n_mmco; k++) {
+            const int op = p->sh0.mmco[k].op, a = p->sh0.mmco[k].a, b = p->sh0.mmco[k].b;
+            if (op == 1 || op == 3) {
+                const int want = p->sh0.frame_num - (a + 1);
+                for (int i = 0; i < p->slots; i++) {
+                    dpb_frame_t *f = &p->dpb[i];
+                    if (!f->used || f->is_long || i == p->cur_slot) continue;
+                    const int num = f->frame_num > p->sh0.frame_num ? f->frame_num - max_fn : f->frame_num;
+                    if (num != want) continue;
+                    if (op == 1) f->used = 0;
+                    else {                                  /* 3: the index is taken away from whoever holds it, then assigned */
+                        for (int j = 0; j < p->slots; j++) if (j != i && p->dpb[j].used && p->dpb[j].is_long && p->dpb[j].long_idx == b) p->dpb[j].used = 0;
+                        f->is_long = 1; f->long_idx = b;
+                    }
+                }
+            } else if (op == 2) {
+                for (int i = 0; i < p->slots; i++) if (p->dpb[i].used && p->dpb[i].is_long && p->dpb[i].long_idx == a && i != p->cur_slot) p->dpb[i].used = 0;
+            } else if (op == 4) {
+                for (int i = 0; i < p->slots; i++) if (p->dpb[i].used && p->dpb[i].is_long && p->dpb[i].long_idx >= a && i != p->cur_slot) p->dpb[i].used = 0;
+            } else if (op == 5) {
+                for (int i = 0; i < p->slots; i++) if (i != p->cur_slot) p->dpb[i].used = 0;
+            } else if (op == 6) {
+                for (int j = 0; j < p->slots; j++) if (j != p->cur_slot && p->dpb[j].used && p->dpb[j].is_long && p->dpb[j].long_idx == b) p->dpb[j].used = 0;
+                cur_long = 1; cur_long_idx = b;
+            }
+        }
     } else if (p->pic_ref_idc) {
+        /* 8.2.5.3 sliding window: when short-term + long-term pictures fill num_ref_frames, the oldest short-term one goes */
         int cnt = 0, oldest = -1, oldest_num = 0;
         for (int i = 0; i < p->slots; i++) {
             if (!p->dpb[i].used || i == p->cur_slot) continue;
+            cnt++;
+            if (p->dpb[i].is_long) continue;
             int num = p->dpb[i].frame_num > p->sh0.frame_num ? p->dpb[i].frame_num - max_fn : p->dpb[i].frame_num;
             if (oldest < 0 || num < oldest_num) { oldest = i; oldest_num = num; }
-            cnt++;
         }
         int cap = sps->num_ref_frames > 0 ? sps->num_ref_frames : 1;
         if (cnt >= cap && oldest >= 0) p->dpb[oldest].used = 0;
     }
-    if (p->pic_ref_idc) { p->dpb[p->cur_slot].used = 1; p->dpb[p->cur_slot].frame_num = p->sh0.frame_num; }
+    if (p->pic_ref_idc) { cur->used = 1; cur->frame_num = p->sh0.frame_num; cur->is_long = cur_long; cur->long_idx = cur_long_idx; }
     /* next picture goes into a slot that holds no reference */
     int next = -1;
     for (int i = 0; i < p->slots; i++) if (!p->dpb[i].used) { next = i; break; }
-    if (next < 0) next = p->cur_slot;             /* cannot happen with slots = num_ref_frames + 1 */
+    if (next < 0) {                               /* a stream that keeps more pictures than num_ref_frames: drop the oldest short-term one */
+        int oldest = -1, oldest_num = 0;
+        for (int i = 0; i < p->slots; i++) {
+            if (p->dpb[i].is_long) continue;
+            int num = p->dpb[i].frame_num > p->sh0.frame_num ? p->dpb[i].frame_num - max_fn : p->dpb[i].frame_num;
+            if (oldest < 0 || num < oldest_num) { oldest = i; oldest_num = num; }
+        }
+        next = oldest >= 0 ? oldest : p->cur_slot;
+        p->dpb[next].used = 0;
+    }
     p->cur_slot = next;
 }
 

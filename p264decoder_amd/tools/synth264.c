@@ -24,6 +24,10 @@
  *            [--reorder]     with --refs 2: some P slices swap the two entries of list 0 (ref_pic_list_reordering; ignored by
  *                            the reference, decoder/lists.c:146-149)
  *            [--dump-mv f]   additionally records, per picture, one byte: 1 when list 0 was reordered
+ *            [--mmco]        with --refs 2..4: adaptive reference picture marking (memory_management_control_operation 1, 2, 3, 6:
+ *                            short-term pictures dropped early, turned into long-term ones, long-term ones dropped, the current
+ *                            picture stored as long-term) and long-term IDR pictures; --dump-mv then also records list 0 of every
+ *                            picture as the writer means it: one byte n, then n 16-bit picture numbers (decode order)
  *            [--pps-alt]     two identical PPS (ids 0 and 1), pictures alternate between them: every picture re-activates a
  *                            parameter set (context re-initialisation in the decoder, decoder/decoder.c:304-343)
  */
@@ -97,6 +101,11 @@ static int8_t  *i4m;                        /* [mb][16], 2 for non-I4x4 */
 static int cur;                             /* current MB index */
 
 static int opt_pps_alt = 0, cur_pps = 0;
+static int opt_mmco = 0;
+/* the writer's own model of the decoded picture buffer (H.264 8.2.4, 8.2.5) */
+typedef struct { int used, pic, frame_num, is_long, long_idx; } wdpb_t;
+static wdpb_t wdpb[8];
+static int wlist[8], wlist_n;                /* list 0 of the current picture: picture numbers in decode order */
 static int opt_qpdelta = 0, opt_alpha = 0, opt_beta = 0, opt_sub8x8 = 0, opt_reorder = 0, slice_reordered;
 static int opt_idc = 0;                     /* --deblock-idc 2: no filtering across slice boundaries */
 static int opt_slices = 1, slice_first;     /* --slices: equal runs of macroblocks; slice_first = first MB of the current slice */
@@ -368,6 +377,8 @@ static void put_intra(bw_t *b, int mbx, int mby, int type_offset)
     else memset(nnz + (size_t)cur * 24, 0, 24);
 }
 
+/* te(v): one inverted bit when the range is 0..1, ue(v) beyond */
+static void put_te(bw_t *b, int max, int v) { if (max == 1) bw_put(b, 1, (uint32_t)!v); else if (max > 1) bw_ue(b, (uint32_t)v); }
 /* try to write a non-skipped inter MB; returns 0 if no legal vectors were found */
 static void put_inter(bw_t *b, int mbx, int mby)
 {
@@ -381,7 +392,7 @@ static void put_inter(bw_t *b, int mbx, int mby)
     int pref[4] = { 0, 0, 0, 0 };
     if (t < 3) {
         int np = t == 0 ? 1 : 2;
-        for (int k = 0; k < np; k++) if (n_active > 1) { pref[k] = pct(35); bw_put(b, 1, !pref[k]); }
+        for (int k = 0; k < np; k++) if (n_active > 1) { pref[k] = pct(55) ? 0 : rnd(n_active); put_te(b, n_active - 1, pref[k]); }
         for (int k = 0; k < np; k++) {
             int mx, my, px, py, dir = t == 0 ? 0 : t == 1 ? 1 + k : 3 + k;
             predict_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], dir, pref[k], &px, &py);
@@ -393,7 +404,7 @@ static void put_inter(bw_t *b, int mbx, int mby)
     } else {
         int sub[4];
         for (int k = 0; k < 4; k++) { sub[k] = opt_sub8x8 ? rnd(4) : 0; bw_ue(b, (uint32_t)sub[k]); }   /* sub_mb_type: 8x8 only inside the reference's safe subset (A-Q4) */
-        for (int k = 0; k < 4; k++) if (n_active > 1) { pref[k] = pct(35); bw_put(b, 1, !pref[k]); }
+        for (int k = 0; k < 4; k++) if (n_active > 1) { pref[k] = pct(55) ? 0 : rnd(n_active); put_te(b, n_active - 1, pref[k]); }
         for (int k = 0; k < 4; k++) {
             int ox = (k & 1) * 2, oy = (k >> 1) * 2;
             int sw = (sub[k] == 0 || sub[k] == 1) ? 2 : 1, sh = (sub[k] == 0 || sub[k] == 2) ? 2 : 1;   /* 8x8, 8x4, 4x8, 4x4 */
@@ -432,10 +443,82 @@ static int try_skip(int mbx, int mby)
 }
 
 /* ---------------------------------------------------------------- pictures -------------- */
-static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn, int refs_available)
+/* list 0 of the picture about to be written, from the writer's frame-store model: short-term pictures by descending PicNum,
+ * then long-term ones by ascending index (8.2.4.2.1) */
+static int model_list0(int frame_num, int max_fn, int *list)
 {
-    n_active = is_p && opt_refs > 1 && refs_available > 1 ? 2 : 1;
+    int n = 0, n_short;
+    int key[8];
+    for (int i = 0; i < 8; i++) {                       /* short-term, PicNum descending */
+        if (!wdpb[i].used || wdpb[i].is_long) continue;
+        const int k = wdpb[i].frame_num > frame_num ? wdpb[i].frame_num - max_fn : wdpb[i].frame_num;
+        int j = n++;
+        while (j > 0 && key[j-1] < k) { key[j] = key[j-1]; list[j] = list[j-1]; j--; }
+        key[j] = k; list[j] = wdpb[i].pic;
+    }
+    n_short = n;
+    for (int i = 0; i < 8; i++) {                       /* long-term, index ascending */
+        if (!wdpb[i].used || !wdpb[i].is_long) continue;
+        int j = n++;
+        while (j > n_short && key[j-1] > wdpb[i].long_idx) { key[j] = key[j-1]; list[j] = list[j-1]; j--; }
+        key[j] = wdpb[i].long_idx; list[j] = wdpb[i].pic;
+    }
+    return n;
+}
+
+static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn, int refs_available, int pic_no)
+{
+    const int max_fn = 1 << log2_fn;
+    int full[8], n_full = 0;
+    if (opt_mmco) { n_full = is_p ? model_list0(frame_num, max_fn, full) : 0; refs_available = n_full; }
+    n_active = is_p && opt_refs > 1 && refs_available > 1 ? (refs_available < opt_refs ? refs_available : opt_refs) : 1;
+    if (!opt_mmco && n_active > 2) n_active = 2;
     slice_reordered = opt_reorder && n_active > 1 && pct(50);
+    wlist_n = 0;
+    if (opt_mmco && is_p) { wlist_n = n_active; for (int i = 0; i < n_active; i++) wlist[i] = full[i < n_full ? i : n_full - 1]; }
+    /* ---- reference picture marking of this picture (decided once, written into every slice header) ---- */
+    int n_cmd = 0, cmd[8][3], idr_long = 0, cur_long = 0, cur_long_idx = 0;
+    if (opt_mmco) {
+        if (idr) { idr_long = pct(30); for (int i = 0; i < 8; i++) wdpb[i].used = 0; cur_long = idr_long; cur_long_idx = 0; }
+        else {
+            int n_short = 0, n_long = 0, cnt = 0;
+            for (int i = 0; i < 8; i++) if (wdpb[i].used) { cnt++; if (wdpb[i].is_long) n_long++; else n_short++; }
+            const int want = pct(60) ? 1 + rnd(4) : 0;        /* 1: drop a short-term, 2: short -> long, 3: drop a long-term, 4: current -> long */
+            int pick = -1;
+            if (want == 1 || want == 2) { int k = n_short ? rnd(n_short) : -1; for (int i = 0; i < 8 && k >= 0; i++) if (wdpb[i].used && !wdpb[i].is_long && k-- == 0) pick = i; }
+            if (want == 3) { int k = n_long ? rnd(n_long) : -1; for (int i = 0; i < 8 && k >= 0; i++) if (wdpb[i].used && wdpb[i].is_long && k-- == 0) pick = i; }
+            if (want == 1 && pick >= 0 && cnt > 1) {
+                const int num = wdpb[pick].frame_num > frame_num ? wdpb[pick].frame_num - max_fn : wdpb[pick].frame_num;
+                cmd[n_cmd][0] = 1; cmd[n_cmd][1] = frame_num - num - 1; n_cmd++; wdpb[pick].used = 0;
+            } else if (want == 2 && pick >= 0) {
+                const int num = wdpb[pick].frame_num > frame_num ? wdpb[pick].frame_num - max_fn : wdpb[pick].frame_num, li = rnd(2);
+                cmd[n_cmd][0] = 3; cmd[n_cmd][1] = frame_num - num - 1; cmd[n_cmd][2] = li; n_cmd++;
+                for (int i = 0; i < 8; i++) if (i != pick && wdpb[i].used && wdpb[i].is_long && wdpb[i].long_idx == li) wdpb[i].used = 0;
+                wdpb[pick].is_long = 1; wdpb[pick].long_idx = li;
+            } else if (want == 3 && pick >= 0 && cnt > 1) {
+                cmd[n_cmd][0] = 2; cmd[n_cmd][1] = wdpb[pick].long_idx; n_cmd++; wdpb[pick].used = 0;
+            } else if (want == 4) {
+                const int li = rnd(2);
+                cmd[n_cmd][0] = 6; cmd[n_cmd][2] = li; n_cmd++;
+                for (int i = 0; i < 8; i++) if (wdpb[i].used && wdpb[i].is_long && wdpb[i].long_idx == li) wdpb[i].used = 0;
+                cur_long = 1; cur_long_idx = li;
+            }
+            /* no sliding window under adaptive marking: make room for this picture ourselves */
+            cnt = 0; for (int i = 0; i < 8; i++) cnt += wdpb[i].used;
+            if (n_cmd && cnt >= opt_refs) {
+                int old = -1, old_num = 0;
+                for (int i = 0; i < 8; i++) if (wdpb[i].used && !wdpb[i].is_long) { const int num = wdpb[i].frame_num > frame_num ? wdpb[i].frame_num - max_fn : wdpb[i].frame_num; if (old < 0 || num < old_num) { old = i; old_num = num; } }
+                if (old >= 0) { cmd[n_cmd][0] = 1; cmd[n_cmd][1] = frame_num - old_num - 1; n_cmd++; wdpb[old].used = 0; }
+                else { for (int i = 0; i < 8; i++) if (wdpb[i].used) { cmd[n_cmd][0] = 2; cmd[n_cmd][1] = wdpb[i].long_idx; n_cmd++; wdpb[i].used = 0; break; } }
+            }
+            if (!n_cmd) {                                       /* sliding window (8.2.5.3) */
+                int old = -1, old_num = 0;
+                for (int i = 0; i < 8; i++) if (wdpb[i].used && !wdpb[i].is_long) { const int num = wdpb[i].frame_num > frame_num ? wdpb[i].frame_num - max_fn : wdpb[i].frame_num; if (old < 0 || num < old_num) { old = i; old_num = num; } }
+                if (cnt >= opt_refs && old >= 0) wdpb[old].used = 0;
+            }
+        }
+        for (int i = 0; i < 8; i++) if (!wdpb[i].used) { wdpb[i].used = 1; wdpb[i].pic = pic_no; wdpb[i].frame_num = frame_num; wdpb[i].is_long = cur_long; wdpb[i].long_idx = cur_long_idx; break; }
+    }
     for (int sl = 0; sl < opt_slices; sl++) {
         const int first = (int)((long)NMB * sl / opt_slices), end = (int)((long)NMB * (sl + 1) / opt_slices);
         if (first == end) continue;
@@ -454,8 +537,16 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
                 bw_put(&b, 1, 1); bw_ue(&b, 0); bw_ue(&b, 1); bw_ue(&b, 3);
             } else bw_put(&b, 1, 0);                        /* no reordering */
         }
-        if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); }    /* no_output_of_prior_pics, long_term_reference */
-        else bw_put(&b, 1, 0);                              /* sliding-window marking */
+        if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, (uint32_t)idr_long); }    /* no_output_of_prior_pics, long_term_reference */
+        else if (n_cmd) {
+            bw_put(&b, 1, 1);                               /* adaptive_ref_pic_marking_mode */
+            for (int k = 0; k < n_cmd; k++) {
+                bw_ue(&b, (uint32_t)cmd[k][0]);
+                if (cmd[k][0] == 1 || cmd[k][0] == 3 || cmd[k][0] == 2) bw_ue(&b, (uint32_t)cmd[k][1]);
+                if (cmd[k][0] == 3 || cmd[k][0] == 6) bw_ue(&b, (uint32_t)cmd[k][2]);
+            }
+            bw_ue(&b, 0);
+        } else bw_put(&b, 1, 0);                            /* sliding-window marking */
         bw_se(&b, 0);                               /* slice_qp_delta */
         bw_ue(&b, (uint32_t)(opt_deblock ? opt_idc : 1)); /* disable_deblocking_filter_idc: 0 also across slice boundaries, 2 not */
         if (opt_deblock) { bw_se(&b, opt_alpha); bw_se(&b, opt_beta); }
@@ -478,6 +569,7 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
     if (dump_mv) {
         fwrite(mvs, 2, (size_t)NMB * 32, dump_mv); fwrite(refs, 1, (size_t)NMB * 16, dump_mv);
         if (opt_reorder) fputc(slice_reordered, dump_mv);
+        if (opt_mmco) { fputc(wlist_n, dump_mv); for (int i = 0; i < wlist_n; i++) { fputc(wlist[i] & 255, dump_mv); fputc(wlist[i] >> 8, dump_mv); } }
     }
 }
 
@@ -512,9 +604,10 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--sub8x8")) opt_sub8x8 = 1;
         else if (!strcmp(a, "--reorder")) opt_reorder = 1;
         else if (!strcmp(a, "--pps-alt")) opt_pps_alt = 1;
+        else if (!strcmp(a, "--mmco")) opt_mmco = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
-    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > 2 || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
+    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > (opt_mmco ? 4 : 2) || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
     NMB = W * H;
     g_rng = seed * 0x9e3779b97f4a7c15ull + 264;
     mb_type = calloc((size_t)NMB, 1); mvs = calloc((size_t)NMB * 32, 2); nnz = calloc((size_t)NMB, 24); i4m = calloc((size_t)NMB, 16); refs = calloc((size_t)NMB, 16);
@@ -548,7 +641,7 @@ int main(int argc, char **argv)
         int idr = intra_only || n == 0 || (gop > 0 && n % gop == 0);
         if (idr) { frame_num = 0; since_idr = 0; }
         cur_pps = opt_pps_alt ? (n & 1) : 0;
-        put_slice(f, idr, !idr, frame_num, idr_id, log2_fn, since_idr);   /* since_idr = reference pictures available (sliding window) */
+        put_slice(f, idr, !idr, frame_num, idr_id, log2_fn, since_idr, n);   /* since_idr = reference pictures available (sliding window) */
         since_idr++;
         if (idr) idr_id = (idr_id + 1) & 0xffff;
         frame_num = (frame_num + 1) & ((1 << log2_fn) - 1);

@@ -30,6 +30,11 @@ SUB8X8 = ["--mbw 11 --mbh 9 --frames 8 --gop 4 --seed 46 --sub8x8 --coded 10 --m
 REORDER = "--mbw 10 --mbh 8 --frames 12 --gop 0 --seed 48 --refs 2 --reorder --sub8x8 --coded 10 --maxlevel 6"
 
 
+MMCO = ["--mbw 8 --mbh 6 --frames 40 --gop 14 --seed 71 --refs 3 --mmco --coded 8 --maxlevel 6",
+        "--mbw 7 --mbh 5 --frames 36 --gop 0 --seed 72 --refs 4 --mmco --sub8x8 --coded 8 --maxlevel 6"]
+
+
+
 def make(tmp_path, args=ARGS):
     synth_cases.ensure_tool()
     stream, dump = str(tmp_path / "mr.264"), str(tmp_path / "mr.mv")
@@ -134,7 +139,7 @@ def test_list0_reordering_parser_against_writer(lib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [ARGS] + SLICED + SUB8X8 + [REORDER])
+@pytest.mark.parametrize("args", [ARGS] + SLICED + SUB8X8 + [REORDER] + MMCO)
 def test_two_references_hip_vs_oracle(lib, oracle, tmp_path, args):
     from p264decoder_amd import HipReconstructor
     from tests import oracle_bind
@@ -151,3 +156,36 @@ def test_two_references_hip_vs_oracle(lib, oracle, tmp_path, args):
         for plane, (a, b) in enumerate(zip(got, want)):
             assert np.array_equal(a, b), "picture %d plane %d differs" % (i, plane)
     hip.close()
+
+
+@pytest.mark.parametrize("args", MMCO)
+def test_adaptive_marking_and_long_term_parser_against_writer(lib, tmp_path, args):
+    """memory_management_control_operation 1, 2, 3, 6 and long-term IDR pictures (the reference parses
+    the commands and ignores them, decoder/lists.c:183-187): the writer keeps its own model of the frame store and records
+    list 0 of every picture as picture numbers; the parser's list 0 must name the frame-store slots those pictures were
+    decoded into - and those slots must still hold them."""
+    data, dump = make(tmp_path, args)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(data)
+    n = pics[0].n_mb
+    base = n * 64 + n * 16
+    slot_pic, at, multi, longs = {}, 0, 0, 0
+    assert parser.slots == int(args.split("--refs ")[1].split()[0]) + 1
+    for i, p in enumerate(pics):
+        blob = dump[at:at + base]
+        mv = blob[:n * 64].view(np.int16).reshape(n, 16, 2)
+        rf = blob[n * 64:].view(np.int8).reshape(n, 16)
+        cnt = int(dump[at + base])
+        want = [int(dump[at + base + 1 + 2 * k]) | int(dump[at + base + 2 + 2 * k]) << 8 for k in range(cnt)]
+        at += base + 1 + 2 * cnt
+        inter = p.mb_records()["mb_type"] > N.MB_IPCM
+        assert np.array_equal(p.mv.reshape(n, 16, 2)[inter], mv[inter]), "picture %d: vectors" % i
+        assert np.array_equal(p.ref_idx.reshape(n, 4)[inter], rf[:, [0, 2, 8, 10]][inter]), "picture %d: reference indices" % i
+        assert p.desc.n_ref == cnt, "picture %d: list length" % i
+        got = [slot_pic[p.desc.ref_slot[k]] for k in range(cnt)]
+        assert got == want, "picture %d: list 0 is pictures %s, the writer meant %s" % (i, got, want)
+        assert p.desc.dst_slot not in [p.desc.ref_slot[k] for k in range(cnt)]
+        multi += cnt > 2
+        longs += any(w < i - 4 for w in want)             # an entry older than any sliding window of this size would keep
+        slot_pic[p.desc.dst_slot] = i
+    assert at == len(dump) and multi > 5 and longs > 3

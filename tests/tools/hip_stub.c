@@ -20,3 +20,5 @@ int p264hip_write_frame(p264hip_ctx *c, int s, int sl, const uint8_t *y, int ys,
 int p264hip_timing_enable(p264hip_ctx *c, int on) { (void)c;(void)on; return -1; }
 int p264hip_timing_read(p264hip_ctx *c, double *a, int64_t *b) { (void)c;(void)a;(void)b; return -1; }
 int p264hip_timing_reset(p264hip_ctx *c) { (void)c; return -1; }
+int p264hip_submit_async(p264hip_ctx *c, int s, const p264hip_picture_t *p) { (void)c;(void)s;(void)p; return -1; }
+int p264hip_read_frame_async(p264hip_ctx *c, int s, int sl, uint8_t *y, int ys, uint8_t *u, uint8_t *v, int cs) { (void)c;(void)s;(void)sl;(void)y;(void)ys;(void)u;(void)v;(void)cs; return -1; }

@@ -154,6 +154,12 @@ int  p264hip_submit_async(p264hip_ctx *ctx, int stream, const p264hip_picture_t 
 int  p264hip_read_frame_async(p264hip_ctx *ctx, int stream, int slot,
                               uint8_t *y, int y_stride, uint8_t *u, uint8_t *v, int c_stride);
 
+/* Bi-prediction combine (first piece of the Main-profile path; pf->avg[] / pf->avg_weight[] of the
+ * reference, core/mc.c:76-155): frame dst_slot of the stream becomes the sample-wise combination of itself and frame
+ * src_slot - weighted = 0: (dst + src + 1) >> 1; weighted = 1: clip((dst * weight1 + src * (64 - weight1) + 32) >> 6), the
+ * implicit-weight form (log2 denominator 5, offset 0).  Asynchronous. */
+int  p264hip_bipred_frames(p264hip_ctx *ctx, int stream, int dst_slot, int src_slot, int weighted, int weight1);
+
 /* Timing hooks used by bench.py: HIP events on the context's own stream.
  * kernel index: 0 inter (MC + residual), 1 intra, 2 deblock, 3 whole reconstruct call. */
 #define P264HIP_NKERNELS 4

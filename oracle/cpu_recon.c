@@ -328,6 +328,19 @@ void oracle_mc_chroma(const uint8_t *ref, int w, int h, int x0, int y0, int mvx,
                                                cC*px(&f,ox+x,oy+y+1) + cD*px(&f,ox+x+1,oy+y+1) + 32) >> 6);
 }
 
+/* ---- bi-prediction: pixel_avg_wxh (core/mc.c:76-88), pixel_avg_weight_wxh (core/mc.c:106-132) ------------------------ */
+void oracle_bipred_avg(uint8_t *dst, int ds, const uint8_t *src, int ss, int w, int h)
+{
+    for (int y = 0; y < h; y++, dst += ds, src += ss)
+        for (int x = 0; x < w; x++) dst[x] = (uint8_t)((dst[x] + src[x] + 1) >> 1);
+}
+void oracle_bipred_weight(uint8_t *dst, int ds, const uint8_t *src, int ss, int w, int h, int w1)
+{   /* implicit weights only: log2_denom 5, offset 0, w1 + w2 = 64 (:104-105) */
+    const int w2 = 64 - w1;
+    for (int y = 0; y < h; y++, dst += ds, src += ss)
+        for (int x = 0; x < w; x++) dst[x] = (uint8_t)clip255((dst[x] * w1 + src[x] * w2 + 32) >> 6);
+}
+
 /* ---- deblocking sample filters ------------------------------------------------------- */
 void oracle_deblock_luma(uint8_t *pix, int xs, int ys, int alpha, int beta, const int8_t tc0[4])
 {   /* core/frame.c:302-341 */

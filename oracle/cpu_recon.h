@@ -41,6 +41,10 @@ void oracle_mc_luma(const uint8_t *ref, int w, int h, int x, int y, int mvx, int
                     int bw, int bh, uint8_t *dst, int dst_stride);           /* core/mc.c:237-266 + 172-235 */
 void oracle_mc_chroma(const uint8_t *ref, int w, int h, int x, int y, int mvx, int mvy,
                       int bw, int bh, uint8_t *dst, int dst_stride);         /* core/mc.c:303-334 */
+/* bi-prediction (not reachable through the reference's decoder, which has no B slices - pinned through its
+ * function tables): dst = (dst + src + 1) >> 1, and the implicit-weight form clip((dst*w1 + src*(64-w1) + 32) >> 6) */
+void oracle_bipred_avg(uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride, int w, int h);                     /* core/mc.c:76-88  */
+void oracle_bipred_weight(uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride, int w, int h, int weight1);     /* core/mc.c:106-132 */
 void oracle_deblock_luma(uint8_t *pix, int xstride, int ystride, int alpha, int beta, const int8_t tc0[4]);   /* core/frame.c:302-341 */
 void oracle_deblock_chroma(uint8_t *pix, int xstride, int ystride, int alpha, int beta, const int8_t tc[4]);  /* core/frame.c:351-377 */
 void oracle_deblock_luma_intra(uint8_t *pix, int xstride, int ystride, int alpha, int beta);                  /* core/frame.c:387-433 */

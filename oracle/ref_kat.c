@@ -115,3 +115,8 @@ void refk_deblock(int which, uint8_t *pix, int stride, int alpha, int beta, int8
     case 7: f->deblock_h_chroma_intra(pix, stride, alpha, beta); break;
     }
 }
+
+/* ---- bi-prediction: pf->avg[] / pf->avg_weight[] (core/mc.c:76-155, tables :366-379),
+ *      which = PIXEL_16x16 .. PIXEL_2x2 (core/pixel.h) --------------------------------------------- */
+void refk_avg(int which, uint8_t *dst, int dst_stride, uint8_t *src, int src_stride) { g_h->mc.avg[which](dst, dst_stride, src, src_stride); }
+void refk_avg_weight(int which, uint8_t *dst, int dst_stride, uint8_t *src, int src_stride, int weight1) { g_h->mc.avg_weight[which](dst, dst_stride, src, src_stride, weight1); }

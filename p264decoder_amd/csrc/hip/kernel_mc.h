@@ -408,6 +408,29 @@ __device__ __forceinline__ uint32_t tap_v4(uint32_t r0, uint32_t r1, uint32_t r2
     return as_u32(a) | (as_u32(b) << 8);
 }
 
+// ------------------------------------------------------------------------------------------
+// bi-prediction (first piece of the B-slice path): the two ways the reference combines two predictions,
+// four samples at a time.  pixel_avg_wxh (core/mc.c:76-88) is the byte-parallel rounding average above; the implicit-weight
+// form pixel_avg_weight_wxh (core/mc.c:106-132): clip((a * w1 + b * (64 - w1) + 32) >> 6), weights from -64 to 128.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bipred_avg4(uint32_t a, uint32_t b) { return avg4(a, b); }
+__device__ __forceinline__ uint32_t bipred_weight4(uint32_t a, uint32_t b, int w1)
+{
+    const int w2 = 64 - w1;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (int)((a >> (8 * i)) & 255u) * w1 + (int)((b >> (8 * i)) & 255u) * w2 + 32;
+    return round_pack4<6>(v);
+}
+// whole frames (every dword of the strip layout is four horizontally adjacent samples of one plane)
+__global__ void k_bipred_frames(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, int n_dwords, int weighted, int w1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dwords) return;
+    const uint32_t a = dst[i], b = src[i];
+    dst[i] = weighted ? bipred_weight4(a, b, w1) : bipred_avg4(a, b);
+}
+
 // ---- the seven phase classes: out[y] = the four samples of row y of the lane's 4x4 block -----------------------------
 // (ix, iy) = integer position of the block's first sample in the reference, (fx, fy) = quarter-pel phase.
 template <class W> __device__ __forceinline__ void mc_copy(uint32_t (&out)[4], const W &w, int ix, int iy)

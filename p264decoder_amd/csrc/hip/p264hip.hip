@@ -452,6 +452,19 @@ extern "C" int p264hip_submit_async(p264hip_ctx *c, int stream, const p264hip_pi
     return p264hip_reconstruct(c, &stream, &stream, 1);
 }
 
+extern "C" int p264hip_bipred_frames(p264hip_ctx *c, int stream, int dst_slot, int src_slot, int weighted, int weight1)
+{
+    if (!c || stream < 0 || stream >= c->n_streams || dst_slot < 0 || dst_slot >= c->slots || src_slot < 0 || src_slot >= c->slots || dst_slot == src_slot ||
+        weight1 < -64 || weight1 > 128)
+        return fail(P264HIP_EINVAL, "p264hip_bipred_frames: bad argument (stream %d, slots %d <- %d, weight %d)", stream, dst_slot, src_slot, weight1);
+    HIPCHK(hipSetDevice(c->device));
+    const int n_dw = c->g.n_mb * 96;
+    hipLaunchKernelGGL(k_bipred_frames, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, (uint32_t *)frame_ptr(c, stream, dst_slot),
+                       (const uint32_t *)frame_ptr(c, stream, src_slot), n_dw, weighted, weight1);
+    HIPCHK(hipGetLastError());
+    return P264HIP_OK;
+}
+
 static int drain_stamps(p264hip_ctx *c)
 {
     for (auto &s : c->stamps) {

@@ -133,6 +133,33 @@ for i in range(n):
 out.update(db_in=np.array(bufs), db_out=np.array(afters), db_par=np.array(params, np.int32))
 
 np.savez_compressed(os.path.join(HERE, "kat_hotpath.npz"), **out)
+
+# ---- 8f rank 4: bi-prediction average / implicit-weight average through pf->avg[] / pf->avg_weight[] (core/mc.c:76-155) ----
+# (its own file and its own generator: the vectors above stay byte-identical)
+rb = np.random.default_rng(264004)
+SIZES = [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (4, 2), (2, 4), (2, 2)]      # PIXEL_16x16 .. PIXEL_2x2 (core/pixel.h)
+lib.refk_avg.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+lib.refk_avg_weight.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+bi_a, bi_b, bi_par, bi_out = [], [], [], []
+for k in range(600):
+    which = k % 10
+    w, h = SIZES[which]
+    a = rb.integers(0, 256, (16, 24)).astype(np.uint8)
+    b = rb.integers(0, 256, (16, 24)).astype(np.uint8)
+    if k % 7 == 0:
+        a[:] = 255; b[:] = rb.integers(250, 256)
+    if k % 11 == 0:
+        a[:] = 0; b[:] = rb.integers(0, 4)
+    weighted = k % 2
+    w1 = int(rb.integers(-64, 129)) if k % 6 else [32, 0, 64, -64, 128, 21][(k // 6) % 6]
+    o = a.copy()
+    if weighted:
+        lib.refk_avg_weight(which, P(o), 24, P(b), 24, w1)
+    else:
+        lib.refk_avg(which, P(o), 24, P(b), 24)
+    bi_a.append(a); bi_b.append(b); bi_out.append(o); bi_par.append((which, w, h, weighted, w1))
+np.savez_compressed(os.path.join(HERE, "kat_bipred.npz"), a=np.array(bi_a), b=np.array(bi_b), out=np.array(bi_out), par=np.array(bi_par, np.int32))
+print("bipred cases:", len(bi_par))
 print({k: v.shape for k, v in out.items()})
 chg = (out["db_in"] != out["db_out"]).reshape(n, -1).any(1)
 print("deblock cases that modified samples:", [int(chg[out["db_par"][:, 0] == w].sum()) for w in range(8)])

@@ -91,3 +91,18 @@ def test_deblock_sample_filters(oracle, kat):
         else:
             oracle.oracle_deblock_chroma_intra(pix, xs, ys, alpha, beta)
         assert np.array_equal(t, kat["db_out"][i]), "deblock filter %d case %d" % (which, i)
+
+
+def test_bipred_average_and_weight(oracle):
+    """pf->avg[] / pf->avg_weight[] of the reference (core/mc.c:76-155), all ten block sizes, weights over
+    the whole implicit range incl. negative ones (tests/golden/kat_bipred.npz, recorded from the real function tables)."""
+    kat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_bipred.npz"))
+    oracle.oracle_bipred_avg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    oracle.oracle_bipred_weight.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    for a, b, want, (which, w, h, weighted, w1) in zip(kat["a"], kat["b"], kat["out"], kat["par"].tolist()):
+        o = a.copy()
+        if weighted:
+            oracle.oracle_bipred_weight(P(o), 24, P(np.ascontiguousarray(b)), 24, w, h, w1)
+        else:
+            oracle.oracle_bipred_avg(P(o), 24, P(np.ascontiguousarray(b)), 24, w, h)
+        assert np.array_equal(o, want), "size %dx%d weighted %d w1 %d" % (w, h, weighted, w1)

@@ -270,9 +270,12 @@ def main():
     # the REAL reference decoder) as long as it is long enough: its timed output is checked against those hashes below.
     golden_hashes = synth_cases.golden("cfg3_1080p_allp")[1]
     use_golden = T <= len(golden_hashes)
+    synth_extra = os.environ.get("P264AMD_BENCH_SYNTH_EXTRA", "")     # experiments only (e.g. "--mvmax 0"): no golden stream then
+    if synth_extra:
+        use_golden = False
     paths, parsed = [], []
     for g in range(DISTINCT):
-        path = synth_cases.generate("cfg3_1080p_allp") if (g == 0 and use_golden) else synth_cases.generate(synth_args(T, 1000 + 16 * rank + g))
+        path = synth_cases.generate("cfg3_1080p_allp") if (g == 0 and use_golden) else synth_cases.generate(synth_args(T, 1000 + 16 * rank + g) + (" " + synth_extra if synth_extra else ""))
         paths.append(path)
         pics = Parser(quiet=True, lib=lib).parse_stream(open(path, "rb").read(), limit=T)
         assert len(pics) == T and all(p.desc.slice_type == 0 for p in pics[1:])

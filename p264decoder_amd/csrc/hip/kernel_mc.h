@@ -29,8 +29,8 @@
 //     otherwise (4 lanes, a 13-row window); quadrants whose 4x4 blocks differ (sub-8x8 partitions) fetch per lane with
 //     clamped coordinates.
 //
-// Chroma (4x4 per quadrant and plane, bilinear) has no phase classes; it has its own kernel and lists (macroblock items
-// of 8 lanes, quadrant items of 2), keys {inside / clamped, residual or not}.
+// Chroma (4x4 per quadrant and plane, bilinear) has no phase classes; it has its own kernels and lists (macroblock items
+// of 8 lanes; quadrant items of 2 lanes, the four of a macroblock consecutive), keys {inside / clamped, residual or not}.
 //
 // Arithmetic to preserve: core/mc.c:172-266 (half-pel planes, quarter-pel averages), :303-334 (chroma),
 // core/quant.c:66-99,138-159, core/dct.c:55-68,205-247 with their int16 stores (A-Q8).
@@ -141,6 +141,7 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
         k.key[1] = k.key[2] = k.key[3] = 0; k.vec[1] = k.vec[2] = k.vec[3] = 0;
         return k;
     }
+    bool c_inside = true;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         // vectors of the quadrant's four 4x4 blocks (raster inside the macroblock: b0, b0+1, b0+4, b0+5)
@@ -157,10 +158,14 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
         if (!uniform) { pc = PC_GEN; fl = MCY_CLAMP; }
         if ((mask >> (4 * q)) & 15) fl |= MCY_RESID;
         const int ky = band * MCY_KEYS + (pc | fl);
-        const int kc = band * MCC_KEYS + ((in_c && uniform) ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
-        k.key[q] = (uint32_t)ky | (uint32_t)kc << 16;
+        c_inside &= in_c && uniform;
+        k.key[q] = (uint32_t)ky;
         k.vec[q] = va;
     }
+    // the chroma entries of a split macroblock stay together (four consecutive list entries, quadrant 0..3): one key for all
+    const int kc = band * MCC_KEYS + (c_inside ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) k.key[q] |= (uint32_t)kc << 16;
     return k;
 }
 
@@ -176,7 +181,8 @@ __device__ __forceinline__ void mc_count(const McSortCtx &c, const McMb &k)
     if (k.info & MCMB_WHOLE) { atomicAdd(&c.cnt[c.b_ym + (k.key[0] & 0xffffu)], 1u); atomicAdd(&c.cnt[c.b_cm + (k.key[0] >> 16)], 1u); }
     else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) { atomicAdd(&c.cnt[c.b_yq + (k.key[q] & 0xffffu)], 1u); atomicAdd(&c.cnt[c.b_cq + (k.key[q] >> 16)], 1u); }
+        for (int q = 0; q < 4; q++) atomicAdd(&c.cnt[c.b_yq + (k.key[q] & 0xffffu)], 1u);
+        atomicAdd(&c.cnt[c.b_cq + (k.key[0] >> 16)], 4u);
     }
 }
 __device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, int mbi)
@@ -187,11 +193,12 @@ __device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, in
         gstore2(c.out + c.l_ym + 2 * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
         gstore2(c.out + c.l_cm + 2 * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
     } else {
+        const uint32_t cq = atomicAdd(&c.pos[c.b_cq + (k.key[0] >> 16)], 4u);     // (a multiple of 4: every segment starts on a chunk)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint2 e = make_uint2(mcmb_entry(k, mbi, q), k.vec[q]);
             gstore2(c.out + c.l_yq + 2 * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
-            gstore2(c.out + c.l_cq + 2 * atomicAdd(&c.pos[c.b_cq + (k.key[q] >> 16)], 1u), e);
+            gstore2(c.out + c.l_cq + 2 * (cq + (uint32_t)q), e);
         }
     }
 }
@@ -282,6 +289,26 @@ __device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
+#ifndef MC_LUMA_STORE16
+#define MC_LUMA_STORE16 1
+#endif
+// 4x4 dword transpose among the four lanes of a quad: t[k] of lane L = x[L] of lane k (two exchange steps)
+__device__ __forceinline__ void quad_transpose(uint32_t (&t)[4], const uint32_t (&x)[4], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    uint32_t a[4];
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {                       // with lane ^ 1: a[i + j] = x[i + b0] of lane (L & ~1) + j
+        const uint32_t r = lane_xor1(b0 ? x[i] : x[i + 1]);
+        a[i] = b0 ? r : x[i]; a[i + 1] = b0 ? x[i + 1] : r;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                          // with lane ^ 2
+        const uint32_t r = lane_xor2(b1 ? a[j] : a[2 + j]);
+        t[j] = b1 ? r : a[j]; t[2 + j] = b1 ? a[2 + j] : r;
+    }
+}
+__device__ __forceinline__ void bstore4(rsrc_t r, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const u32x4 v = { a, b, c, d }; __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0); }
 
 // ------------------------------------------------------------------------------------------
 // reference windows in registers
@@ -739,7 +766,13 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     }
     // ---- store: the two lanes of a block row swap halves, so that a lane writes two rows of 8 samples (four lanes: eight
     // consecutive rows, one or two cache lines) instead of four rows of 4 ----
-    {
+    if (MB && MC_LUMA_STORE16) {
+        // macroblock items: the four lanes of a quad are the four blocks of a block row - transposed, a lane writes one
+        // whole 16-byte row and the macroblock's sixteen lanes two whole cache lines
+        uint32_t t[4];
+        quad_transpose(t, out, lane);
+        if (valid) bstore4(rs, pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + bx) * 16), t[0], t[1], t[2], t[3]);
+    } else {
         const bool right = bx & 1;
         const uint32_t g0 = lane_xor1(right ? out[0] : out[2]), g1 = lane_xor1(right ? out[1] : out[3]);
         const uint32_t r0a = right ? g0 : out[0], r0b = right ? out[2] : g0;       // row 4*by + 2*right: samples 0-3, 4-7
@@ -980,10 +1013,17 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
         idct_add(col, px);
         if (has_res) { out[0] = px[0]; out[1] = px[1]; out[2] = px[2]; out[3] = px[3]; }
     }
-    if (valid) {
-        const uint32_t o = pd->dst_off + mb_chroma_off(g, mbx, mby) + (uint32_t)((q >> 1) * 64 + p * 8 + (q & 1) * 4);
-#pragma unroll
-        for (int y = 0; y < 4; y++) bstore(rs, o + (uint32_t)(y * 16), out[y]);
+    {
+        // (Quadrant items: the four entries of a split macroblock are consecutive, so its eight lanes sit exactly like the
+        // eight lanes of a macroblock item.)  The four lanes of a quad hold the four dwords of the same four rows (U left, V left, U right, V right block):
+        // transpose among them, so that a lane writes ONE whole 16-byte row and a macroblock's eight lanes one cache line
+        // (four 4-byte stores per lane kept the address unit busier than anything else in this kernel).
+        uint32_t t[4];
+        quad_transpose(t, out, lane);
+        if (valid) {
+            const uint32_t o = pd->dst_off + mb_chroma_off(g, mbx, mby) + (uint32_t)((q >> 1) * 64 + (lane & 3) * 16);
+            bstore4(rs, o, t[0], t[2], t[1], t[3]);      // lane-in-quad = plane + 2 * (block column): dwords U0 U1 V0 V1
+        }
     }
     if (!more) break;
     chunk = next; key_w = key_w_next; e = e_next;

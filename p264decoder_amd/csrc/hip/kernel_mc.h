@@ -54,11 +54,13 @@ __host__ __device__ static inline int mc_chunk_items(int l) { return l == ML_YM 
 __host__ __device__ static inline int mc_list_keys(int l) { return l < ML_CM ? MCY_KEYS : MCC_KEYS; }
 
 // Per-picture scratch written by k_mc_sort (32-bit words): [l] chunks in use of list l, then per list one class byte
-// per chunk, then the lists.  A list entry is 8 bytes: x = reference index << 28 | macroblock index << 2 | quadrant (low
-// 28 bits all ones = padding), y = the item's vector (packed) - all a wavefront needs to start fetching its windows
-// without looking at the macroblock arrays (each look-up is a dependent memory round trip per wavefront); only chunks
-// with residual read the macroblock record.  Same layout for every picture of a batch.
+// per chunk, then the lists.  A list entry is 16 bytes: x = reference index << 28 | macroblock index << 2 | quadrant (low
+// 28 bits all ones = padding), y = the item's vector (packed), z = the macroblock's coded-block mask | QP << 26, w = its
+// place in the coefficient stream - all a wavefront needs to start fetching its windows AND its coded levels without
+// looking at the macroblock arrays (each look-up is a dependent memory round trip per wavefront).  Same layout for
+// every picture of a batch.
 #define MC_ITEM_MASK 0x0fffffffu
+#define MC_ENTRY_WORDS 4u
 struct McLayout {
     uint32_t band_log2, n_bands;
     uint32_t max_chunks[ML_LISTS], off_cls[ML_LISTS], off_list[ML_LISTS], words;
@@ -76,7 +78,7 @@ static inline McLayout mc_layout(int mb_w, int mb_h, int band_log2)
         L.off_cls[l] = at; at += (L.max_chunks[l] + 3) / 4;
     }
     at = (at + 15) & ~15u;
-    for (int l = 0; l < ML_LISTS; l++) { L.off_list[l] = at; at += L.max_chunks[l] * (uint32_t)mc_chunk_items(l) * 2u; }
+    for (int l = 0; l < ML_LISTS; l++) { L.off_list[l] = at; at += L.max_chunks[l] * (uint32_t)mc_chunk_items(l) * MC_ENTRY_WORDS; }
     L.words = (at + 63) & ~63u;
     return L;
 }
@@ -114,7 +116,7 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
     int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
     if (mbi - mby * g.mb_w >= g.mb_w) mby++;
     const int mbx = mbi - mby * g.mb_w, band = mby >> band_log2;
-    const unsigned mask = rec.y, cc = (rec.x >> 20) & 3;
+    const unsigned mask = rec.y, cc = mask & (0x00ff0000u | P264_COEF_CHROMA_DC);   // any chroma level present
     const int n_ref = pd->n_ref;
     int ri[4];
 #pragma unroll
@@ -174,7 +176,7 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
 // stays in registers between the two passes: the macroblock arrays are read once.
 #define MC_KEY_SLOTS (2 * MC_MAX_BANDS * MCY_KEYS + 2 * MC_MAX_BANDS * MCC_KEYS)
 #define MC_SORT_KEEP 8
-struct McSortCtx { uint32_t *cnt, *pos, *out; int b_ym, b_yq, b_cm, b_cq; uint32_t l_ym, l_yq, l_cm, l_cq; };
+struct McSortCtx { const PicDev *pd; uint32_t *cnt, *pos, *out; int b_ym, b_yq, b_cm, b_cq; uint32_t l_ym, l_yq, l_cm, l_cq; };
 __device__ __forceinline__ void mc_count(const McSortCtx &c, const McMb &k)
 {
     if (!(k.info & MCMB_INTER)) return;
@@ -188,17 +190,19 @@ __device__ __forceinline__ void mc_count(const McSortCtx &c, const McMb &k)
 __device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, int mbi)
 {
     if (!(k.info & MCMB_INTER)) return;
+    const uint4 rec = gload4(c.pd->mb + mbi);              // (second look at the record: out of the cache)
+    const uint32_t ez = (rec.y & 0x03ffffffu) | ((rec.x >> 8) & 63u) << 26, ew = rec.z;
     if (k.info & MCMB_WHOLE) {
-        const uint2 e = make_uint2(mcmb_entry(k, mbi, 0), k.vec[0]);
-        gstore2(c.out + c.l_ym + 2 * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
-        gstore2(c.out + c.l_cm + 2 * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
+        const uint4 e = make_uint4(mcmb_entry(k, mbi, 0), k.vec[0], ez, ew);
+        gstore4(c.out + c.l_ym + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
+        gstore4(c.out + c.l_cm + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
     } else {
         const uint32_t cq = atomicAdd(&c.pos[c.b_cq + (k.key[0] >> 16)], 4u);     // (a multiple of 4: every segment starts on a chunk)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint2 e = make_uint2(mcmb_entry(k, mbi, q), k.vec[q]);
-            gstore2(c.out + c.l_yq + 2 * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
-            gstore2(c.out + c.l_cq + 2 * (cq + (uint32_t)q), e);
+            const uint4 e = make_uint4(mcmb_entry(k, mbi, q), k.vec[q], ez, ew);
+            gstore4(c.out + c.l_yq + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
+            gstore4(c.out + c.l_cq + MC_ENTRY_WORDS * (cq + (uint32_t)q), e);
         }
     }
 }
@@ -210,7 +214,7 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
     uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
     const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
     const int b_ym = 0, b_yq = nky, b_cm = 2 * nky, b_cq = 2 * nky + nkc, b_end = 2 * nky + 2 * nkc;     // key slots of the four lists
-    const McSortCtx ctx = { cnt, pos, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[ML_YM], ml.off_list[ML_YQ], ml.off_list[ML_CM], ml.off_list[ML_CQ] };
+    const McSortCtx ctx = { pd, cnt, pos, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[ML_YM], ml.off_list[ML_YQ], ml.off_list[ML_CM], ml.off_list[ML_CQ] };
     const int tid = threadIdx.x;
     if (pd->slice_type != P264_SLICE_P) {                 // wave-uniform
         if (tid < ML_LISTS) gstore1(out + tid, 0);
@@ -259,7 +263,7 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
         const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
         const uint32_t per = (uint32_t)mc_chunk_items(l), end = pos[k];
         const uint32_t lo = l == ML_YM ? ml.off_list[ML_YM] : l == ML_YQ ? ml.off_list[ML_YQ] : l == ML_CM ? ml.off_list[ML_CM] : ml.off_list[ML_CQ];
-        for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore2(out + lo + 2 * p, make_uint2(0xffffffffu, 0));
+        for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore4(out + lo + MC_ENTRY_WORDS * p, make_uint4(0xffffffffu, 0, 0, 0));
     }
 }
 
@@ -289,6 +293,15 @@ __device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
+#ifndef MCX_NOSTORE
+#define MCX_NOSTORE 0
+#endif
+#ifndef MCX_NOLOAD
+#define MCX_NOLOAD 0
+#endif
+#ifndef MCX_NOCOMPUTE
+#define MCX_NOCOMPUTE 0
+#endif
 #ifndef MC_LUMA_STORE16
 #define MC_LUMA_STORE16 1
 #endif
@@ -346,7 +359,7 @@ __device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t rof
         dst[j] = row * I::PITCH + s * 16;
         on[j] = !MB || s < 2 || third;
         v[j] = u32x4{ 0, 0, 0, 0 };
-        if (on[j]) {
+        if (on[j] && !MCX_NOLOAD) {
             if (!CLAMP) v[j] = bload4(rs, roff + (uint32_t)(sA + s) * g.ystrip + (uint32_t)((wy + row) * 16));
             else {
                 const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
@@ -682,12 +695,12 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     const int n_ref = pd->n_ref;
     uint32_t key_w = cls_w[chunk >> 2];
-    uint2 e = gload2(list + (size_t)(chunk * I::PER_WAVE + it) * 2);
+    uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
   for (;;) {
     const int next = chunk + stride;
     const bool more = next < n_chunks;
-    uint32_t key_w_next = 0; uint2 e_next = make_uint2(0, 0);
-    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload2(list + (size_t)(next * I::PER_WAVE + it) * 2); }
+    uint32_t key_w_next = 0; uint4 e_next = make_uint4(0, 0, 0, 0);
+    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload4(list + (size_t)(next * I::PER_WAVE + it) * MC_ENTRY_WORDS); }
     const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);                                 // scalar: the chunk's key bits
     const int pc = key & 7;
     wave_lds_fence();                                      // the previous chunk's image has been read
@@ -696,9 +709,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     // block position inside the macroblock
     const int q = MB ? 0 : (valid ? (int)(e.x & 3) : 0);
     const int bx = MB ? (li & 3) : (q & 1) * 2 + (li & 1), by = MB ? (li >> 2) : (q >> 1) * 2 + (li >> 1);
-    // chunks with residual: the macroblock record (QP, coded-block mask, place in the coefficient stream)
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (key & MCY_RESID) rec = gload4(pd->mb + mbi);
+    // chunks with residual: QP, coded-block mask and place in the coefficient stream come with the entry
     int mvp = (int)e.y;
     if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
     uint32_t roff = pd->ref_off[0];
@@ -707,10 +718,10 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
     const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
-    const unsigned mask = rec.y;
+    const unsigned mask = e.z & 0x03ffffffu;
     const int blk = blk_at(bx, by);                        // decode-order index: bit of coef_mask, position in the packed stream
     const bool coded = valid && ((mask >> blk) & 1);
-    // coded levels (the record was requested before the windows, the levels fly while the prediction is computed)
+    // coded levels (requested right behind the windows: they fly while the prediction is computed)
     uint4 la = make_uint4(0, 0, 0, 0), lb = la;
     // ---- prediction ----
     uint32_t out[4];
@@ -726,17 +737,17 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         if (!(key & MCY_CLAMP)) { if (rows_mid) stage_luma<MB, 2, RM, false>(img, rs, roff, g, wx, wy, li, third); else stage_luma<MB, 0, I::ROWS, false>(img, rs, roff, g, wx, wy, li, third); }
         else                    { if (rows_mid) stage_luma<MB, 2, RM, true>(img, rs, roff, g, wx, wy, li, third);  else stage_luma<MB, 0, I::ROWS, true>(img, rs, roff, g, wx, wy, li, third); }
         if ((key & MCY_RESID) && coded) {
-            const int16_t *cf = pd->coefs + ((size_t)rec.z + coef_slot(mask, blk)) * 16;
+            const int16_t *cf = pd->coefs + ((size_t)e.w + coef_slot(mask, blk)) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
         }
         wave_lds_fence();
         const LWin<I::PITCH> w = { img, (wx >> 4) * 16, wy };
-        mc_luma_class(pc, out, w, ix, iy, fx, fy);
+        mc_luma_class(MCX_NOCOMPUTE ? PC_COPY : pc, out, w, ix, iy, fx, fy);
     } else {
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
         // straight from memory, one pass per phase class present among the lanes.
         if ((key & MCY_RESID) && coded) {
-            const int16_t *cf = pd->coefs + ((size_t)rec.z + coef_slot(mask, blk)) * 16;
+            const int16_t *cf = pd->coefs + ((size_t)e.w + coef_slot(mask, blk)) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
         }
         out[0] = out[1] = out[2] = out[3] = 0;
@@ -759,7 +770,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<false>(lv, col);
-        dequant_cols(col, (int)((rec.x >> 8) & 255));
+        dequant_cols(col, (int)(e.z >> 26));
         uint32_t px[4] = { out[0], out[1], out[2], out[3] };
         idct_add(col, px);
         if (coded) { out[0] = px[0]; out[1] = px[1]; out[2] = px[2]; out[3] = px[3]; }
@@ -771,7 +782,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         // whole 16-byte row and the macroblock's sixteen lanes two whole cache lines
         uint32_t t[4];
         quad_transpose(t, out, lane);
-        if (valid) bstore4(rs, pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + bx) * 16), t[0], t[1], t[2], t[3]);
+        if (valid && (!MCX_NOSTORE || t[0] == 0x12345678u)) bstore4(rs, pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + bx) * 16), t[0], t[1], t[2], t[3]);
     } else {
         const bool right = bx & 1;
         const uint32_t g0 = lane_xor1(right ? out[0] : out[2]), g1 = lane_xor1(right ? out[1] : out[3]);
@@ -787,13 +798,19 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     chunk = next; key_w = key_w_next; e = e_next;
   }
 }
-__global__ __launch_bounds__(256, 4)
+#ifndef MC_LUMA_MB_WAVES
+#define MC_LUMA_MB_WAVES 4
+#endif
+__global__ __launch_bounds__(256, MC_LUMA_MB_WAVES)
 void k_mc_luma_mb(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
     __shared__ __attribute__((aligned(16))) uint8_t images[4 * 4 * YItem<true>::BYTES];
     mc_luma_body<true>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
 }
-__global__ __launch_bounds__(256, 4)
+#ifndef MC_LUMA_QUAD_WAVES
+#define MC_LUMA_QUAD_WAVES 4
+#endif
+__global__ __launch_bounds__(256, MC_LUMA_QUAD_WAVES)
 void k_mc_luma_quad(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
     __shared__ __attribute__((aligned(16))) uint8_t images[4 * 16 * YItem<false>::BYTES];
@@ -887,27 +904,25 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     const int n_ref = pd->n_ref;
     uint32_t key_w = cls_w[chunk >> 2];
-    uint2 e = gload2(list + (size_t)(chunk * I::PER_WAVE + it) * 2);
+    uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
   for (;;) {
     const int next = chunk + stride;
     const bool more = next < n_chunks;
-    uint32_t key_w_next = 0; uint2 e_next = make_uint2(0, 0);
-    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload2(list + (size_t)(next * I::PER_WAVE + it) * 2); }
+    uint32_t key_w_next = 0; uint4 e_next = make_uint4(0, 0, 0, 0);
+    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload4(list + (size_t)(next * I::PER_WAVE + it) * MC_ENTRY_WORDS); }
     const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
     const int mbi = valid ? (int)((e.x & MC_ITEM_MASK) >> 2) : 0;
     const int q = MB ? (li >> 1) : (valid ? (int)(e.x & 3) : 0);
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (key & MCC_RESID) rec = gload4(pd->mb + mbi);
     uint32_t roff = pd->ref_off[0];
     if (n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;      // the block's first sample
-    const unsigned mask = rec.y;
+    const unsigned mask = e.z & 0x03ffffffu;
     const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
-    const bool has_res = valid && ((rec.x >> 20) & 3) != 0;  // cbp >> 4
+    const bool has_res = valid && (mask & (0x00ff0000u | P264_COEF_CHROMA_DC)) != 0;
     uint4 la = make_uint4(0, 0, 0, 0), lb = la; uint2 dcl = make_uint2(0, 0);
     // ---- prediction ----
     uint32_t out[4];
@@ -951,7 +966,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
             img = pimg + (i >> 1) * I::BYTES;
         }
         if (key & MCC_RESID) {
-            const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+            const int16_t *cf = pd->coefs + (size_t)e.w * 16;
             if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
@@ -969,7 +984,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
         // follows its own vector): clamped windows straight from memory, one pass per piece, wave-uniformly skipped when
         // nobody needs it
         if (key & MCC_RESID) {
-            const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+            const int16_t *cf = pd->coefs + (size_t)e.w * 16;
             if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
@@ -995,7 +1010,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     }
     // ---- residual (decoder/macroblock.c:851-890): chroma DC through the 2x2 transform, AC, inverse transform ----
     if ((key & MCC_RESID) && __ballot(has_res)) {
-        const int qpc = chroma_qp(clip3i((int)((rec.x >> 8) & 255) + pd->chroma_qp_offset, 0, 51));
+        const int qpc = chroma_qp(clip3i((int)(e.z >> 26) + pd->chroma_qp_offset, 0, 51));
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<true>(lv, col);

@@ -44,18 +44,21 @@ struct Geom {
 // immediate per row, no per-row address arithmetic (kernel_mc.h).  Planar views exist only at the host boundary
 // (p264hip_read_frame / p264hip_write_frame).
 #define MB_LUMA_BYTES   256
+// strip index x strip size: both below 2^24 (a strip is 16 bytes x the picture height), so the full-rate 24-bit multiply
+// does it (v_mul_lo_u32 runs at a quarter of the rate and sits in every address computation of the kernels)
+__device__ __forceinline__ uint32_t strip_mul(int strip, uint32_t strip_bytes)  { return __umul24((unsigned)strip, strip_bytes); }
 #define MB_CHROMA_BYTES 128
 __device__ __forceinline__ uint32_t luma_off(const Geom &g, int x, int y)
 {
-    return (uint32_t)(x >> 4) * g.ystrip + (uint32_t)(y * 16 + (x & 15));
+    return strip_mul(x >> 4, g.ystrip) + (uint32_t)(y * 16 + (x & 15));
 }
 __device__ __forceinline__ uint32_t chroma_off(const Geom &g, int plane, int x, int y)
 {
-    return g.coff + (uint32_t)(x >> 3) * g.cstrip + (uint32_t)(y * 16 + plane * 8 + (x & 7));
+    return g.coff + strip_mul(x >> 3, g.cstrip) + (uint32_t)(y * 16 + plane * 8 + (x & 7));
 }
 // first byte of a macroblock's luma / chroma part
-__device__ __forceinline__ uint32_t mb_luma_off(const Geom &g, int mbx, int mby) { return (uint32_t)mbx * g.ystrip + (uint32_t)mby * MB_LUMA_BYTES; }
-__device__ __forceinline__ uint32_t mb_chroma_off(const Geom &g, int mbx, int mby) { return g.coff + (uint32_t)mbx * g.cstrip + (uint32_t)mby * MB_CHROMA_BYTES; }
+__device__ __forceinline__ uint32_t mb_luma_off(const Geom &g, int mbx, int mby) { return strip_mul(mbx, g.ystrip) + (uint32_t)mby * MB_LUMA_BYTES; }
+__device__ __forceinline__ uint32_t mb_chroma_off(const Geom &g, int mbx, int mby) { return g.coff + strip_mul(mbx, g.cstrip) + (uint32_t)mby * MB_CHROMA_BYTES; }
 
 // ---- global-memory accessors ------------------------------------------------------------
 // Pointers that reach a kernel through memory (the fields of PicDev) are "flat" to the compiler:

@@ -54,8 +54,8 @@ __host__ __device__ static inline int mc_chunk_items(int l) { return l == ML_YM 
 __host__ __device__ static inline int mc_list_keys(int l) { return l < ML_CM ? MCY_KEYS : MCC_KEYS; }
 
 // Per-picture scratch written by k_mc_sort (32-bit words): [l] chunks in use of list l, then per list one class byte
-// per chunk, then the lists.  A list entry is 16 bytes: x = reference index << 28 | macroblock index << 2 | quadrant (low
-// 28 bits all ones = padding), y = the item's vector (packed), z = the macroblock's coded-block mask | QP << 26, w = its
+// per chunk, then the lists.  A list entry is 16 bytes: x = reference index << 28 | macroblock row << 13 | column << 2 |
+// quadrant (low 28 bits all ones = padding; no division in the consumers), y = the item's vector (packed), z = the macroblock's coded-block mask | QP << 26, w = its
 // place in the coefficient stream - all a wavefront needs to start fetching its windows AND its coded levels without
 // looking at the macroblock arrays (each look-up is a dependent memory round trip per wavefront).  Same layout for
 // every picture of a batch.
@@ -97,6 +97,13 @@ __device__ __forceinline__ int phase_class(int fx, int fy)
     return PC_CV;
 }
 
+__device__ __forceinline__ void split_mb(int mbi, const Geom &g, uint32_t inv_mbw, int &mbx, int &mby)
+{
+    mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+    mbx = mbi - mby * g.mb_w;
+}
+
 // What one inter macroblock contributes: either one macroblock item per plane kind (one vector, one reference) or its
 // four quadrants.  Packed so that a thread can keep the classification of several macroblocks in registers between
 // the counting and the scattering pass: key[q] = luma key | chroma key << 16, vec[q] = the entry's vector,
@@ -104,7 +111,7 @@ __device__ __forceinline__ int phase_class(int fx, int fy)
 struct McMb { uint32_t info, key[4], vec[4]; };
 #define MCMB_INTER 1u
 #define MCMB_WHOLE 2u
-__device__ __forceinline__ uint32_t mcmb_entry(const McMb &k, int mbi, int q) { return ((k.info >> (8 + 4 * q)) & 15u) << 28 | (uint32_t)mbi << 2 | (uint32_t)q; }
+__device__ __forceinline__ uint32_t mcmb_entry(const McMb &k, int mbx, int mby, int q) { return ((k.info >> (8 + 4 * q)) & 15u) << 28 | (uint32_t)mby << 13 | (uint32_t)mbx << 2 | (uint32_t)q; }
 __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int mbi, uint32_t inv_mbw, int band_log2)
 {
     McMb k;
@@ -187,20 +194,22 @@ __device__ __forceinline__ void mc_count(const McSortCtx &c, const McMb &k)
         atomicAdd(&c.cnt[c.b_cq + (k.key[0] >> 16)], 4u);
     }
 }
-__device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, int mbi)
+__device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, int mbi, const Geom &g, uint32_t inv_mbw)
 {
     if (!(k.info & MCMB_INTER)) return;
+    int mbx, mby;
+    split_mb(mbi, g, inv_mbw, mbx, mby);
     const uint4 rec = gload4(c.pd->mb + mbi);              // (second look at the record: out of the cache)
     const uint32_t ez = (rec.y & 0x03ffffffu) | ((rec.x >> 8) & 63u) << 26, ew = rec.z;
     if (k.info & MCMB_WHOLE) {
-        const uint4 e = make_uint4(mcmb_entry(k, mbi, 0), k.vec[0], ez, ew);
+        const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, 0), k.vec[0], ez, ew);
         gstore4(c.out + c.l_ym + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
         gstore4(c.out + c.l_cm + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
     } else {
         const uint32_t cq = atomicAdd(&c.pos[c.b_cq + (k.key[0] >> 16)], 4u);     // (a multiple of 4: every segment starts on a chunk)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint4 e = make_uint4(mcmb_entry(k, mbi, q), k.vec[q], ez, ew);
+            const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, q), k.vec[q], ez, ew);
             gstore4(c.out + c.l_yq + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
             gstore4(c.out + c.l_cq + MC_ENTRY_WORDS * (cq + (uint32_t)q), e);
         }
@@ -254,9 +263,9 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
     __syncthreads();
     if (keep) {
 #pragma unroll
-        for (int j = 0; j < MC_SORT_KEEP; j++) mc_scatter(ctx, kept[j], tid + j * MC_SORT_THREADS);
+        for (int j = 0; j < MC_SORT_KEEP; j++) mc_scatter(ctx, kept[j], tid + j * MC_SORT_THREADS, g, inv_mbw);
     } else {
-        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_scatter(ctx, mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2), mbi);
+        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_scatter(ctx, mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2), mbi, g, inv_mbw);
     }
     __syncthreads();
     for (int k = tid; k < b_end; k += MC_SORT_THREADS) {                      // padding entries behind every segment
@@ -298,6 +307,9 @@ __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__b
 #endif
 #ifndef MCX_NOLOAD
 #define MCX_NOLOAD 0
+#endif
+#ifndef MCX_CLASS
+#define MCX_CLASS (-1)
 #endif
 #ifndef MCX_NOCOMPUTE
 #define MCX_NOCOMPUTE 0
@@ -360,10 +372,10 @@ __device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t rof
         on[j] = !MB || s < 2 || third;
         v[j] = u32x4{ 0, 0, 0, 0 };
         if (on[j] && !MCX_NOLOAD) {
-            if (!CLAMP) v[j] = bload4(rs, roff + (uint32_t)(sA + s) * g.ystrip + (uint32_t)((wy + row) * 16));
+            if (!CLAMP) v[j] = bload4(rs, roff + strip_mul(sA + s, g.ystrip) + (uint32_t)((wy + row) * 16));
             else {
                 const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
-                u32x4 t = bload4(rs, roff + (uint32_t)sc * g.ystrip + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
+                u32x4 t = bload4(rs, roff + strip_mul(sc, g.ystrip) + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
                 if (st < 0) { const uint32_t e = perm(t.x, t.x, 0x00000000u); t.x = t.y = t.z = t.w = e; }
                 if (st >= g.mb_w) { const uint32_t e = perm(t.w, t.w, 0x03030303u); t.x = t.y = t.z = t.w = e; }
                 v[j] = t;
@@ -382,7 +394,7 @@ template <int PITCH> struct LWin {
     const uint8_t *img; int x0, y0;                        // the image's sample (0,0) is (x0, y0) of the reference
     template <int R0, int NR, int NC> __device__ __forceinline__ void load(uint32_t (&d)[9][3], int xw, int yw) const
     {
-        const uint8_t *b = img + (yw - y0) * PITCH + ((xw & ~3) - x0);
+        const uint8_t *b = img + __mul24(yw - y0, PITCH) + ((xw & ~3) - x0);
 #pragma unroll
         for (int r = R0; r < R0 + NR; r++)
 #pragma unroll
@@ -398,7 +410,7 @@ struct GWin {
 #pragma unroll
         for (int k = 0; k < NC; k++) {
             const int x = xa + 4 * k, xc = clip3i(x, 0, g.w - 4);
-            col[k] = roff + (uint32_t)(xc >> 4) * g.ystrip + (uint32_t)(xc & 15);
+            col[k] = roff + strip_mul(xc >> 4, g.ystrip) + (uint32_t)(xc & 15);
             sel[k] = x < 0 ? 0x00000000u : x >= g.w ? 0x03030303u : 0x03020100u;
         }
 #pragma unroll
@@ -652,12 +664,6 @@ __device__ __forceinline__ void idct_add(const uint32_t (&col)[4][2], uint32_t (
     }
 }
 
-__device__ __forceinline__ void split_mb(int mbi, const Geom &g, uint32_t inv_mbw, int &mbx, int &mby)
-{
-    mby = (int)__umulhi((unsigned)mbi, inv_mbw);
-    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
-    mbx = mbi - mby * g.mb_w;
-}
 
 // XCD-aware block mapping: the dispatcher deals workgroups round-robin over the 8 XCDs; every XCD gets one contiguous
 // eighth of the batch, so that the windows of a picture meet in ONE L2 (speed only, never correctness).
@@ -705,17 +711,15 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     const int pc = key & 7;
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
-    const int mbi = valid ? (int)((e.x & MC_ITEM_MASK) >> 2) : 0;
+    const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x & MC_ITEM_MASK) >> 13) : 0;
     // block position inside the macroblock
     const int q = MB ? 0 : (valid ? (int)(e.x & 3) : 0);
     const int bx = MB ? (li & 3) : (q & 1) * 2 + (li & 1), by = MB ? (li >> 2) : (q >> 1) * 2 + (li >> 1);
     // chunks with residual: QP, coded-block mask and place in the coefficient stream come with the entry
     int mvp = (int)e.y;
-    if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + mbi * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
+    if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + (mby * g.mb_w + mbx) * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
     uint32_t roff = pd->ref_off[0];
     if (n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];                             // (wave-uniform branch)
-    int mbx, mby;
-    split_mb(mbi, g, inv_mbw, mbx, mby);
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
     const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
     const unsigned mask = e.z & 0x03ffffffu;
@@ -742,7 +746,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         }
         wave_lds_fence();
         const LWin<I::PITCH> w = { img, (wx >> 4) * 16, wy };
-        mc_luma_class(MCX_NOCOMPUTE ? PC_COPY : pc, out, w, ix, iy, fx, fy);
+        mc_luma_class(MCX_NOCOMPUTE ? PC_COPY : MCX_CLASS >= 0 ? MCX_CLASS : pc, out, w, ix, iy, fx, fy);
     } else {
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
         // straight from memory, one pass per phase class present among the lanes.
@@ -850,7 +854,7 @@ __device__ __forceinline__ void mc_chroma_clamped(uint32_t (&out)[4], rsrc_t rs,
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int x = xa + 4 * k, xc = clip3i(x, 0, g.cw - 4);
-        col[k] = roff + g.coff + (uint32_t)(xc >> 3) * g.cstrip + (uint32_t)(p * 8 + (xc & 7));
+        col[k] = roff + g.coff + strip_mul(xc >> 3, g.cstrip) + (uint32_t)(p * 8 + (xc & 7));
         sel[k] = x < 0 ? 0x00000000u : x >= g.cw ? 0x03030303u : 0x03020100u;
     }
 #pragma unroll
@@ -873,9 +877,9 @@ template <bool MB> struct CItem {
 // replicated first / last sample of each plane's 8 bytes)
 template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece(rsrc_t rs, uint32_t roff, const Geom &g, int strip, int y)
 {
-    if (!CLAMP) return bload4(rs, roff + g.coff + (uint32_t)strip * g.cstrip + (uint32_t)(y * 16));
+    if (!CLAMP) return bload4(rs, roff + g.coff + strip_mul(strip, g.cstrip) + (uint32_t)(y * 16));
     const int sc = clip3i(strip, 0, g.mb_w - 1);             // (a chroma strip is 8 samples wide: one per macroblock column)
-    u32x4 t = bload4(rs, roff + g.coff + (uint32_t)sc * g.cstrip + (uint32_t)(clip3i(y, 0, g.ch - 1) * 16));
+    u32x4 t = bload4(rs, roff + g.coff + strip_mul(sc, g.cstrip) + (uint32_t)(clip3i(y, 0, g.ch - 1) * 16));
     if (strip < 0) { const uint32_t u = perm(t.x, t.x, 0x00000000u), v = perm(t.z, t.z, 0x00000000u); t.x = t.y = u; t.z = t.w = v; }
     if (strip >= g.mb_w) { const uint32_t u = perm(t.y, t.y, 0x03030303u), v = perm(t.w, t.w, 0x03030303u); t.x = t.y = u; t.z = t.w = v; }
     return t;
@@ -913,12 +917,10 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
-    const int mbi = valid ? (int)((e.x & MC_ITEM_MASK) >> 2) : 0;
+    const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x & MC_ITEM_MASK) >> 13) : 0;
     const int q = MB ? (li >> 1) : (valid ? (int)(e.x & 3) : 0);
     uint32_t roff = pd->ref_off[0];
     if (n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];
-    int mbx, mby;
-    split_mb(mbi, g, inv_mbw, mbx, mby);
     const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;      // the block's first sample
     const unsigned mask = e.z & 0x03ffffffu;
     const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
@@ -953,7 +955,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
             // bytes), then row 4 of their own strips.
             const int sA = cx >> 3;
             x0 = sA * 8; y0 = cy;
-            const uint32_t own = roff + g.coff + (uint32_t)sA * g.cstrip + (uint32_t)(cy * 16), other = lane_xor2(own);
+            const uint32_t own = roff + g.coff + strip_mul(sA, g.cstrip) + (uint32_t)(cy * 16), other = lane_xor2(own);
             const int i = lane & 3;
             uint8_t *pimg = images + (wave * I::PER_WAVE + (lane >> 2) * 2) * I::BYTES;
             u32x4 v[5];
@@ -989,6 +991,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
         const int b0 = (q >> 1) * 8 + (q & 1) * 2;
+        const int mbi = mby * g.mb_w + mbx;
         const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
         const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
         const int v4[4] = { (int)va.x, (int)va.y, (int)vb.x, (int)vb.y };

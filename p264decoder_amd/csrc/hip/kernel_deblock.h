@@ -45,7 +45,7 @@
 
 enum { EC_LEFT = 0, EC_TOP = 1, EC_INNER = 2 };     // edge classes
 
-struct EdgeClass { uint8_t alpha, beta, tc[3], any, pad[2]; };   // tc = tc0 for bS 1..3 (chroma: already +1)
+struct EdgeClass { uint8_t alpha, beta, any, pad, zero, tc[3]; };   // tc = tc0 for bS 1..3 (chroma: already +1); second dword: byte bS = tc0[bS]
 struct EdgeInfo {                  // 64 bytes per macroblock, written by k_deblock_bs
     uint32_t  bs[4];               // 8 edges x 4 segments x 4 bits: word = dir*2 + (edge>>1), nibble = (edge&1)*4 + seg
     EdgeClass cls[6];              // [class + 3*chroma]; cls[0].any = some bS != 0
@@ -144,8 +144,8 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
         const uint32_t be = t_beta[clip3i(q + beta_off, 0, 51)];
         const uint32_t add = chroma ? 0x01010100u : 0u;                                            // chroma: tc0 + 1
         const uint32_t v = at + add;                                                               // alpha | tc0[0..2] (+1), no carries: tc0 <= 25
-        cls[2 * k] = (v & 0xffu) | (be << 8) | ((v & 0x00ffff00u) << 8);
-        cls[2 * k + 1] = (v >> 24) | ((uint32_t)(any ? 1 : 0) << 8);
+        cls[2 * k] = (v & 0xffu) | (be << 8) | ((uint32_t)(any ? 1 : 0) << 16);
+        cls[2 * k + 1] = v & 0xffffff00u;                                                         // byte bS (1..3) = its tc0, byte 0 = 0
     }
     EdgeInfo *out = info + (size_t)blockIdx.y * g.n_mb + mbi;
     uint32_t *o = (uint32_t *)out;
@@ -162,14 +162,19 @@ struct EdgeRegs {
     const uint32_t *lds;            // the octet's copy of the 16 dwords
     __device__ __forceinline__ uint32_t nib(int dir, int ed) const { return (e[dir * 2 + (ed >> 1)] >> ((ed & 1) * 16)) & 0xffffu; }
 };
-// class k occupies dwords 4+2k (alpha, beta, tc[0], tc[1]) and 5+2k (tc[2], any); k is a compile-time constant
+// class k occupies dwords 4+2k (alpha, beta, any) and 5+2k (0, tc0[1..3]); k is a compile-time constant.  Everything comes out
+// as a 16-bit pair with the same value in both halves, one v_perm each: the filter arithmetic is packed.
 struct EdgeParams {
     uint32_t lo, hi;
     __device__ __forceinline__ EdgeParams(const EdgeRegs &E, int k) { uint2 v = *(const uint2 *)(E.lds + 4 + 2 * k); lo = v.x; hi = v.y; }
-    __device__ __forceinline__ int alpha() const { return (int)(lo & 255); }
-    __device__ __forceinline__ int beta() const { return (int)((lo >> 8) & 255); }
-    __device__ __forceinline__ int tc(int b) const { return (int)((((lo >> 16) | (hi << 16)) >> (8 * b)) & 255); }   // b = bS-1 in 0..2, per lane
+    __device__ __forceinline__ uint32_t alpha2() const { return perm(lo, lo, 0x0c000c00u); }
+    __device__ __forceinline__ uint32_t beta2() const { return perm(lo, lo, 0x0c010c01u); }
+    // tc0 of boundary strength b (per lane; 0 for b = 0 and for b = 4, which does not use it): byte b of {0, hi}
+    __device__ __forceinline__ uint32_t tc2(int b) const { return perm(0u, hi, 0x0c000c00u + (uint32_t)b * 0x00010001u); }
 };
+// all ones where the boundary strength is 1..3 / is 4 (one sign-extending bit-field extract instead of compare + select)
+__device__ __forceinline__ uint32_t mask_bs123(int b) { return (uint32_t)__builtin_amdgcn_sbfe(0x0e, (unsigned)b, 1u); }
+__device__ __forceinline__ uint32_t mask_bs4(int b) { return (uint32_t)__builtin_amdgcn_sbfe(0x10, (unsigned)b, 1u); }
 __device__ __forceinline__ int edge_class(int dir, int ed) { return ed == 0 ? (dir == 0 ? EC_LEFT : EC_TOP) : EC_INNER; }
 
 // ------------------------------------------------------------------------------------------
@@ -221,13 +226,19 @@ __device__ __forceinline__ void pk_luma_strong(pk16 p3, pk16 &p2, pk16 &p1, pk16
     p2 = pk_sel(s & sp, p2s, p2); q2 = pk_sel(s & sq, q2s, q2);
 }
 // chroma edge, any bS (core/frame.c:351-377, 438-462); T = tc0+1 (from K4a), en/str = masks of the bS 1..3 / bS 4 lanes
-__device__ __forceinline__ void pk_chroma(pk16 p1, pk16 &p0, pk16 &q0, pk16 q1, pk16 f, pk16 en, pk16 str, pk16 T)
+// any_strong (wave-uniform): some lane of the wavefront has bS 4 on this edge
+__device__ __forceinline__ void pk_chroma(pk16 p1, pk16 &p0, pk16 &q0, pk16 q1, pk16 f, pk16 en, pk16 str, bool any_strong, pk16 T)
 {
     const pk16 delta = pk_clamp((((q0 - p0) << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -T, T) & (f & en);
-    const pk16 p0w = (p1 + p1 + p0 + q1 + (pk16)2) >> (pk16)2, q0w = (q1 + q1 + q0 + p1 + (pk16)2) >> (pk16)2;
-    const pk16 s = f & str;
-    p0 = pk_sel(s, p0w, pk_clamp(p0 + delta, (pk16)0, (pk16)255));
-    q0 = pk_sel(s, q0w, pk_clamp(q0 - delta, (pk16)0, (pk16)255));
+    const pk16 op0 = p0, oq0 = q0;
+    p0 = pk_clamp(p0 + delta, (pk16)0, (pk16)255);
+    q0 = pk_clamp(q0 - delta, (pk16)0, (pk16)255);
+    if (any_strong) {
+        const pk16 p0w = (p1 + p1 + op0 + q1 + (pk16)2) >> (pk16)2, q0w = (q1 + q1 + oq0 + p1 + (pk16)2) >> (pk16)2;
+        const pk16 s = f & str;
+        p0 = pk_sel(s, p0w, p0);
+        q0 = pk_sel(s, q0w, q0);
+    }
 }
 
 // byte K of two dwords as a 16-bit pair (a -> low half, b -> high half)
@@ -394,14 +405,14 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     pk16 p2 = pair_byte<1>(ya[ed], yb[ed]), p1 = pair_byte<2>(ya[ed], yb[ed]), p0 = pair_byte<3>(ya[ed], yb[ed]);
                     pk16 q0 = pair_byte<0>(ya[ed+1], yb[ed+1]), q1 = pair_byte<1>(ya[ed+1], yb[ed+1]), q2 = pair_byte<2>(ya[ed+1], yb[ed+1]);
                     const EdgeParams ep(E, k);
-                    const pk16 A = pk_splat(ep.alpha()), B = pk_splat(ep.beta());
+                    const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
                     const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
                     const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
-                    const pk16 en = as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u);
+                    const pk16 en = as_pk(mask_bs123(b));
                     const pk16 op2 = p2, op1 = p1, op0 = p0, oq0 = q0, oq1 = q1, oq2 = q2;
-                    pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, pk_splat(ep.tc((b - 1) & 3)));
+                    pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
                     if (__ballot(b == 4)) {
-                        const pk16 str = as_pk(b == 4 ? 0xffffffffu : 0u);
+                        const pk16 str = as_pk(mask_bs4(b));
                         pk16 sp2 = op2, sp1 = op1, sp0 = op0, sq0 = oq0, sq1 = oq1, sq2 = oq2;
                         pk_luma_strong(pair_byte<0>(ya[ed], yb[ed]), sp2, sp1, sp0, sq0, sq1, sq2, pair_byte<3>(ya[ed+1], yb[ed+1]), f & str, ap, aq, A);
                         p1 = pk_sel(str, sp1, p1); p0 = pk_sel(str, sp0, p0); q0 = pk_sel(str, sq0, q0); q1 = pk_sel(str, sq1, q1);
@@ -419,9 +430,8 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     pk16 p1 = pair_byte<2>(ca[c], cb[c]), p0 = pair_byte<3>(ca[c], cb[c]);
                     pk16 q0 = pair_byte<0>(ca[c+1], cb[c+1]), q1 = pair_byte<1>(ca[c+1], cb[c+1]);
                     const EdgeParams ep(E, k);
-                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, pk_splat(ep.alpha()), pk_splat(ep.beta()));
-                    pk_chroma(p1, p0, q0, q1, f, as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u), as_pk(b == 4 ? 0xffffffffu : 0u),
-                              pk_splat(ep.tc((b - 1) & 3)));
+                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, as_pk(ep.alpha2()), as_pk(ep.beta2()));
+                    pk_chroma(p1, p0, q0, q1, f, as_pk(mask_bs123(b)), as_pk(mask_bs4(b)), __ballot(b == 4) != 0, as_pk(ep.tc2(b)));
                     ca[c] = perm(as_u(p0), ca[c], 0x04020100u);     cb[c] = perm(as_u(p0), cb[c], 0x06020100u);
                     ca[c+1] = perm(as_u(q0), ca[c+1], 0x03020104u); cb[c+1] = perm(as_u(q0), cb[c+1], 0x03020106u);
                 }
@@ -463,14 +473,14 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         if (__ballot(b != 0) == 0) continue;
                         pk16 &p3 = c[4*ed], &p2 = c[4*ed+1], &p1 = c[4*ed+2], &p0 = c[4*ed+3], &q0 = c[4*ed+4], &q1 = c[4*ed+5], &q2 = c[4*ed+6], &q3 = c[4*ed+7];
                         const EdgeParams ep(E, k);
-                        const pk16 A = pk_splat(ep.alpha()), B = pk_splat(ep.beta());
+                        const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
                         const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
                         const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
-                        const pk16 en = as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u);
+                        const pk16 en = as_pk(mask_bs123(b));
                         pk16 sp2 = p2, sp1 = p1, sp0 = p0, sq0 = q0, sq1 = q1, sq2 = q2;
-                        pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, pk_splat(ep.tc((b - 1) & 3)));
+                        pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
                         if (__ballot(b == 4)) {
-                            const pk16 str = as_pk(b == 4 ? 0xffffffffu : 0u);
+                            const pk16 str = as_pk(mask_bs4(b));
                             pk_luma_strong(p3, sp2, sp1, sp0, sq0, sq1, sq2, q3, f & str, ap, aq, A);
                             p2 = pk_sel(str, sp2, p2); p1 = pk_sel(str, sp1, p1); p0 = pk_sel(str, sp0, p0);
                             q0 = pk_sel(str, sq0, q0); q1 = pk_sel(str, sq1, q1); q2 = pk_sel(str, sq2, q2);
@@ -494,9 +504,8 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         const int b = (E.nib(1, ed) >> (4 * cseg)) & 15, k = edge_class(1, ed) + 3;
                         if (__ballot(b != 0) == 0) continue;
                         const EdgeParams ep(E, k);
-                        const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], pk_splat(ep.alpha()), pk_splat(ep.beta()));
-                        pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], f, as_pk((unsigned)(b - 1) < 3u ? 0xffffffffu : 0u),
-                                  as_pk(b == 4 ? 0xffffffffu : 0u), pk_splat(ep.tc((b - 1) & 3)));
+                        const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], as_pk(ep.alpha2()), as_pk(ep.beta2()));
+                        pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], f, as_pk(mask_bs123(b)), as_pk(mask_bs4(b)), __ballot(b == 4) != 0, as_pk(ep.tc2(b)));
                     }
                     *(uint16_t *)((uint8_t *)ring + 64 + cp * 16 + cr + 8) = (uint16_t)perm(as_u(d[1]), as_u(d[1]), 0x0c0c0200u);
                     *(uint16_t *)(ccol) = (uint16_t)perm(as_u(d[2]), as_u(d[2]), 0x0c0c0200u);

@@ -427,12 +427,13 @@ struct GWin {
 // `bias` = 4096 + rounding term.
 __device__ __forceinline__ void tap_h4(uint32_t n0, uint32_t n1, uint32_t n2, int bias, int t[4])
 {
-    const int C0 = 0x1414fb01, C1 = 0x000001fb;            // (1,-5,20,20) and (-5,1,0,0) as int8
+    // Sample i needs bytes i..i+5.  Instead of shifting the window to each sample (two v_alignbyte per sample) the TAPS are
+    // shifted: every sample is a sum of dot products of the same aligned dwords with its own constant vectors.
     n0 ^= 0x80808080u; n1 ^= 0x80808080u; n2 ^= 0x80808080u;
-    t[0] = __builtin_amdgcn_sdot4((int)n0, C0, __builtin_amdgcn_sdot4((int)n1, C1, bias, false), false);
-    t[1] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 1), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 1), C1, bias, false), false);
-    t[2] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 2), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 2), C1, bias, false), false);
-    t[3] = __builtin_amdgcn_sdot4((int)alignbyte(n1, n0, 3), C0, __builtin_amdgcn_sdot4((int)alignbyte(n2, n1, 3), C1, bias, false), false);
+    t[0] = __builtin_amdgcn_sdot4((int)n0, 0x1414fb01, __builtin_amdgcn_sdot4((int)n1, 0x000001fb, bias, false), false);   // (1,-5,20,20 | -5,1,0,0)
+    t[1] = __builtin_amdgcn_sdot4((int)n0, 0x14fb0100, __builtin_amdgcn_sdot4((int)n1, 0x0001fb14, bias, false), false);   // (0,1,-5,20 | 20,-5,1,0)
+    t[2] = __builtin_amdgcn_sdot4((int)n0, (int)0xfb010000u, __builtin_amdgcn_sdot4((int)n1, 0x01fb1414, bias, false), false);   // (0,0,1,-5 | 20,20,-5,1)
+    t[3] = __builtin_amdgcn_sdot4((int)n0, 0x01000000, __builtin_amdgcn_sdot4((int)n1, (int)0xfb1414fbu, __builtin_amdgcn_sdot4((int)n2, 0x00000001, bias, false), false), false);   // (0,0,0,1 | -5,20,20,-5 | 1,0,0,0)
 }
 // (t >> sh) clipped to a byte, four at once: gfx950's v_ashr_pk_u8_i32 shifts, saturates and packs two values per
 // instruction (result bits 16..31 are not defined: only its low two bytes are used)

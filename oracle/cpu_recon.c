@@ -14,7 +14,9 @@
  * [0] HV (centre) half-pel samples evaluated, [1] of those outside [-80,335] - the domain of the
  * reference's clip LUT (core/clip1.h:36-70), beyond which the reference reads past its table
  * (undefined; we clamp like the standard), [2] luma edge lines with bS>0, [3] of those modified,
- * [4] chroma edge lines with bS>0, [5] of those modified. */
+ * [4] chroma edge lines with bS>0, [5] of those modified, [6] macroblock edges with bS>0 whose two macroblocks have
+ * different QPs (the filter parameters come from the mean), [7] dequantised luma/chroma AC coefficients whose int16 store
+ * wrapped (A-Q8). */
 static long long g_stats[8];
 void oracle_stats_reset(void) { memset(g_stats, 0, sizeof g_stats); }
 void oracle_stats_get(long long out[8]) { memcpy(out, g_stats, sizeof g_stats); }
@@ -59,6 +61,7 @@ void oracle_dequant4x4(int16_t d[16], int qp)
     int qbits = qp / 6 - 4;
     for (int i = 0; i < 16; i++) {
         int v = d[i] * dq_mf(qp, i);
+        if (qbits >= 0 && (long long)v * (1 << qbits) != (int16_t)((unsigned)v << qbits)) g_stats[7]++;   /* the int16 store wraps (A-Q8) */
         if (qbits >= 0) d[i] = (int16_t)((unsigned)v << qbits);
         else            d[i] = (int16_t)((v + (1 << (-qbits - 1))) >> (-qbits));
     }
@@ -621,6 +624,7 @@ int oracle_deblock_picture(const p264hip_picture_t *pic, uint8_t **planes)
                         }
                     }
                     int qp = m->qp, qpn = n->qp;
+                    if (qp != qpn && (bS[0] | bS[1] | bS[2] | bS[3])) g_stats[6]++;   /* an edge filtered with the mean of two QPs */
                     uint8_t *py = dir == 0 ? Y + mby*16*w + mbx*16 + 4*e : Y + (mby*16 + 4*e)*w + mbx*16;
                     edge(pic, py, w, dir, bS, (qp + qpn + 1) >> 1, 0);       /* :593-595, :615-617 */
                     if (!(e & 1)) {                                          /* :597-608, :620-630 */

@@ -3,6 +3,7 @@ p264hip_submit against the CPU oracle, byte for byte.  Covers what no decodable 
 every partition shape down to 4x4 at every quarter-pel phase, a QP per macroblock, levels up to the int16 limits (storage
 wrap, A-Q8), three reference frames with an index per quadrant, slice-shaped availability / edge patterns, deblocking
 offsets over their whole range.  The coverage assertions check that the drawn pictures really contain those cases."""
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -48,6 +49,7 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
             dst[:] = src
         hip.write_frame(0, s, *f)
     seen = dict(sub4x4=0, qp_edges=0, wrap=0, phases=set(), multi_ref=0, types=set(), avail=set(), intra4_modes=set())
+    oracle.oracle_stats_reset()
     for i in range(n_pics):
         pic = seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=(i != 2), dst_slot=i % slots, **kw)
         want = oracle_bind.reconstruct(oracle, store, pic)
@@ -78,6 +80,14 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
         i4 = pic.i4modes.reshape(n, 16)[rec["mb_type"] == N.MB_I4x4]
         seen["intra4_modes"] |= set(i4.reshape(-1).tolist())
     hip.close()
+    # what the arithmetic really went through, counted by the oracle on the same inputs (oracle/cpu_recon.c, g_stats)
+    st = (C.c_longlong * 8)()
+    oracle.oracle_stats_get(st)
+    assert st[2] > 0 and st[3] > 0 and st[4] > 0 and st[5] > 0, "the loop filter changed nothing: %s" % list(st)
+    if kw["qp_mode"] in ("random", "two") and mb_w * mb_h >= 9:
+        assert st[6] > 0, "no edge was filtered with the mean of two different QPs"
+    if kw["level_style"] in ("wrap", "mixed"):
+        assert st[7] > 0, "no dequantised coefficient wrapped its int16 store (A-Q8)"
     assert {N.MB_I4x4, N.MB_I16x16, N.MB_P_L0, N.MB_P_8x8, N.MB_P_SKIP} <= seen["types"]
     if kw.get("sub8x8", True) and mb_w * mb_h >= 30:
         assert seen["sub4x4"] > 0, "no quadrant with three or more different vectors was drawn"

@@ -38,3 +38,28 @@ def test_builder_is_deterministic_and_wellformed(oracle):
             assert np.array_equal(p, q)
     c = run(oracle, 6)
     assert any(not np.array_equal(p, q) for x, y in zip(a, c) for p, q in zip(x, y))
+
+
+def test_fuzz_configurations_reach_the_paths_they_are_meant_for(oracle):
+    """The oracle's coverage counters over the GPU test's configurations (tests/test_gpu_seam_fuzz.py asserts the same
+    behind the comparison with the HIP kernels): the loop filter changes samples, edges between macroblocks of different QP
+    get filtered, dequantised coefficients wrap their int16 store where the configuration asks for it."""
+    import ctypes as C
+    from tests.test_gpu_seam_fuzz import CONFIGS
+    for name, mb_w, mb_h, n_pics, kw in CONFIGS:
+        rng = np.random.default_rng(sum(map(ord, name)) * 7919)
+        slots = kw["slots"]
+        store = oracle_bind.FrameStore(mb_w, mb_h, slots)
+        for s in range(slots):
+            for dst, src in zip(store[s], seam_fuzz.random_frame(rng, mb_w, mb_h, "smooth" if name == "two_qps_smooth" else "noise")):
+                dst[:] = src
+        oracle.oracle_stats_reset()
+        for i in range(n_pics):
+            oracle_bind.reconstruct(oracle, store, seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=(i != 2), dst_slot=i % slots, **kw))
+        st = (C.c_longlong * 8)()
+        oracle.oracle_stats_get(st)
+        assert st[2] > 0 and st[3] > 0 and st[4] > 0 and st[5] > 0, (name, list(st))
+        if kw["qp_mode"] in ("random", "two") and mb_w * mb_h >= 9:
+            assert st[6] > 0, (name, list(st))
+        if kw["level_style"] in ("wrap", "mixed"):
+            assert st[7] > 0, (name, list(st))

@@ -6,8 +6,11 @@
 // p264_mb_dequant_4x4_dc (core/dct.c:104-136, core/quant.c:161-191) and add16x16_idct.
 //
 // Intra prediction reads the UNFILTERED reconstruction of the left / top / top-left / top-right
-// neighbours, so macroblocks form a 2-MB-lag wavefront over the picture (wavefront_sync.h): one
-// workgroup per picture, one wavefront per macroblock row.  In P pictures the inter MBs were
+// neighbours, so macroblocks form a 2-MB-lag wavefront over the picture (wavefront_sync.h): per
+// picture one workgroup for luma and one for chroma (independent chains: the kernel is bound by the
+// latency of the macroblock-to-macroblock chain per wavefront, so two shorter chains side by side
+// and the registers of only one of them - 70 instead of 92, seven wavefronts per SIMD - beat one
+// long one), one wavefront per macroblock row.  In P pictures the inter MBs were
 // already written by k_mc_luma / k_mc_chroma, so only the sparse intra MBs are visited.  Missing neighbours are
 // substituted in registers (128 / replicated t3) instead of being written into the frame as the
 // reference does (decoder/macroblock.c:697-713, SURVEY A-Q7).
@@ -62,6 +65,8 @@ __device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, in
 // Reconstruct one intra macroblock with one wavefront.  Every global load the macroblock needs (neighbour samples,
 // prediction modes, coefficients of all three planes) is issued at the top, before anything waits: one memory round
 // trip per macroblock, everything after that runs out of registers and LDS.
+// LUMA / CHROMA: which planes this wavefront reconstructs (k_intra runs the two as separate workgroups of a picture)
+template <bool LUMA, bool CHROMA>
 __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, const p264hip_mb_t m, int lane, RowSync &sync, int row_publish_as)
 {
 #if INTRA_NO_HOIST
@@ -86,19 +91,20 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     uint8_t *const lds8 = (uint8_t *)&L;                   // byte offsets, so that the stores stay LDS stores
     const int c_base = (int)offsetof(IntraLds, c), c_size = (int)sizeof(L.c[0]);
     int dstA = 0, dstB = 0;
-    if (lane < 21) {
+    if (!LUMA && lane < 37) {
+    } else if (lane < 21) {
         int x = lane - 1;
         okA = x < 0 ? aTL : x < 16 ? aT : aTR;
         offA = luma_off(g, X0 + x, Y0 - 1); dstA = 3 + lane;
     } else if (lane < 37) {
         int r = lane - 21;
         okA = aL; offA = luma_off(g, X0 - 1, Y0 + r); dstA = (r + 1) * IT_STRIDE + 3;
-    } else if (lane < 55) {
+    } else if (CHROMA && lane < 55) {
         int p = (lane - 37) / 9, x = (lane - 37) % 9 - 1;
         okA = x < 0 ? aTL : aT;
         offA = chroma_off(g, p, X0 / 2 + x, Y0 / 2 - 1); dstA = c_base + p * c_size + 3 + x + 1;
     }
-    if (lane < 16) {
+    if (CHROMA && lane < 16) {
         int p = lane >> 3, r = lane & 7;
         okB = aL; offB = chroma_off(g, p, X0 / 2 - 1, Y0 / 2 + r); dstB = c_base + p * c_size + (r + 1) * CT_STRIDE + 3;
     }
@@ -108,14 +114,14 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     // ---- (b) luma levels: lane = (block lane>>2 in decode order, levels 4*(lane&3) .. +3 of its 16 slots) ----
     const int lb = lane >> 2;
     uint2 lv = make_uint2(0, 0);
-    if ((mask >> lb) & 1) lv = gload2(cf + coef_slot(mask, lb) * 16 + (lane & 3) * 4);
+    if (LUMA && ((mask >> lb) & 1)) lv = gload2(cf + coef_slot(mask, lb) * 16 + (lane & 3) * 4);
     int ldc = 0;                                           // Intra16x16 DC levels, lanes 0..15
-    if (is16 && (mask & P264_COEF_LUMA_DC) && lane < 16) ldc = cf[lane];
+    if (LUMA && is16 && (mask & P264_COEF_LUMA_DC) && lane < 16) ldc = cf[lane];
     // ---- (c) Intra4x4 prediction modes, lanes 0..15 ----
     int modebyte = 0;
-    if (!is16) modebyte = glob(pd->i4modes)[mbi * 16 + (lane & 15)];
+    if (LUMA && !is16) modebyte = glob(pd->i4modes)[mbi * 16 + (lane & 15)];
     // ---- (d) chroma: AC level k-1 of block j = lane>>4 of each plane (k = lane&15), DC levels in lanes 0..7 ----
-    const bool has_chroma = (m.cbp >> 4) != 0;
+    const bool has_chroma = CHROMA && (m.cbp >> 4) != 0;
     int cac[2] = { 0, 0 }, cdcv = 0;
     if (has_chroma) {
         const int j = lane >> 4, k = lane & 15;
@@ -131,13 +137,14 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     // the wave has to wait for its loads anyway, keeps the store latency off the macroblock-to-macroblock path.
     row_publish(sync, mby, row_publish_as);
     // ---- land the neighbours ----
-    if (lane < 55) lds8[dstA] = (uint8_t)vA;
-    if (lane < 16) lds8[dstB] = (uint8_t)vB;
+    if (LUMA ? lane < (CHROMA ? 55 : 37) : (lane >= 37 && lane < 55)) lds8[dstA] = (uint8_t)vA;
+    if (CHROMA && lane < 16) lds8[dstB] = (uint8_t)vB;
     wave_lds_fence();
-    if (!aTR && lane < 4) L.y[20 + lane] = L.y[19];         // top-right of the MB missing: replicate t15 (:706-709)
+    if (LUMA && !aTR && lane < 4) L.y[20 + lane] = L.y[19];  // top-right of the MB missing: replicate t15 (:706-709)
     wave_lds_fence();
 
-    if (is16) {
+    if (!LUMA) {
+    } else if (is16) {
         // ---- prediction: each lane 4 samples of one row ----
         int mode = m.intra_modes & 3;
         if (mode == 2) mode = aTL ? 2 : aL ? 4 : aT ? 5 : 6;                    // :635-667
@@ -264,7 +271,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
     }
 
     // ---- chroma prediction (core/predict.c:199-361), one sample per lane and plane ----
-    {
+    if (CHROMA) {
         int mode = (m.intra_modes >> 4) & 3;
         if (mode == 0) mode = aTL ? 0 : aL ? 4 : aT ? 5 : 6;                     // :721-753
         const int px = lane & 7, py = lane >> 3;
@@ -322,8 +329,8 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         int row = lane >> 2, d = lane & 3;
         // lane (row, d) owns dword `lane` of the macroblock's 256 contiguous luma bytes, lane (p, r, dd) a dword of its
         // 128 chroma bytes (rows of 8 bytes U + 8 bytes V)
-        gstore1(F + mb_luma_off(g, mbx, mby) + lane * 4, *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4));
-        if (lane < 32) {
+        if (LUMA) gstore1(F + mb_luma_off(g, mbx, mby) + lane * 4, *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4));
+        if (CHROMA && lane < 32) {
             int p = lane >> 4, r = (lane >> 1) & 7, dd = lane & 1;
             gstore1(F + mb_chroma_off(g, mbx, mby) + r * 16 + p * 8 + dd * 4, *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4));
         }
@@ -342,6 +349,7 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
     __shared__ RowSync sync;
     __shared__ IntraLds lds[INTRA_ROW_WAVES];
     const PicDev *pd = pics + blockIdx.x;
+    const bool chroma_role = blockIdx.y != 0;               // grid.y = 2: luma and chroma of a picture in separate workgroups
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     rows_init(sync, g.mb_h);
     bool ok = true;
@@ -373,7 +381,8 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                 if (((deps >> bit) & 1) && ok) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
                 const uint4 mr = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)rec.x, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.y, bit),
                                             (uint32_t)__builtin_amdgcn_readlane((int)rec.z, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.w, bit));
-                intra_mb(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane, sync, mbx);
+                if (chroma_role)       intra_mb<false, true>(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane, sync, mbx);
+                else                   intra_mb<true, false>(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane, sync, mbx);
             }
         }
         row_publish(sync, row, g.mb_w);

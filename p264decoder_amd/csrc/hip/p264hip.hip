@@ -409,7 +409,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // four pictures share a CU (the kernel is dependency/latency bound: measured +19 % at 512 and +9 % at 1024 pictures)
         int intra_waves = n > 2 * c->n_cu ? INTRA_ROW_WAVES / 4 : n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
         if (const char *e = getenv("P264AMD_INTRA_WAVES")) { int v = atoi(e); if (v >= 1 && v <= INTRA_ROW_WAVES) intra_waves = v; }
-        hipLaunchKernelGGL(k_intra, dim3(n), dim3(intra_waves * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
+        // luma and chroma of a picture are independent chains: as two workgroups they run side by side (the kernel is bound by
+        // the latency of the macroblock-to-macroblock chain, not by arithmetic)
+        hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
     }
     {
         ScopedStamp t(c, 2);

@@ -302,18 +302,6 @@ __device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
-#ifndef MCX_NOSTORE
-#define MCX_NOSTORE 0
-#endif
-#ifndef MCX_NOLOAD
-#define MCX_NOLOAD 0
-#endif
-#ifndef MCX_CLASS
-#define MCX_CLASS (-1)
-#endif
-#ifndef MCX_NOCOMPUTE
-#define MCX_NOCOMPUTE 0
-#endif
 #ifndef MC_LUMA_STORE16
 #define MC_LUMA_STORE16 1
 #endif
@@ -371,7 +359,7 @@ __device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t rof
         dst[j] = row * I::PITCH + s * 16;
         on[j] = !MB || s < 2 || third;
         v[j] = u32x4{ 0, 0, 0, 0 };
-        if (on[j] && !MCX_NOLOAD) {
+        if (on[j]) {
             if (!CLAMP) v[j] = bload4(rs, roff + strip_mul(sA + s, g.ystrip) + (uint32_t)((wy + row) * 16));
             else {
                 const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
@@ -747,7 +735,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         }
         wave_lds_fence();
         const LWin<I::PITCH> w = { img, (wx >> 4) * 16, wy };
-        mc_luma_class(MCX_NOCOMPUTE ? PC_COPY : MCX_CLASS >= 0 ? MCX_CLASS : pc, out, w, ix, iy, fx, fy);
+        mc_luma_class(pc, out, w, ix, iy, fx, fy);
     } else {
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
         // straight from memory, one pass per phase class present among the lanes.
@@ -787,7 +775,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         // whole 16-byte row and the macroblock's sixteen lanes two whole cache lines
         uint32_t t[4];
         quad_transpose(t, out, lane);
-        if (valid && (!MCX_NOSTORE || t[0] == 0x12345678u)) bstore4(rs, pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + bx) * 16), t[0], t[1], t[2], t[3]);
+        if (valid) bstore4(rs, pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + bx) * 16), t[0], t[1], t[2], t[3]);
     } else {
         const bool right = bx & 1;
         const uint32_t g0 = lane_xor1(right ? out[0] : out[2]), g1 = lane_xor1(right ? out[1] : out[3]);

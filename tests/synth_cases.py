@@ -47,9 +47,12 @@ CASES = {
     "dboffs_neg": ("--mbw 11 --mbh 9 --frames 10 --gop 5 --seed 54 --qp 34 --deblock-offsets -6 -4 --coded 20 --maxlevel 6", None),
     "qpd_dbo": ("--mbw 12 --mbh 7 --frames 10 --gop 5 --seed 55 --qp 30 --qp-delta 8 --deblock-offsets 3 -2 --cqo 4 --coded 25 --maxlevel 5", None),
     "qpd_1080p": ("--mbw 120 --mbh 68 --frames 4 --gop 0 --seed 56 --qp 27 --qp-delta 5 --deblock-offsets 2 1 --coded 12 --maxlevel 8 --crop-bottom 4", 2),
+    # larger than 8192 macroblocks: the work-list sort classifies twice instead of keeping its macroblocks in registers, nine
+    # bands of work lists, 17 deblocking bands of eight rows for a single picture
+    "uhd_2160p_allp": ("--mbw 240 --mbh 135 --frames 3 --gop 0 --seed 61 --qp 29 --qp-delta 3 --coded 12 --maxlevel 10", 2),
     "mv_far": ("--mbw 10 --mbh 8 --frames 10 --gop 10 --seed 28 --mvmax 64 --coded 5 --maxlevel 6", None),
 }
-BIG = ("cfg2_720p_intra", "cfg3_1080p_ip", "cfg3_1080p_allp", "qpd_1080p")
+BIG = ("cfg2_720p_intra", "cfg3_1080p_ip", "cfg3_1080p_allp", "qpd_1080p", "uhd_2160p_allp")
 
 
 def ensure_tool():

@@ -58,6 +58,30 @@ def test_per_macroblock_qp_1080p(lib, oracle):
     run_case(lib, oracle, "qpd_1080p")
 
 
+def test_2160p_all_p(lib, oracle):
+    """3840x2160: more macroblocks than the work-list sort keeps in registers (it classifies twice instead), nine bands of
+    work lists, 135 macroblock rows for the two row-wavefront kernels - against the oracle and the reference's hashes"""
+    run_case(lib, oracle, "uhd_2160p_allp")
+
+
+def test_2160p_batch_of_streams(lib):
+    """the same pictures as a batch of 5 streams in one call (two-picture deblocking workgroups at this size)"""
+    _, hashes = synth_cases.golden("uhd_2160p_allp")
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("uhd_2160p_allp"))
+    S = 5
+    hip = HipReconstructor(pics[0].mb_w, pics[0].mb_h, n_streams=S, slots=parser.slots, max_pictures=S, lib=lib)
+    for i, p in enumerate(pics):
+        hip.upload(0, [p])
+        for s in range(1, S):
+            hip.clone_picture(s, 0)
+        hip.reconstruct(list(range(S)), list(range(S)))
+        hip.sync()
+        for s in range(S):
+            assert frame_sha256(*hip.read_frame(s, p.desc.dst_slot)) == hashes[i], "picture %d stream %d differs from the reference decoder" % (i, s)
+    hip.close()
+
+
 def test_bench_shape_batch_against_reference_hashes(lib):
     """The batch bench.py times: more pictures than 2 x compute units in ONE reconstruct call (that is what selects the
     small-band workgroup shapes of the row-wavefront kernels: 4 intra wavefronts, 4 pictures per deblocking workgroup),

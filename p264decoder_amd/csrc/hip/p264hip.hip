@@ -104,7 +104,8 @@ static uint8_t *frame_ptr(p264hip_ctx *c, int stream, int slot)
 
 extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h, int n_streams, int slots, int max_pictures)
 {
-    if (!out || mb_w < 1 || mb_h < 1 || mb_h > MAX_MB_ROWS || n_streams < 1 || slots < 1 || slots > P264HIP_MAX_REFS + 1 || max_pictures < 1)
+    if (!out || mb_w < 1 || mb_w > 2047 || mb_h < 1 || mb_h > MAX_MB_ROWS ||    /* (11 bits of macroblock column in a work-list entry) */
+        n_streams < 1 || slots < 1 || slots > P264HIP_MAX_REFS + 1 || max_pictures < 1)
         return fail(P264HIP_EINVAL, "p264hip_create: bad argument (mb %dx%d, streams %d, slots %d, pictures %d)", mb_w, mb_h, n_streams, slots, max_pictures);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)

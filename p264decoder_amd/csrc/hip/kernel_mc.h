@@ -935,10 +935,12 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
             for (int j = 0; j < 3; j++) {
                 const int pp = min(li + 8 * j, 17), s = pp >= 9 ? 1 : 0, row = pp - 9 * s;
                 dst[j] = row * I::PITCH + s * 16;
-                v[j] = (key & MCC_CLAMP) ? chroma_piece<true>(rs, roff, g, sA + s, wy + row) : chroma_piece<false>(rs, roff, g, sA + s, wy + row);
+                v[j] = u32x4{ 0, 0, 0, 0 };
+                if (j < 2 || li < 2)                           // (pieces 16 and 17 only: the other lanes would fetch piece 17 again)
+                    v[j] = (key & MCC_CLAMP) ? chroma_piece<true>(rs, roff, g, sA + s, wy + row) : chroma_piece<false>(rs, roff, g, sA + s, wy + row);
             }
 #pragma unroll
-            for (int j = 0; j < 3; j++) lds_put16(img + dst[j], v[j]);
+            for (int j = 0; j < 3; j++) if (j < 2 || li < 2) lds_put16(img + dst[j], v[j]);
         } else {
             // Four lanes = two quadrants stage together: rows 0..3 of one strip of one quadrant per load (64 contiguous
             // bytes), then row 4 of their own strips.

@@ -411,7 +411,9 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     const pk16 en = as_pk(mask_bs123(b));
                     const pk16 op2 = p2, op1 = p1, op0 = p0, oq0 = q0, oq1 = q1, oq2 = q2;
                     pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
-                    if (__ballot(b == 4)) {
+                    // bS 4 exists on macroblock edges only (k_deblock_bs), and the strong filter changes nothing where the
+                    // sample flag is off
+                    if (ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
                         const pk16 str = as_pk(mask_bs4(b));
                         pk16 sp2 = op2, sp1 = op1, sp0 = op0, sq0 = oq0, sq1 = oq1, sq2 = oq2;
                         pk_luma_strong(pair_byte<0>(ya[ed], yb[ed]), sp2, sp1, sp0, sq0, sq1, sq2, pair_byte<3>(ya[ed+1], yb[ed+1]), f & str, ap, aq, A);
@@ -479,7 +481,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         const pk16 en = as_pk(mask_bs123(b));
                         pk16 sp2 = p2, sp1 = p1, sp0 = p0, sq0 = q0, sq1 = q1, sq2 = q2;
                         pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
-                        if (__ballot(b == 4)) {
+                        if (ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
                             const pk16 str = as_pk(mask_bs4(b));
                             pk_luma_strong(p3, sp2, sp1, sp0, sq0, sq1, sq2, q3, f & str, ap, aq, A);
                             p2 = pk_sel(str, sp2, p2); p1 = pk_sel(str, sp1, p1); p0 = pk_sel(str, sp0, p0);

@@ -170,7 +170,7 @@ def fanout_leg(rank, local_rank, world, lib):
     try:
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
         try:
-            out, err = p.communicate(timeout=240)
+            out, err = p.communicate(timeout=120)
         except subprocess.TimeoutExpired:
             p.kill()
             out, err = p.communicate()

@@ -1,7 +1,7 @@
 /* bits.h - MSB-first bit reader over an RBSP buffer, with Exp-Golomb helpers.
  *
  * Replaces core/bs.h:54-170 of the reference.  Built around a 64-bit window that is
- * refilled bytewise, so peeks of up to 32 bits are branch-light and reads past the end
+ * refilled four bytes at a time, so peeks of up to 32 bits are branch-light and reads past the end
  * return zeros (the reference's bs_read stops at p_end; its bs_show over-reads 3 bytes,
  * core/bs.h:119-126 - we pad instead).
  */
@@ -9,6 +9,7 @@
 #define P264_BITS_H
 #include <stdint.h>
 #include <stddef.h>
+#include <string.h>
 
 typedef struct {
     const uint8_t *buf;
@@ -21,6 +22,16 @@ typedef struct {
 
 static inline void br_refill(bitrd_t *b)
 {
+    /* keep at least 33 valid bits in the window (peeks take up to 32): four bytes at a time while the buffer lasts,
+     * bytewise (zero-padded) at its end */
+    if (b->avail > 32) return;
+    if (b->pos + 4 <= b->size) {
+        uint32_t v;
+        memcpy(&v, b->buf + b->pos, 4);
+        b->win |= (uint64_t)__builtin_bswap32(v) << (32 - b->avail);
+        b->pos += 4; b->avail += 32;
+        return;
+    }
     while (b->avail <= 56) {
         uint64_t byte = b->pos < b->size ? b->buf[b->pos] : 0;
         b->pos++;

@@ -346,8 +346,11 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(dom)
-                traffic_source = "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
+                if S == int(tj.get("pictures_per_launch", 1024)):              # (counted for the default batch: scaled to nothing else)
+                    traffic = tj.get(dom)
+                    traffic_source = "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
+                else:
+                    traffic_source = "none: profiles/%s was collected at %d pictures per launch, this run has %d" % (tj.get("source"), int(tj.get("pictures_per_launch", 1024)), S)
             except Exception:
                 traffic = None
         out = {

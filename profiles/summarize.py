@@ -44,6 +44,7 @@ def hbm(k):
     return int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
 traffic = {"inter": sum(hbm(k) for k in pmc if k.startswith("k_mc_")), "intra": hbm("k_intra"), "deblock": hbm("k_deblock") + hbm("k_deblock_bs"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
+traffic["pictures_per_launch"] = 1024          # bench.py's default batch, which collect.sh profiles
 json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(traffic))
 print(open(os.path.join(here, tag + "_kernel_stats.csv")).read())

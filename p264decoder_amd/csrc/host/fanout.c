@@ -8,6 +8,7 @@
 #include <errno.h>
 #include <time.h>
 #include <unistd.h>
+#include <pthread.h>
 #include <sys/socket.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -252,6 +253,31 @@ static const p264hip_picture_t *next_picture(fstream_t *s, int max_pictures, int
     return NULL;
 }
 
+/* the round's pictures are parsed side by side: the streams are independent, and the serial parse is what bounds the
+ * fan-out (a 1080p picture takes the parser longer than eight GPUs need to reconstruct one each) */
+typedef struct { fstream_t *st; const p264hip_picture_t **pics; int first, step, n_streams, max_pictures, failed; } parse_job_t;
+static void *parse_worker(void *arg)
+{
+    parse_job_t *j = (parse_job_t *)arg;
+    for (int s = j->first; s < j->n_streams; s += j->step) j->pics[s] = next_picture(&j->st[s], j->max_pictures, &j->failed);
+    return NULL;
+}
+static int parse_round(fstream_t *st, const p264hip_picture_t **pics, int n_streams, int max_pictures, int threads)
+{
+    if (threads > n_streams) threads = n_streams;
+    if (threads > 64) threads = 64;
+    parse_job_t jobs[64];
+    pthread_t tid[64];
+    int started = 0, failed = 0;
+    for (int t = 0; t < threads; t++) jobs[t] = (parse_job_t){ st, pics, t, threads, n_streams, max_pictures, 0 };
+    for (int t = 1; t < threads; t++) { if (pthread_create(&tid[t], NULL, parse_worker, &jobs[t])) break; started = t; }
+    for (int t = started + 1; t < threads; t++) parse_worker(&jobs[t]);     /* (threads that could not be started: done here) */
+    parse_worker(&jobs[0]);
+    for (int t = 1; t <= started; t++) pthread_join(tid[t], NULL);
+    for (int t = 0; t < threads; t++) failed |= jobs[t].failed;
+    return failed;
+}
+
 int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, const int64_t *sizes, int max_pictures,
                      p264fan_frame_cb on_frame, void *user, p264fan_stats_t *stats)
 {
@@ -271,18 +297,17 @@ int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, co
         if (!st[s].parser) rc = fail("p264parse_open failed");
     }
     p264fan_stats_t S; memset(&S, 0, sizeof S); S.world = W;
+    int parse_threads = 8;                                    /* P264AMD_FAN_THREADS: host threads parsing a round's pictures */
+    { const char *e = getenv("P264AMD_FAN_THREADS"); if (e && atoi(e) >= 1) parse_threads = atoi(e); }
     const double t0 = now_s();
     int mb_w = 0, mb_h = 0, slots = 0;
     while (!rc) {
         /* ---- parse: the next picture of every stream (the serial CPU part; its arrays live until the stream's next call) */
         const double p0 = now_s();
-        int n = 0, failed = 0;
+        int n = 0;
         const p264hip_picture_t **pics = (const p264hip_picture_t **)alloca(sizeof(void *) * (size_t)n_streams);
-        for (int s = 0; s < n_streams; s++) {
-            pics[s] = next_picture(&st[s], max_pictures, &failed);
-            has[s] = pics[s] != NULL;
-            n += has[s];
-        }
+        const int failed = parse_round(st, pics, n_streams, max_pictures, parse_threads);
+        for (int s = 0; s < n_streams; s++) { has[s] = pics[s] != NULL; n += has[s]; }
         S.parse_seconds += now_s() - p0;
         if (failed) { rc = fail("a stream failed to parse"); break; }
         if (!n) break;

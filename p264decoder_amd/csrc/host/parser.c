@@ -85,6 +85,7 @@ struct p264parse {
     /* current MB */
     int mbx, mby, mbi;
     unsigned mv_done;                         /* bit (y*4+x): that 4x4 of the current MB has its MV */
+    int      cur_avail;                       /* P264_AVAIL_* of the current MB (set by begin_mb) */
     int skip_run;
 };
 
@@ -490,7 +491,7 @@ static int predict_nc(const p264parse *p, int blk)
 {
     const uint8_t *cur = p->nnz + (size_t)p->mbi * 24;
     int na = -1, nb = -1;
-    int left_ok = mb_avail(p, p->mbx - 1, p->mby), top_ok = mb_avail(p, p->mbx, p->mby - 1);
+    const int left_ok = p->cur_avail & P264_AVAIL_LEFT, top_ok = p->cur_avail & P264_AVAIL_TOP;    /* (begin_mb) */
     if (blk < 16) {
         int x = blk_x[blk], y = blk_y[blk];
         if (x > 0) na = cur[blk_of_xy[y][x-1]]; else if (left_ok) na = (cur - 24)[blk_of_xy[y][3]];
@@ -510,11 +511,11 @@ static int predict_i4mode(const p264parse *p, int blk)
     const picbuf_t *q = &p->buf[p->cur];
     int x = blk_x[blk], y = blk_y[blk], ma, mb;
     if (x > 0) ma = q->i4[p->mbi * 16 + blk_of_xy[y][x-1]];
-    else if (mb_avail(p, p->mbx - 1, p->mby))
+    else if (p->cur_avail & P264_AVAIL_LEFT)
         ma = q->mb[p->mbi - 1].mb_type == P264_MB_I4x4 ? q->i4[(p->mbi - 1) * 16 + blk_of_xy[y][3]] : 2;
     else ma = -1;
     if (y > 0) mb = q->i4[p->mbi * 16 + blk_of_xy[y-1][x]];
-    else if (mb_avail(p, p->mbx, p->mby - 1))
+    else if (p->cur_avail & P264_AVAIL_TOP)
         mb = q->mb[p->mbi - p->mb_w].mb_type == P264_MB_I4x4 ? q->i4[(p->mbi - p->mb_w) * 16 + blk_of_xy[3][x]] : 2;
     else mb = -1;
     int m = ma < mb ? ma : mb;
@@ -586,7 +587,7 @@ static int store_coefs(p264parse *p, p264hip_mb_t *m, const mbcoef_t *cf)
     int16_t *dst = q->coef + q->coef_n * 16;
     if (cf->mask & P264_COEF_LUMA_DC)   { memcpy(dst, cf->dc_luma, 32); dst += 16; }
     if (cf->mask & P264_COEF_CHROMA_DC) { memcpy(dst, cf->dc_chroma, 32); dst += 16; }
-    for (int i = 0; i < 24; i++) if (cf->mask & (1u << i)) { memcpy(dst, cf->blk[i], 32); dst += 16; }
+    for (uint32_t left = cf->mask & 0xffffffu; left; left &= left - 1) { memcpy(dst, cf->blk[__builtin_ctz(left)], 32); dst += 16; }
     q->coef_n = (size_t)(dst - q->coef) / 16;
     return 0;
 }
@@ -601,6 +602,7 @@ static void begin_mb(p264parse *p, p264hip_mb_t *m)
     if (mb_avail(p, p->mbx + 1, p->mby - 1)) a |= P264_AVAIL_TOPRIGHT;
     if (mb_avail(p, p->mbx - 1, p->mby - 1)) a |= P264_AVAIL_TOPLEFT;
     m->avail = (uint8_t)a;
+    p->cur_avail = a;
     int e = 0;
     if (p->sh.disable_deblock != 1) {
         e = P264_EDGE_INNER;

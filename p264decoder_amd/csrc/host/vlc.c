@@ -109,7 +109,11 @@ int cavlc_read_block(bitrd_t *b, int nC, int max_coeff, int16_t *out)
         if (v == 3) { tc = 0; t1 = 0; }
         else { tc = (v >> 2) + 1; t1 = v & 3; if (t1 > tc) return -1; }
     } else {
-        int s = vlc_get(b, &g_ct[nC < 2 ? 0 : nC < 4 ? 1 : 2]);
+        /* the empty block first: its code is all ones, 1 / 2 / 4 bits long in the three tables (H.264 table 9-5), and it
+         * is what most calls find */
+        const int t = nC < 2 ? 0 : nC < 4 ? 1 : 2, n1 = t == 0 ? 1 : t == 1 ? 2 : 4;
+        if (br_peek(b, n1) == (1u << n1) - 1u) { br_skip(b, n1); return 0; }
+        int s = vlc_get(b, &g_ct[t]);
         if (s < 0) return -1;
         tc = s & 31; t1 = s >> 5;
     }

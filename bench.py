@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 MB_W, MB_H = 120, 68
 N_MB = MB_W * MB_H
 DISTINCT = 4                   # distinct synthetic streams per rank; the S streams cycle through private copies of them
-STAGE_KERNELS = {"inter": "k_mc_sort + k_mc_luma_mb + k_mc_luma_quad + k_mc_chroma_mb + k_mc_chroma_quad", "intra": "k_intra",
+STAGE_KERNELS = {"inter": "k_mc_sort + k_mc", "intra": "k_intra",
                  "deblock": "k_deblock_bs + k_deblock"}
 
 
@@ -46,22 +46,26 @@ def synth_args(frames, seed):
 
 
 def algorithmic_bytes(pics):
-    """Bytes that must cross HBM once per launch, per kernel (DESIGN.md 'Roofline')."""
+    """Bytes that must cross HBM once per launch, per stage (DESIGN.md 'Roofline').  The MC figure is SURVEY 8d's
+    836 B per inter macroblock (384 B reference + 64 B motion + 4 B type read, 384 B written), its read part 452 B; the residual
+    input the MC kernels also consume (16 B record + 32 B per coded block, the seam's dense block format) is reported
+    separately as `inter_with_residual` and never enters `roofline.frac`."""
     import numpy as np
-    inter = intra = deblock = 0
+    inter = inter_read = inter_resid = intra = deblock = 0
     for p in pics:
         rec = p.mb_records()
         is_intra = rec["mb_type"] <= 2
         blocks = np.array([bin(int(m) & 0x3ffffff).count("1") for m in rec["coef_mask"]])
         n_inter = int((~is_intra).sum())
         n_intra = int(is_intra.sum())
-        # MC: 384 B reference samples + 64 B motion + 4 B type/ref, 384 B written; + 16 B MB record, 32 B per coded block
-        inter += n_inter * (836 + 16) + int(blocks[~is_intra].sum()) * 32
+        inter += n_inter * 836
+        inter_read += n_inter * 452
+        inter_resid += n_inter * (836 + 16) + int(blocks[~is_intra].sum()) * 32
         # intra: 384 B written + modes (16 B) + MB record (16 B) + coded blocks
         intra += n_intra * (384 + 32) + int(blocks[is_intra].sum()) * 32
         # deblock: 384 B read + 384 B written + side tables (16 B record, 64 B motion, 4 B refs)
         deblock += len(rec) * (768 + 84)
-    return {"inter": inter, "intra": intra, "deblock": deblock}
+    return {"inter": inter, "intra": intra, "deblock": deblock, "inter_read": inter_read, "inter_with_residual": inter_resid}
 
 
 def cpu_model():
@@ -196,6 +200,9 @@ def cpu_baseline(stream_path, n_pictures):
             out = subprocess.run([driver, "time", stream_path, str(loops)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                  text=True, timeout=600).stdout.split()
             return {"value": round(float(out[out.index("fps") + 1]), 3), "unit": "frames/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model(),
+                    "includes_parse": True,
+                    "note": "the reference cannot reconstruct without parsing: this rate includes its CAVLC parse (12-14 % of its time, SURVEY 6), "
+                            "`value` (inputs resident in HBM) does not - compare with extras.end_to_end_pipeline for parse-inclusive rates",
                     "sample": "%d-picture 1920x1088 all-P stream decoded %dx by the reference decoder (parse + reconstruction)" % (n_pictures, loops)}
         except Exception:
             pass
@@ -210,7 +217,7 @@ def cpu_baseline(stream_path, n_pictures):
         for p in pics:
             oracle_bind.reconstruct(ora, store, p)
             n += 1
-    return {"value": round(n / (time.time() - t0), 3), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+    return {"value": round(n / (time.time() - t0), 3), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(), "includes_parse": False,
             "sample": "%d 1920x1088 pictures through the scalar oracle (reconstruction only, parse excluded)" % n}
 
 
@@ -338,21 +345,41 @@ def main():
                 gbps = alg[name] / (avg * 1e-3) / 1e9
                 kernels[name] = {"kernels": STAGE_KERNELS[name], "avg_ms": round(avg, 4), "launches": int(cnt), "algorithmic_bytes": alg[name],
                                  "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4)}
+                if name == "inter":                       # the read-only fraction (452 B/MB) and, separately, the figure with the residual input
+                    kernels[name]["bytes_per_inter_mb"] = 836
+                    kernels[name]["frac_read"] = round(alg["inter_read"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    kernels[name]["algorithmic_bytes_with_residual"] = alg["inter_with_residual"]
+                    kernels[name]["frac_with_residual"] = round(alg["inter_with_residual"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        # HBM traffic cannot be counted inside this run (PMC counters need rocprofv3 passes of their own): it is replayed from
-        # the committed summary of the same command profiled on the same code (profiles/collect.sh), and says so
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+
+        def traffic_of(stage):
+            """HBM traffic cannot be counted inside this run (PMC counters need rocprofv3 passes of their own): it is replayed
+            from the committed summary of the same command profiled on the same code (profiles/collect.sh), and says so."""
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if not os.path.exists(tpath):
+                return None, None
             try:
                 tj = json.load(open(tpath))
                 if S == int(tj.get("pictures_per_launch", 1024)):              # (counted for the default batch: scaled to nothing else)
-                    traffic = tj.get(dom)
-                    traffic_source = "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
-                else:
-                    traffic_source = "none: profiles/%s was collected at %d pictures per launch, this run has %d" % (tj.get("source"), int(tj.get("pictures_per_launch", 1024)), S)
+                    return tj.get(stage), "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
+                return None, "none: profiles/%s was collected at %d pictures per launch, this run has %d" % (tj.get("source"), int(tj.get("pictures_per_launch", 1024)), S)
             except Exception:
-                traffic = None
+                return None, None
+
+        def roofline_of(stage):
+            traffic, traffic_source = traffic_of(stage)
+            r = {"kernel": STAGE_KERNELS[stage], "stage": stage, "bound": "hbm", "achieved": kernels[stage]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(kernels[stage]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_source,
+                 "algorithmic_bytes_per_launch": kernels[stage]["algorithmic_bytes"], "avg_ms": kernels[stage]["avg_ms"], "measured_copy_GBps": copy_gbps}
+            if traffic:
+                r["traffic_over_algorithmic"] = round(traffic / kernels[stage]["algorithmic_bytes"], 3)
+            if stage == "inter":
+                r["bytes_per_inter_mb"] = 836
+                r["frac_read"] = kernels[stage]["frac_read"]
+                r["frac_with_residual"] = kernels[stage]["frac_with_residual"]
+                if traffic:
+                    r["traffic_over_algorithmic_with_residual"] = round(traffic / kernels[stage]["algorithmic_bytes_with_residual"], 3)
+            return r
         out = {
             "metric": "1080p decoded frames/sec", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -361,10 +388,10 @@ def main():
                                    "reconstruction hot path (MC + residual, intra, deblock), parsed inputs resident in HBM",
                        "streams_per_gpu": S, "pictures_per_step": S * world, "mb_per_picture": N_MB, "parallelism": "stream-parallel x%d" % world},
             "macroblocks_per_s": round(fps * N_MB, 0),
-            "roofline": {"kernel": STAGE_KERNELS[dom], "stage": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
-                         "measured_copy_GBps": copy_gbps},
+            # `roofline` = the stage that takes longest (the contract's "dominant kernel"); `roofline_mc` = the motion-compensation
+            # stage, which the north star names, whichever is longer
+            "roofline": roofline_of(dom),
+            "roofline_mc": roofline_of("inter") if "inter" in kernels else None,
             "kernels": kernels,
             "reconstruct_call_ms": round(timing["reconstruct"][0] / max(timing["reconstruct"][1], 1), 4),
             "golden_check": golden_check,

@@ -21,18 +21,6 @@
 // 16-bit arithmetic without branches, and a wavefront walks eight macroblock rows as a diagonal.
 #pragma once
 #include "device_common.h"
-#ifndef EXPD_NOFILTER
-#define EXPD_NOFILTER 0
-#endif
-#ifndef EXPD_NOSTORE
-#define EXPD_NOSTORE 0
-#endif
-#ifndef EXPD_NOLOAD
-#define EXPD_NOLOAD 0
-#endif
-#ifndef EXPD_NOWAIT
-#define EXPD_NOWAIT 0
-#endif
 #include "wavefront_sync.h"
 #ifndef DEBLOCK_WAIT_SLEEP
 #define DEBLOCK_WAIT_SLEEP 16
@@ -337,7 +325,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         auto prefetch = [&](int t) {
             const int x = t - 2 * gr;
             const bool actn = have_row && x >= 0 && x < g.mb_w;
-            if (!EXPD_NOWAIT && ok) {
+            if (ok) {
                 // macroblock x needs the band above to have stored x completely
                 const bool need = from_above && actn;
                 const int want = x + 1;
@@ -384,7 +372,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             if (publisher) __hip_atomic_store(my_progress, min(max(x - 1, 0), g.mb_w), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             wave_lds_fence();
             // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
-            if (flush && top_exists && !EXPD_NOSTORE) {
+            if (flush && top_exists) {
                 const uint32_t *pr = L.ring[(x - 1) & 3];
                 if (j < 4) gstore4(topP + (x - 1) * sT, *(const uint4 *)(pr + j * 4));
                 else gstore2(topP + (x - 1) * sT, *(const uint2 *)(pr + 16 + (j - 4) * 2));
@@ -396,7 +384,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             }
             const bool any_edges = __ballot((E.e[0] | E.e[1] | E.e[2] | E.e[3]) != 0) != 0;
 
-            if (!EXPD_NOFILTER && any_edges) {
+            if (any_edges) {
                 // ---------- vertical edges, in registers ----------
 #pragma unroll
                 for (int ed = 0; ed < 4; ed++) {
@@ -446,9 +434,9 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 sa.w = ya[0]; sb.w = yb[0]; ta.y = ca[0]; tb.y = cb[0];
                 uint32_t *nr = Lnext.ring[(x - 1) & 3];
                 if (below_in_band && j >= 6) { *(uint4 *)(nr + (2 * j - 12) * 4) = sa; *(uint4 *)(nr + (2 * j - 11) * 4) = sb; }
-                else if (!EXPD_NOSTORE) { gstore4(ownY + (x - 1) * sY, sa); gstore4(ownY + (x - 1) * sY + 16, sb); }
+                else { gstore4(ownY + (x - 1) * sY, sa); gstore4(ownY + (x - 1) * sY + 16, sb); }
                 if (below_in_band && (j & 3) == 3) { *(uint2 *)(nr + 16 + cp * 4) = ta; *(uint2 *)(nr + 16 + cp * 4 + 2) = tb; }
-                else if (!EXPD_NOSTORE) { gstore2(ownC + (x - 1) * sC, ta); gstore2(ownC + (x - 1) * sC + 16, tb); }
+                else { gstore2(ownC + (x - 1) * sC, ta); gstore2(ownC + (x - 1) * sC + 16, tb); }
             }
             wave_lds_fence();
             // ---------- rows of macroblock x -> tile ----------
@@ -460,7 +448,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             if (t + 1 < n_iter) prefetch(t + 1);                      // the next iteration's loads travel during the horizontal pass
             // ---------- horizontal edges: column pairs out of the tile, filtered, back into the tile ----------
             const bool h_edges = __ballot((E.e[2] | E.e[3]) != 0) != 0;
-            if (!EXPD_NOFILTER && h_edges) {
+            if (h_edges) {
                 if (act) {
                     // luma: columns 2j, 2j+1
                     const uint8_t *top = (const uint8_t *)ring + 2 * j, *col = tile8 + 2 * j;

@@ -19,12 +19,6 @@
 #include "device_common.h"
 #include "wavefront_sync.h"
 
-#ifndef INTRA_NO_HOIST
-#define INTRA_NO_HOIST 1
-#endif
-#ifndef I4_UNROLL
-#define I4_UNROLL 16
-#endif
 #define IT_STRIDE 24               // luma tile: row -1..15, byte 3 = left column, 4..19 = MB, 20..23 = top-right
 #define CT_STRIDE 12               // chroma tile: byte 3 = left column, 4..11 = MB
 
@@ -69,12 +63,10 @@ __device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, in
 template <bool LUMA, bool CHROMA>
 __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, const p264hip_mb_t m, int lane, RowSync &sync, int row_publish_as)
 {
-#if INTRA_NO_HOIST
     // Everything below that depends on the lane number alone (roles, tile offsets, scan positions) would otherwise be
     // hoisted out of the caller's macroblock loop and kept - or spilled - across it: recomputing it per macroblock is a few
     // dozen instructions, holding it is ~50 registers.
     asm volatile("" : "+v"(lane));
-#endif
     const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w, X0 = mbx * 16, Y0 = mby * 16;
     const bool aL = m.avail & P264_AVAIL_LEFT, aT = m.avail & P264_AVAIL_TOP;
     const bool aTR = m.avail & P264_AVAIL_TOPRIGHT, aTL = m.avail & P264_AVAIL_TOPLEFT;
@@ -239,7 +231,7 @@ __device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, 
         const unsigned left_m = 0xFAFAu | (aL ? 0x0505u : 0u), top_m = 0xFFCCu | (aT ? 0x0033u : 0u);
         const unsigned tl_m = 0xFAC8u | (aT ? 0x0032u : 0u) | (aL ? 0x0504u : 0u) | (aTL ? 0x0001u : 0u);
         const unsigned tr_m = 0x5744u | (aT ? 0x0013u : 0u) | (aTR ? 0x0020u : 0u);
-#pragma unroll I4_UNROLL
+#pragma unroll
         for (int i = 0; i < 16; i++) {
             const int bx = blk_x(i), by = blk_y(i);
             const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1, topleft = (tl_m >> i) & 1, topright = (tr_m >> i) & 1;

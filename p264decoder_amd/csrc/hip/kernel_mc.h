@@ -302,9 +302,6 @@ __device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
-#ifndef MC_LUMA_STORE16
-#define MC_LUMA_STORE16 1
-#endif
 // 4x4 dword transpose among the four lanes of a quad: t[k] of lane L = x[L] of lane k (two exchange steps)
 __device__ __forceinline__ void quad_transpose(uint32_t (&t)[4], const uint32_t (&x)[4], int lane)
 {
@@ -667,23 +664,17 @@ __device__ __forceinline__ int xcd_logical_block()
 // the lane is one 4x4 block
 // ------------------------------------------------------------------------------------------
 template <bool MB>
-__device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g,
-                                             const McLayout &ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+__device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
+                                             const McLayout &ml, int sub, int role_wgs)
 {
     typedef YItem<MB> I;
     constexpr int LIST = MB ? ML_YM : ML_YQ;
-    const int logical = xcd_logical_block();
-    if (logical >= n_wgs) return;
-    int pic = (int)__umulhi((unsigned)logical, inv_wgs);
-    if (logical - pic * wgs_per_pic >= wgs_per_pic) pic++;
-    const PicDev *pd = pics + pic;
-    const uint32_t *mc = mc_all + (size_t)pic * ml.words;  // (addresses from kernel arguments only: the first loads depend on nothing)
     const int wave = rfl((int)(threadIdx.x >> 6));
-    // A wavefront walks the picture's chunks with a stride of all the picture's wavefronts; the key and the list entries of
-    // its NEXT chunk are requested before it starts on the current one, so that only the window fetch itself is a memory
-    // round trip the wavefront has to sit through.
-    const int stride = wgs_per_pic * 4, n_chunks = (int)mc[LIST];
-    int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
+    // A wavefront walks the list's chunks with a stride of all the wavefronts that work on this list of this picture; the key
+    // and the list entries of its NEXT chunk are requested before it starts on the current one, so that only the window
+    // fetch itself is a memory round trip the wavefront has to sit through.
+    const int stride = role_wgs * 4, n_chunks = (int)mc[LIST];
+    int chunk = sub * 4 + wave;
     if (chunk >= n_chunks) return;
     const int lane = threadIdx.x & 63, li = lane & (I::LANES - 1), it = lane / I::LANES;
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
@@ -770,7 +761,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     }
     // ---- store: the two lanes of a block row swap halves, so that a lane writes two rows of 8 samples (four lanes: eight
     // consecutive rows, one or two cache lines) instead of four rows of 4 ----
-    if (MB && MC_LUMA_STORE16) {
+    if (MB) {
         // macroblock items: the four lanes of a quad are the four blocks of a block row - transposed, a lane writes one
         // whole 16-byte row and the macroblock's sixteen lanes two whole cache lines
         uint32_t t[4];
@@ -791,25 +782,6 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     chunk = next; key_w = key_w_next; e = e_next;
   }
 }
-#ifndef MC_LUMA_MB_WAVES
-#define MC_LUMA_MB_WAVES 4
-#endif
-__global__ __launch_bounds__(256, MC_LUMA_MB_WAVES)
-void k_mc_luma_mb(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 4 * YItem<true>::BYTES];
-    mc_luma_body<true>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
-}
-#ifndef MC_LUMA_QUAD_WAVES
-#define MC_LUMA_QUAD_WAVES 4
-#endif
-__global__ __launch_bounds__(256, MC_LUMA_QUAD_WAVES)
-void k_mc_luma_quad(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 16 * YItem<false>::BYTES];
-    mc_luma_body<false>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
-}
-
 // ------------------------------------------------------------------------------------------
 // k_mc_chroma<MB>: one wavefront = one chunk: 8 macroblock items of 8 lanes or 32 quadrant items of 2 lanes;
 // the lane is one 4x4 chroma block (quadrant, plane)
@@ -876,21 +848,15 @@ template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece(rsrc_t rs, u
 __device__ __forceinline__ void lds_put16(uint8_t *p, u32x4 v) { *(uint2 *)p = make_uint2(v.x, v.y); *(uint2 *)(p + 8) = make_uint2(v.z, v.w); }
 
 template <bool MB>
-__device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g,
-                                               const McLayout &ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+__device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
+                                               const McLayout &ml, int sub, int role_wgs)
 {
     typedef CItem<MB> I;
     constexpr int LIST = MB ? ML_CM : ML_CQ;
-    const int logical = xcd_logical_block();
-    if (logical >= n_wgs) return;
-    int pic = (int)__umulhi((unsigned)logical, inv_wgs);
-    if (logical - pic * wgs_per_pic >= wgs_per_pic) pic++;
-    const PicDev *pd = pics + pic;
-    const uint32_t *mc = mc_all + (size_t)pic * ml.words;
     const int wave = rfl((int)(threadIdx.x >> 6));
     // (chunk walk with the next chunk's key and entries requested ahead, as in mc_luma_body)
-    const int stride = wgs_per_pic * 4, n_chunks = (int)mc[LIST];
-    int chunk = (logical - pic * wgs_per_pic) * 4 + wave;
+    const int stride = role_wgs * 4, n_chunks = (int)mc[LIST];
+    int chunk = sub * 4 + wave;
     if (chunk >= n_chunks) return;
     const int lane = threadIdx.x & 63, p = lane & 1, li = lane & (I::LANES - 1), it = lane / I::LANES;
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
@@ -1038,15 +1004,41 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     chunk = next; key_w = key_w_next; e = e_next;
   }
 }
+// ------------------------------------------------------------------------------------------
+// k_mc: ONE launch for the four kinds of work.  A picture gets `wgs_per_pic` consecutive (logical) workgroups; they split
+// into the four roles - luma macroblock items, luma quadrant items, chroma macroblock items, chroma quadrant items - in
+// proportion to the work the picture's lists hold (chunks in use x a cost weight per chunk, measured), decided on the device
+// from the counts k_mc_sort left.  All four roles of a picture run at the same time on the same XCD and walk the picture's
+// bands in step: a reference line fetched for a macroblock item is in L2 when the quadrant item next to it and the chroma
+// windows ask for it (as four launches every kernel pulled the whole reference through HBM again: measured 7.0 GB of reads
+// against 3.1 GB of reference samples), and the bandwidth-bound chroma work shares its CU with the issue-bound luma work.
+// ------------------------------------------------------------------------------------------
+#define MC_COST_YM 7u               // relative cost of one chunk (wavefront pass) per role, from the round-2 profiles
+#define MC_COST_YQ 10u
+#define MC_COST_CM 5u
+#define MC_COST_CQ 9u
 __global__ __launch_bounds__(256, 4)
-void k_mc_chroma_mb(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+void k_mc(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 8 * CItem<true>::BYTES];
-    mc_chroma_body<true>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
-}
-__global__ __launch_bounds__(256, 4)
-void k_mc_chroma_quad(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 32 * CItem<false>::BYTES];
-    mc_chroma_body<false>(images, pics, mc_all, g, ml, inv_mbw, wgs_per_pic, n_wgs, inv_wgs);
+    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 16 * YItem<false>::BYTES];        // the largest of the four roles' images
+    static_assert(sizeof(images) >= 4 * 4 * YItem<true>::BYTES && sizeof(images) >= 4 * 8 * CItem<true>::BYTES && sizeof(images) >= 4 * 32 * CItem<false>::BYTES, "image space");
+    const int logical = xcd_logical_block();
+    if (logical >= n_wgs) return;
+    int pic = (int)__umulhi((unsigned)logical, inv_wgs);
+    if (logical - pic * wgs_per_pic >= wgs_per_pic) pic++;
+    const int s = logical - pic * wgs_per_pic;
+    const PicDev *pd = pics + pic;
+    const uint32_t *mc = mc_all + (size_t)pic * ml.words;  // (addresses from kernel arguments only: the first loads depend on nothing)
+    // role split (scalar): every non-empty list gets one workgroup, the rest go by cost
+    const uint32_t n0 = mc[ML_YM], n1 = mc[ML_YQ], n2 = mc[ML_CM], n3 = mc[ML_CQ];
+    const uint32_t t0 = n0 * MC_COST_YM, t1 = n1 * MC_COST_YQ, t2 = n2 * MC_COST_CM, t3 = n3 * MC_COST_CQ, tt = t0 + t1 + t2 + t3;
+    if (tt == 0) return;
+    const uint32_t nz = (n0 != 0) + (n1 != 0) + (n2 != 0) + (n3 != 0), spare = (uint32_t)wgs_per_pic - nz;       // wgs_per_pic >= 4
+    const float inv = (float)spare / (float)tt;
+    const int w1 = (n1 != 0) + (int)((float)t1 * inv), w2 = (n2 != 0) + (int)((float)t2 * inv), w3 = (n3 != 0) + (int)((float)t3 * inv);
+    const int w0 = wgs_per_pic - w1 - w2 - w3;             // (luma macroblock items take the rounding remainder)
+    if (s < w0) mc_luma_body<true>(images, pd, mc, g, ml, s, w0);
+    else if (s < w0 + w1) mc_luma_body<false>(images, pd, mc, g, ml, s - w0, w1);
+    else if (s < w0 + w1 + w2) mc_chroma_body<true>(images, pd, mc, g, ml, s - w0 - w1, w2);
+    else mc_chroma_body<false>(images, pd, mc, g, ml, s - w0 - w1 - w2, w3);
 }

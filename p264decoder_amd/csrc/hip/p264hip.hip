@@ -87,6 +87,8 @@ struct p264hip_ctx {
     hipStream_t side[4] = {};
     hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[4] = {};
     bool concurrent = false;      // P264AMD_CONCURRENT=1: measured no gain at full batches (every kernel fills the chip on its own), kept as a knob
+    // tuning knobs, read from the environment ONCE (p264hip_create); 0 = built-in choice
+    int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0;
     hipEvent_t markers[P264HIP_MARKERS] = {};
     int next_marker = 0;
     bool timing = false;
@@ -135,6 +137,10 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming);
     if (const char *env = getenv("P264AMD_CONCURRENT")) c->concurrent = atoi(env) != 0;
+    if (const char *env = getenv("P264AMD_MC_WGS_PER_PIC")) c->tune_mc_wgs = atoi(env);
+    if (const char *env = getenv("P264AMD_INTRA_WAVES")) c->tune_intra_waves = atoi(env);
+    if (const char *env = getenv("P264AMD_DEBLOCK_RB_LOG2")) c->tune_rb_log2 = atoi(env);
+    if (const char *env = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) c->tune_pics_per_wg = atoi(env);
     if (e == hipSuccess) e = hipMalloc((void **)&c->frames, c->frame_bytes * (size_t)n_streams * slots);
     if (e == hipSuccess) e = hipMemsetAsync(c->frames, 0, c->frame_bytes * (size_t)n_streams * slots, c->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int));
@@ -377,31 +383,18 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         ScopedStamp t(c, 0);
         const McLayout ml = c->ml;
         hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
-        if (conc) HIPCHK(hipEventRecord(c->ev_fork2, c->stream));
-        const uint32_t *mc = c->d_mc;
-        auto launch = [&](void (*k)(const PicDev *, const uint32_t *, Geom, McLayout, uint32_t, int, int, uint32_t), int list, hipStream_t st) {
-            // four wavefronts per workgroup, every wavefront walks its picture's chunks with a stride: enough workgroups
-            // per picture to fill the chip a few times over, no more than there are chunks
-            int wgs = (c->n_cu * 192 + n - 1) / n;
-            const int max_wgs = (int)(ml.max_chunks[list] + 3) / 4;
-            if (wgs > max_wgs) wgs = max_wgs;
-            if (const char *e = getenv("P264AMD_MC_WGS_PER_PIC")) { int v = atoi(e); if (v >= 1 && v <= max_wgs) wgs = v; }
-            hipLaunchKernelGGL(k, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, st, (const PicDev *)c->d_batch[r], mc, g, ml, inv_mbw,
-                               wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
-        };
-        if (conc) {
-            for (int i = 0; i < 3; i++) HIPCHK(hipStreamWaitEvent(c->side[i], c->ev_fork2, 0));
-            launch(k_mc_luma_mb, ML_YM, c->stream);
-            launch(k_mc_chroma_mb, ML_CM, c->side[0]);
-            launch(k_mc_luma_quad, ML_YQ, c->side[1]);
-            launch(k_mc_chroma_quad, ML_CQ, c->side[2]);
-            for (int i = 0; i < 3; i++) { HIPCHK(hipEventRecord(c->ev_join[i], c->side[i])); HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[i], 0)); }
-        } else {
-            launch(k_mc_luma_mb, ML_YM, c->stream);
-            launch(k_mc_luma_quad, ML_YQ, c->stream);
-            launch(k_mc_chroma_mb, ML_CM, c->stream);
-            launch(k_mc_chroma_quad, ML_CQ, c->stream);
-        }
+        // one launch for luma / chroma, macroblock / quadrant items (k_mc): every picture gets the same number of workgroups,
+        // which split into the four roles on the device.  Enough workgroups per picture to fill the chip a few times over,
+        // no more than there can be chunks (four wavefronts per workgroup, one chunk per wavefront pass).
+        int wgs = (c->n_cu * 384 + n - 1) / n;
+        if (wgs < 16) wgs = 16;
+        int max_wgs = 0;
+        for (int l = 0; l < ML_LISTS; l++) max_wgs += (int)(ml.max_chunks[l] + 3) / 4;
+        if (wgs > max_wgs) wgs = max_wgs;
+        if (c->tune_mc_wgs >= 4 && c->tune_mc_wgs <= max_wgs) wgs = c->tune_mc_wgs;
+        if (wgs < 4) wgs = 4;
+        hipLaunchKernelGGL(k_mc, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, c->stream, (const PicDev *)c->d_batch[r], (const uint32_t *)c->d_mc, g, ml,
+                           wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
     }
     if (conc) { launch_bs(); HIPCHK(hipEventRecord(c->ev_join[3], c->side[3])); bs_forked = true; }
     {
@@ -409,7 +402,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // one workgroup per picture: 16 wavefronts while every picture can have a CU to itself, else 8 or 4 so that two or
         // four pictures share a CU (the kernel is dependency/latency bound: measured +19 % at 512 and +9 % at 1024 pictures)
         int intra_waves = n > 2 * c->n_cu ? INTRA_ROW_WAVES / 4 : n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
-        if (const char *e = getenv("P264AMD_INTRA_WAVES")) { int v = atoi(e); if (v >= 1 && v <= INTRA_ROW_WAVES) intra_waves = v; }
+        if (c->tune_intra_waves >= 1 && c->tune_intra_waves <= INTRA_ROW_WAVES) intra_waves = c->tune_intra_waves;
         // luma and chroma of a picture are independent chains: as two workgroups they run side by side (the kernel is bound by
         // the latency of the macroblock-to-macroblock chain, not by arithmetic)
         hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
@@ -426,8 +419,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         if (per_wg < 1) per_wg = 1;
         if (per_wg > 4) per_wg = 4;
         int rb_log2 = per_wg == 1 ? 3 : per_wg == 2 ? 2 : 1;
-        if (const char *e = getenv("P264AMD_DEBLOCK_RB_LOG2")) { int v = atoi(e); if (v >= 1 && v <= 3) { rb_log2 = v; per_wg = 8 >> v; } }
-        if (const char *e = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) { int v = atoi(e); if (v >= 1 && v <= (8 >> rb_log2)) per_wg = v; }
+        if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) { rb_log2 = c->tune_rb_log2; per_wg = 8 >> rb_log2; }
+        if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= (8 >> rb_log2)) per_wg = c->tune_pics_per_wg;
         const int n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
         const int waves = n_bands < ROW_WAVES ? n_bands : ROW_WAVES;
         hipLaunchKernelGGL(k_deblock, dim3((n + per_wg - 1) / per_wg), dim3(waves * 64), 0, c->stream, c->d_batch[r], g,

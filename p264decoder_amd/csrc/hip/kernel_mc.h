@@ -298,7 +298,10 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes)
 __device__ __forceinline__ uint32_t bload(rsrc_t r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
 __device__ __forceinline__ void bstore(rsrc_t r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)off, 0, 0); }
 __device__ __forceinline__ u32x4 bload4(rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); }
-__device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b) { const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, 0); }
+// reconstructed samples are written once and not read again by this stage: non-temporal stores keep them from pushing
+// reference lines out of L2 (measured: -3 % on the stage)
+#define MC_ST_AUX 2
+__device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b) { const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, MC_ST_AUX); }
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
@@ -318,7 +321,7 @@ __device__ __forceinline__ void quad_transpose(uint32_t (&t)[4], const uint32_t 
         t[j] = b1 ? r : a[j]; t[2 + j] = b1 ? a[2 + j] : r;
     }
 }
-__device__ __forceinline__ void bstore4(rsrc_t r, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const u32x4 v = { a, b, c, d }; __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0); }
+__device__ __forceinline__ void bstore4(rsrc_t r, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const u32x4 v = { a, b, c, d }; __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, MC_ST_AUX); }
 
 // ------------------------------------------------------------------------------------------
 // reference windows in registers
@@ -329,31 +332,42 @@ __device__ __forceinline__ void bstore4(rsrc_t r, uint32_t off, uint32_t a, uint
 // GWin - straight from memory with clamped coordinates; only for quadrants whose 4x4 blocks have different vectors
 //        (sub-8x8 partitions), where there is no common window.
 //
-// Luma work items: MB = a whole macroblock (16 lanes, window 21 rows x 3 strips) or an 8x8 quadrant (4 lanes, 13 rows x 2
-// strips).  Image row = the strips side by side + 4 bytes so that rows spread over the LDS banks.
+// Luma work items: MB = a whole macroblock (16 lanes, window 21 rows x up to 3 strips) or an 8x8 quadrant (4 lanes, 13 rows x 2
+// strips).  The image holds only the dword columns the item reads, ROTATED so that column 0 is the dword of the first
+// sample the class needs (x0 = xs & ~3): a lane's reads are at column (its block column + k) whatever the vector, and pitch
+// and item stride are chosen so that every read instruction of a wavefront is free of bank conflicts BY CONSTRUCTION
+// (64 banks of 4 bytes):
+//   macroblock items: dword = item * 208 + (4 by + r) * 9 + bx + k   ->  bank = 16 item + 36 by + bx + const: the sixteen
+//                     (item, by) pairs land on sixteen different 4-bank slots;
+//   quadrant items:   dword = item * 130 + (4 ly + r) * 8 + lx + k   ->  bank = 2 item + 32 ly + lx + const.
+// (With the strips stored side by side at a pitch of 52 / 36 bytes, the lanes of different items met on the same banks at
+// random: LDS bank-conflict cycles were twice the LDS issue cycles of these kernels.)  The staging stores of a 16-byte row
+// piece go to columns 4 s - dx .. 4 s - dx + 3; columns outside 0 .. 5 (0 .. 3) fall into the row's padding or the padding of
+// the row above - nobody reads them.  LEAD bytes in front of the first item take the negative columns of its first row.
 template <bool MB> struct YItem {
     static constexpr int LANES = MB ? 16 : 4, PER_WAVE = 64 / LANES, STRIPS = MB ? 3 : 2, ROWS = MB ? 21 : 13;
-    static constexpr int PITCH = STRIPS * 16 + 4, BYTES = ROWS * PITCH + 4;
+    static constexpr int PITCH = MB ? 36 : 32, BYTES = MB ? 832 : 520, LEAD = 16;
+    static_assert(ROWS * PITCH + 12 <= BYTES, "item image");
 };
 
-// Stage rows R0S .. R0S+NRS-1 of the window whose top-left sample is (wx, wy); li = lane inside the item.  Piece p = strip
+// Stage rows R0S .. R0S+NRS-1 of the window whose first needed sample is (xs, wy); li = lane inside the item.  Piece p = strip
 // p / NRS, row p % NRS: consecutive lanes fetch consecutive rows of one strip (64 contiguous bytes per four lanes).  A
-// macroblock window reaches into its third strip only when it starts in the last 12 samples of a strip: `third` says so.
+// macroblock window reaches into its third strip only when it starts in the last dword of a strip: `third` says so.
 // CLAMP: coordinates clamped to the picture = the reference's replicated borders (core/frame.c:183-222, A-Q9): a strip
 // that lies outside the picture becomes the replicated first (last) sample of the row.
 template <bool MB, int R0S, int NRS, bool CLAMP>
-__device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t roff, const Geom &g, int wx, int wy, int li, bool third)
+__device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t roff, const Geom &g, int xs, int wy, int li, bool third)
 {
     typedef YItem<MB> I;
     constexpr int NP = I::STRIPS * NRS, NJ = (NP + I::LANES - 1) / I::LANES;
-    const int sA = wx >> 4;
+    const int sA = xs >> 4, dx4 = xs & 12;                  // first strip, byte offset of the first needed dword inside it
     u32x4 v[NJ];
     int dst[NJ];
     bool on[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int p = min(li + I::LANES * j, NP - 1), s = p >= 2 * NRS ? 2 : p >= NRS ? 1 : 0, row = R0S + p - s * NRS;
-        dst[j] = row * I::PITCH + s * 16;
+        dst[j] = row * I::PITCH + s * 16 - dx4;
         on[j] = !MB || s < 2 || third;
         v[j] = u32x4{ 0, 0, 0, 0 };
         if (on[j]) {
@@ -713,19 +727,21 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         // the item's window (all its lanes hold the same vector): top-left sample (wx, wy), staged in LDS
         const int ox = MB ? bx * 4 : (li & 1) * 4, oy = MB ? by * 4 : (li >> 1) * 4;
         const int wx = ix - ox - 2, wy = iy - oy - 2;
-        uint8_t *img = images + (wave * I::PER_WAVE + it) * I::BYTES;
+        uint8_t *img = images + I::LEAD + (wave * I::PER_WAVE + it) * I::BYTES;
         const bool rows_mid = pc <= PC_H;                  // copy / horizontal: no rows above and below the blocks
-        // (macroblock items) the window's last dword, read by the lanes of the right-most block column, decides about strip 3
-        const bool third = MB && ((((wx + 12) & ~3) + 11) >> 4) - (wx >> 4) >= 2;
+        // first sample the class reads in a row (copy / vertical: no columns left of the blocks); image column 0 = its dword
+        const int xs = (pc == PC_COPY || pc == PC_V) ? wx + 2 : wx;
+        // (macroblock items) six dwords from the first one: the third strip is needed when they start in a strip's last dword
+        const bool third = MB && (xs & 12) == 12 && !(pc == PC_COPY || pc == PC_V);
         constexpr int RM = MB ? 16 : 8;
-        if (!(key & MCY_CLAMP)) { if (rows_mid) stage_luma<MB, 2, RM, false>(img, rs, roff, g, wx, wy, li, third); else stage_luma<MB, 0, I::ROWS, false>(img, rs, roff, g, wx, wy, li, third); }
-        else                    { if (rows_mid) stage_luma<MB, 2, RM, true>(img, rs, roff, g, wx, wy, li, third);  else stage_luma<MB, 0, I::ROWS, true>(img, rs, roff, g, wx, wy, li, third); }
+        if (!(key & MCY_CLAMP)) { if (rows_mid) stage_luma<MB, 2, RM, false>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 0, I::ROWS, false>(img, rs, roff, g, xs, wy, li, third); }
+        else                    { if (rows_mid) stage_luma<MB, 2, RM, true>(img, rs, roff, g, xs, wy, li, third);  else stage_luma<MB, 0, I::ROWS, true>(img, rs, roff, g, xs, wy, li, third); }
         if ((key & MCY_RESID) && coded) {
             const int16_t *cf = pd->coefs + ((size_t)e.w + coef_slot(mask, blk)) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
         }
         wave_lds_fence();
-        const LWin<I::PITCH> w = { img, (wx >> 4) * 16, wy };
+        const LWin<I::PITCH> w = { img, xs & ~3, wy };
         mc_luma_class(pc, out, w, ix, iy, fx, fy);
     } else {
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
@@ -1020,8 +1036,8 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
 __global__ __launch_bounds__(256, 4)
 void k_mc(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t images[4 * 16 * YItem<false>::BYTES];        // the largest of the four roles' images
-    static_assert(sizeof(images) >= 4 * 4 * YItem<true>::BYTES && sizeof(images) >= 4 * 8 * CItem<true>::BYTES && sizeof(images) >= 4 * 32 * CItem<false>::BYTES, "image space");
+    __shared__ __attribute__((aligned(16))) uint8_t images[YItem<false>::LEAD + 4 * 16 * YItem<false>::BYTES];        // the largest of the four roles' images
+    static_assert(sizeof(images) >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && sizeof(images) >= 4 * 8 * CItem<true>::BYTES && sizeof(images) >= 4 * 32 * CItem<false>::BYTES, "image space");
     const int logical = xcd_logical_block();
     if (logical >= n_wgs) return;
     int pic = (int)__umulhi((unsigned)logical, inv_wgs);

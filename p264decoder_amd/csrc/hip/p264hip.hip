@@ -386,7 +386,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // one launch for luma / chroma, macroblock / quadrant items (k_mc): every picture gets the same number of workgroups,
         // which split into the four roles on the device.  Enough workgroups per picture to fill the chip a few times over,
         // no more than there can be chunks (four wavefronts per workgroup, one chunk per wavefront pass).
-        int wgs = (c->n_cu * 384 + n - 1) / n;
+        int wgs = (c->n_cu * 192 + n - 1) / n;
         if (wgs < 16) wgs = 16;
         int max_wgs = 0;
         for (int l = 0; l < ML_LISTS; l++) max_wgs += (int)(ml.max_chunks[l] + 3) / 4;

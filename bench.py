@@ -166,7 +166,7 @@ def fanout_leg(rank, local_rank, world, lib):
     if uid[0].startswith("error"):
         return {"error": uid[0]}
     cmd = [sys.executable, "-m", "p264decoder_amd.tools.fan_bench", "--rank", str(rank), "--world", str(world), "--transport", "rccl",
-           "--uid", uid[0], "--device", str(local_rank), "--streams", str(world), "--pictures", "6"]
+           "--uid", uid[0], "--device", str(local_rank), "--streams", str(max(world, 8)), "--pictures", "12"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK"):
         env.pop(k, None)
@@ -181,11 +181,19 @@ def fanout_leg(rank, local_rank, world, lib):
             res = {"error": "rank %d: fan-out child timed out" % rank}
         for line in out.splitlines():
             if line.startswith("FANOUT "):
-                res = json.loads(line[7:])
-        if "error" in res and p.returncode not in (0, None) and rank == 0:
-            res = {"error": "root child exited with %s: %s" % (p.returncode, err.strip().splitlines()[-1] if err.strip() else "")}
+                res = json.loads(line[7:])                 # the report, or {"error": the transport's / RCCL's own message}
+        if res.get("error") == "no report" and p.returncode not in (0, None):
+            res = {"error": "rank %d: child exited with %s: %s" % (rank, p.returncode, err.strip().splitlines()[-1] if err.strip() else "")}
     except Exception as e:                                    # noqa: BLE001
         res = {"error": "rank %d: %r" % (rank, e)}
+    # the root's report plus whatever the other ranks have to say (a worker's RCCL error is the interesting one when the
+    # root only sees a time-out)
+    every = [None] * world
+    dist.all_gather_object(every, res)
+    if rank == 0:
+        worker_errors = [r["error"] for r in every[1:] if isinstance(r, dict) and r.get("error")]
+        if worker_errors:
+            res = dict(res, worker_errors=worker_errors)
     return res
 
 

@@ -17,8 +17,12 @@
  * loudly: there is no CPU reconstruction in the product (tests plug the CPU oracle in through the backend interface).
  *
  * Per round the root sends every worker ONE control block (how many pictures, their sizes, or "finished") and then the
- * pictures; the worker reconstructs them and sends the planes back.  All sends and receives of a step are posted between
- * group_begin / group_end (ncclGroupStart / ncclGroupEnd).
+ * pictures; the worker reconstructs them and answers with ONE fixed-size status block (0 or its error text) followed, when
+ * the status is 0, by the planes.  A worker that fails keeps answering (with its error) until the root says "finished",
+ * which it only does where a worker expects a control block: no failure on either side leaves the other one waiting
+ * inside a round.  All sends and receives of a step are posted between group_begin / group_end (ncclGroupStart /
+ * ncclGroupEnd).  Rounds are double-buffered on the root: while round r is exchanged and reconstructed, round r+1 is
+ * parsed (one host thread per stream) and packed.
  */
 #ifndef P264FAN_H
 #define P264FAN_H
@@ -49,6 +53,10 @@ typedef struct p264fan_backend {
     int (*open)(void **ctx, int device, int mb_w, int mb_h, int n_local_streams, int slots);
     int (*reconstruct)(void *ctx, int local_stream, const p264hip_picture_t *pic, uint8_t *i420);
     void (*close)(void *ctx);
+    /* optional (NULL: reconstruct() is synchronous): reconstruct() may only enqueue its work; sync() returns when every
+     * picture handed over since the last sync() is in its i420 buffer.  The picture's arrays and the buffers stay valid
+     * until then. */
+    int (*sync)(void *ctx);
 } p264fan_backend_t;
 
 typedef struct {
@@ -56,6 +64,11 @@ typedef struct {
     int64_t bytes_scattered, bytes_gathered;
     double  seconds, parse_seconds, exchange_seconds;
     int     rounds, world;
+    /* rounds are double-buffered: round r+1 is parsed and packed (parse_seconds, on parse_threads host threads) while round
+     * r is exchanged and reconstructed; parse_wait_seconds is the part of the parse the exchange side had to wait for (the
+     * rest was hidden), reconstruct_seconds the root's own reconstruction */
+    double  parse_wait_seconds, reconstruct_seconds;
+    int     parse_threads, reserved;
 } p264fan_stats_t;
 
 /* called on the root for every reconstructed picture, in decode order per stream */

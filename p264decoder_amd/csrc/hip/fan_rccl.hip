@@ -10,6 +10,8 @@
 #include <vector>
 #include "p264fan.h"
 
+extern "C" int p264fan_set_error(const char *fmt, ...);       // fanout.c: the message p264fan_last_error() returns
+
 namespace {
 struct Uid { char internal[128]; };                       // ncclUniqueId (rccl.h:43)
 typedef void *Comm;
@@ -19,8 +21,11 @@ typedef int (*fn_sr)(void *, size_t, int, int, Comm, hipStream_t);
 typedef int (*fn_v)();
 typedef int (*fn_destroy)(Comm);
 typedef const char *(*fn_err)(int);
-struct Api { void *lib = nullptr; fn_uid uid; fn_init init; fn_sr send, recv; fn_v gstart, gend; fn_destroy destroy; fn_err err; };
+struct Api { void *lib = nullptr; fn_uid uid; fn_init init; fn_sr send, recv; fn_v gstart, gend; fn_destroy destroy, abort; fn_err err; };
 Api g_api;
+const char *nccl_str(int e) { return g_api.err ? g_api.err(e) : "RCCL error"; }
+#define RFAIL(what, e) p264fan_set_error("rccl transport: %s: %s (%d)", what, nccl_str(e), e)
+#define HFAIL(what, e) p264fan_set_error("rccl transport: %s: %s", what, hipGetErrorString(e))
 bool load_api()
 {
     if (g_api.lib) return true;
@@ -30,12 +35,13 @@ bool load_api()
     if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!l) l = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!l) l = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!l) { fprintf(stderr, "p264fan: cannot load librccl.so: %s\n", dlerror()); return false; }
+    if (!l) { p264fan_set_error("rccl transport: cannot load librccl.so: %s", dlerror()); return false; }
     g_api.uid = (fn_uid)dlsym(l, "ncclGetUniqueId"); g_api.init = (fn_init)dlsym(l, "ncclCommInitRank");
     g_api.send = (fn_sr)dlsym(l, "ncclSend"); g_api.recv = (fn_sr)dlsym(l, "ncclRecv");
     g_api.gstart = (fn_v)dlsym(l, "ncclGroupStart"); g_api.gend = (fn_v)dlsym(l, "ncclGroupEnd");
-    g_api.destroy = (fn_destroy)dlsym(l, "ncclCommDestroy"); g_api.err = (fn_err)dlsym(l, "ncclGetErrorString");
-    if (!g_api.uid || !g_api.init || !g_api.send || !g_api.recv || !g_api.gstart || !g_api.gend || !g_api.destroy) { dlclose(l); fprintf(stderr, "p264fan: librccl.so lacks a symbol\n"); return false; }
+    g_api.destroy = (fn_destroy)dlsym(l, "ncclCommDestroy"); g_api.abort = (fn_destroy)dlsym(l, "ncclCommAbort");
+    g_api.err = (fn_err)dlsym(l, "ncclGetErrorString");
+    if (!g_api.uid || !g_api.init || !g_api.send || !g_api.recv || !g_api.gstart || !g_api.gend || !g_api.destroy) { dlclose(l); p264fan_set_error("rccl transport: librccl.so lacks a symbol"); return false; }
     g_api.lib = l;
     return true;
 }
@@ -44,7 +50,7 @@ struct Rccl {
     Comm comm = nullptr; int device = 0; hipStream_t stream = nullptr;
     std::vector<void *> stage; std::vector<size_t> cap; size_t used = 0;      // staging buffers of the current group
     std::vector<Pending> pending;
-    bool in_group = false;
+    bool in_group = false, broken = false;
 };
 void *stage_buf(Rccl *r, size_t bytes)
 {
@@ -52,16 +58,21 @@ void *stage_buf(Rccl *r, size_t bytes)
     if (r->cap[r->used] < bytes) {
         if (r->stage[r->used]) (void)hipFree(r->stage[r->used]);
         r->stage[r->used] = nullptr; r->cap[r->used] = 0;
-        if (hipMalloc(&r->stage[r->used], bytes + bytes / 4) != hipSuccess) return nullptr;
+        hipError_t e = hipMalloc(&r->stage[r->used], bytes + bytes / 4);
+        if (e != hipSuccess) { HFAIL("hipMalloc of a staging buffer", e); return nullptr; }
         r->cap[r->used] = bytes + bytes / 4;
     }
     return r->stage[r->used++];
 }
+// the group's transfers are on the stream: the device -> host copies of what was received follow them on the same stream
+// (real DMA when the caller's buffers are pinned, which the fan-out's frame buffers are), one wait for everything
 int finish(Rccl *r)
 {
-    if (hipStreamSynchronize(r->stream) != hipSuccess) return -1;
-    for (auto &p : r->pending) if (hipMemcpy(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    hipError_t e = hipSuccess;
+    for (auto &p : r->pending) if (e == hipSuccess) e = hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     r->pending.clear(); r->used = 0;
+    if (e != hipSuccess) { r->broken = true; return HFAIL("completing a group", e); }
     return 0;
 }
 int rc_send(void *c, int peer, const void *buf, size_t n)
@@ -69,8 +80,10 @@ int rc_send(void *c, int peer, const void *buf, size_t n)
     Rccl *r = (Rccl *)c;
     (void)hipSetDevice(r->device);
     void *d = stage_buf(r, n);
-    if (!d || hipMemcpyAsync(d, buf, n, hipMemcpyHostToDevice, r->stream) != hipSuccess) return -1;
-    if (g_api.send(d, n, 1 /* ncclUint8 */, peer, r->comm, r->stream)) return -1;
+    if (!d) return -1;
+    hipError_t e = hipMemcpyAsync(d, buf, n, hipMemcpyHostToDevice, r->stream);
+    if (e != hipSuccess) return HFAIL("host -> device copy of a send", e);
+    if (int ne = g_api.send(d, n, 1 /* ncclUint8 */, peer, r->comm, r->stream)) { r->broken = true; return RFAIL("ncclSend", ne); }
     return r->in_group ? 0 : finish(r);
 }
 int rc_recv(void *c, int peer, void *buf, size_t n)
@@ -78,18 +91,20 @@ int rc_recv(void *c, int peer, void *buf, size_t n)
     Rccl *r = (Rccl *)c;
     (void)hipSetDevice(r->device);
     void *d = stage_buf(r, n);
-    if (!d || g_api.recv(d, n, 1, peer, r->comm, r->stream)) return -1;
+    if (!d) return -1;
+    if (int ne = g_api.recv(d, n, 1, peer, r->comm, r->stream)) { r->broken = true; return RFAIL("ncclRecv", ne); }
     r->pending.push_back({ buf, d, n });
     return r->in_group ? 0 : finish(r);
 }
-int rc_begin(void *c) { Rccl *r = (Rccl *)c; r->in_group = true; return g_api.gstart() ? -1 : 0; }
-int rc_end(void *c) { Rccl *r = (Rccl *)c; r->in_group = false; if (g_api.gend()) return -1; return finish(r); }
+int rc_begin(void *c) { Rccl *r = (Rccl *)c; r->in_group = true; if (int ne = g_api.gstart()) { r->broken = true; return RFAIL("ncclGroupStart", ne); } return 0; }
+int rc_end(void *c) { Rccl *r = (Rccl *)c; r->in_group = false; if (int ne = g_api.gend()) { r->broken = true; r->pending.clear(); r->used = 0; return RFAIL("ncclGroupEnd", ne); } return finish(r); }
 void rc_close(void *c)
 {
     Rccl *r = (Rccl *)c;
     if (!r) return;
     (void)hipSetDevice(r->device);
-    if (r->comm) g_api.destroy(r->comm);
+    // a communicator that has seen an error is aborted, not destroyed: ncclCommDestroy waits for outstanding operations
+    if (r->comm) { if (r->broken && g_api.abort) g_api.abort(r->comm); else g_api.destroy(r->comm); }
     for (void *p : r->stage) if (p) (void)hipFree(p);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
@@ -98,23 +113,29 @@ void rc_close(void *c)
 
 extern "C" int p264fan_rccl_unique_id(uint8_t id[128])
 {
-    if (!id || !load_api()) return -1;
+    if (!id) return p264fan_set_error("p264fan_rccl_unique_id: null argument");
+    if (!load_api()) return -1;
     Uid u;
-    if (g_api.uid(&u)) return -1;
+    if (int ne = g_api.uid(&u)) return RFAIL("ncclGetUniqueId", ne);
     memcpy(id, u.internal, 128);
     return 0;
 }
 
 extern "C" int p264fan_rccl_transport(p264fan_transport_t *t, int rank, int world, const uint8_t id[128], int device)
 {
-    if (!t || !id || world < 1 || rank < 0 || rank >= world || !load_api()) return -1;
+    if (!t || !id || world < 1 || rank < 0 || rank >= world) return p264fan_set_error("p264fan_rccl_transport: bad argument");
+    if (!load_api()) return -1;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { fprintf(stderr, "p264fan: no HIP device %d for the RCCL transport\n", device); return -1; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return p264fan_set_error("rccl transport: no HIP device %d (have %d)", device, ndev);
     Rccl *r = new Rccl();
     r->device = device;
     Uid u; memcpy(u.internal, id, 128);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess || g_api.init(&r->comm, world, u, rank)) {
-        fprintf(stderr, "p264fan: ncclCommInitRank failed (rank %d of %d, device %d)\n", rank, world, device);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { HFAIL("stream on the rank's device", e); rc_close(r); return -1; }
+    if (int ne = g_api.init(&r->comm, world, u, rank)) {
+        p264fan_set_error("rccl transport: ncclCommInitRank(rank %d of %d, device %d): %s (%d)", rank, world, device, nccl_str(ne), ne);
+        r->comm = nullptr;
         rc_close(r);
         return -1;
     }

@@ -24,9 +24,27 @@ static int fail(const char *fmt, ...)
     return -1;
 }
 const char *p264fan_last_error(void) { return g_err; }
+/* (for the RCCL transport in csrc/hip/fan_rccl.hip: same message slot) */
+int p264fan_set_error(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return -1;
+}
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 /* ---------------------------------------------------------------- messages -------------- */
+/* Per round and worker, always in this order and always of these sizes (a fixed-size exchange keeps both sides in step
+ * whatever fails):
+ *   root -> worker   fan_ctrl_t                      how many pictures follow and their sizes, or FAN_FINISHED
+ *   root -> worker   n packed pictures
+ *   worker -> root   fan_status_t                    0, or what failed on the worker (it keeps serving: the root ends the job
+ *                                                    with FAN_FINISHED at the next round boundary)
+ *   worker -> root   n frames of MB-aligned I420     only when the status is 0
+ * The root sends FAN_FINISHED only where a worker expects a control block.  Everything on the root that can fail
+ * without the transport failing (parse, allocation, packing) happens BEFORE the round's control block goes out, and a
+ * failure of the root's own reconstruction is reported only after the round's gather: the root never leaves a worker
+ * in the middle of a round.  If the transport itself fails there is nothing left to say - both transports' calls
+ * return an error then (TCP: peer closed). */
 #define FAN_MAX_PER_ROUND 64            /* pictures one worker takes per round */
 #define FAN_FINISHED (-1)
 typedef struct {                        /* root -> worker, once per round, fixed size */
@@ -34,13 +52,17 @@ typedef struct {                        /* root -> worker, once per round, fixed
     int32_t mb_w, mb_h, slots, n_local_streams;
     uint32_t bytes[FAN_MAX_PER_ROUND];  /* size of each packed picture */
 } fan_ctrl_t;
+typedef struct {                        /* worker -> root, once per round, fixed size */
+    int32_t rc, n;
+    char msg[248];
+} fan_status_t;
 typedef struct {                        /* head of a packed picture; the arrays follow, each padded to 16 bytes */
     uint32_t magic;
     int32_t  local_stream;
     p264hip_picture_t desc;             /* pointers are meaningless on the wire */
     uint32_t n_mb;
 } fan_head_t;
-#define FAN_MAGIC 0x70464e31u
+#define FAN_MAGIC 0x70464e32u
 static size_t pad16(size_t v) { return (v + 15) & ~(size_t)15; }
 static size_t packed_size(const p264hip_picture_t *p)
 {
@@ -80,6 +102,10 @@ static int unpack_picture(const uint8_t *src, size_t bytes, p264hip_picture_t *o
 }
 
 /* ---------------------------------------------------------------- default backend ------- */
+/* The MI355X path of this library.  reconstruct() only ENQUEUES (upload, kernels, layout conversion, download into the
+ * caller's buffer); sync() waits for everything enqueued - a round's pictures overlap on the device and there is one wait
+ * per round.  The picture's arrays and the output buffer must stay untouched until sync() (the fan-out keeps a round's
+ * messages and frames alive until then; frames live in pinned memory so that the downloads are real DMA transfers). */
 typedef struct { p264hip_ctx *hip; int mb_w, mb_h; } hipbk_t;
 static int hipbk_open(void **ctx, int device, int mb_w, int mb_h, int n_local, int slots)
 {
@@ -94,12 +120,21 @@ static int hipbk_reconstruct(void *ctx, int s, const p264hip_picture_t *pic, uin
 {
     hipbk_t *b = (hipbk_t *)ctx;
     const int w = b->mb_w * 16, h = b->mb_h * 16;
-    if (p264hip_submit(b->hip, s, pic) != P264HIP_OK) return fail("%s", p264hip_last_error());
-    if (p264hip_read_frame(b->hip, s, pic->dst_slot, i420, w, i420 + (size_t)w * h, i420 + (size_t)w * h * 5 / 4, w / 2) != P264HIP_OK) return fail("%s", p264hip_last_error());
+    if (p264hip_submit_async(b->hip, s, pic) != P264HIP_OK) return fail("%s", p264hip_last_error());
+    if (p264hip_read_frame_async(b->hip, s, pic->dst_slot, i420, w, i420 + (size_t)w * h, i420 + (size_t)w * h * 5 / 4, w / 2) != P264HIP_OK) return fail("%s", p264hip_last_error());
     return 0;
 }
+static int hipbk_sync(void *ctx) { hipbk_t *b = (hipbk_t *)ctx; return p264hip_sync(b->hip) == P264HIP_OK ? 0 : fail("%s", p264hip_last_error()); }
 static void hipbk_close(void *ctx) { hipbk_t *b = (hipbk_t *)ctx; if (b) { if (b->hip) p264hip_destroy(b->hip); free(b); } }
-static const p264fan_backend_t g_hip_backend = { NULL, hipbk_open, hipbk_reconstruct, hipbk_close };
+static const p264fan_backend_t g_hip_backend = { NULL, hipbk_open, hipbk_reconstruct, hipbk_close, hipbk_sync };
+/* frames: pinned when a HIP device is there (downloads and RCCL staging copies become DMA), plain memory otherwise */
+static uint8_t *frames_alloc(size_t bytes, int *pinned)
+{
+    uint8_t *p = (uint8_t *)p264hip_host_alloc(bytes);
+    *pinned = p != NULL;
+    return p ? p : (uint8_t *)malloc(bytes);
+}
+static void frames_free(uint8_t *p, int pinned) { if (pinned) p264hip_host_free(p); else free(p); }
 
 /* ---------------------------------------------------------------- TCP transport --------- */
 typedef struct { int rank, world; int *fd; } tcp_t;        /* fd[peer]; root: one per worker, worker: fd[0] */
@@ -195,41 +230,59 @@ void p264fan_close(p264fan *f)
 }
 static int gb(p264fan *f) { return f->t.group_begin ? f->t.group_begin(f->t.ctx) : 0; }
 static int ge(p264fan *f) { return f->t.group_end ? f->t.group_end(f->t.ctx) : 0; }
+static int bk_sync(p264fan *f) { return (f->bk.sync && f->bk_ctx) ? f->bk.sync(f->bk_ctx) : 0; }
 
 int p264fan_worker_run(p264fan *f)
 {
     if (!f || f->rank == 0) return fail("p264fan_worker_run: not a worker");
     uint8_t *msg[FAN_MAX_PER_ROUND] = { 0 }; size_t cap[FAN_MAX_PER_ROUND] = { 0 };
-    uint8_t *out = NULL; size_t frame = 0;
-    int rc = 0;
+    uint8_t *out = NULL; size_t frame = 0; int out_pinned = 0;
+    int rc = 0;                                             /* transport failures only: they end the loop */
+    char first_err[248] = "";
     for (;;) {
         fan_ctrl_t c;
         if (gb(f) || f->t.recv(f->t.ctx, 0, &c, sizeof c) || ge(f)) { rc = -1; break; }
         if (c.n == FAN_FINISHED) break;
-        if (c.n < 0 || c.n > FAN_MAX_PER_ROUND) { rc = fail("worker %d: bad control block", f->rank); break; }
-        if (!f->bk_ctx) {
-            if (f->bk.open(&f->bk_ctx, f->device, c.mb_w, c.mb_h, c.n_local_streams, c.slots)) { rc = -1; break; }
-            frame = (size_t)c.mb_w * c.mb_h * 384;
-            out = (uint8_t *)malloc(frame * FAN_MAX_PER_ROUND);
-            if (!out) { rc = fail("out of memory"); break; }
-        }
-        if (gb(f)) { rc = -1; break; }
-        for (int k = 0; k < c.n && !rc; k++) {
-            if (c.bytes[k] > cap[k]) { free(msg[k]); cap[k] = c.bytes[k] + c.bytes[k] / 4; msg[k] = (uint8_t *)malloc(cap[k]); if (!msg[k]) { rc = fail("out of memory"); break; } }
-            if (f->t.recv(f->t.ctx, 0, msg[k], c.bytes[k])) rc = -1;
-        }
-        if (ge(f) || rc) { rc = -1; break; }
-        for (int k = 0; k < c.n && !rc; k++) {
-            p264hip_picture_t pic; int ls = 0;
-            if (unpack_picture(msg[k], c.bytes[k], &pic, &ls) || f->bk.reconstruct(f->bk_ctx, ls, &pic, out + frame * (size_t)k)) rc = -1;
-        }
+        if (c.n < 0 || c.n > FAN_MAX_PER_ROUND) { rc = fail("worker %d: bad control block", f->rank); break; }   /* (out of step: nothing sane left to do) */
+        fan_status_t st; memset(&st, 0, sizeof st); st.n = c.n;
+        /* ---- the round's pictures: always received, whatever state this worker is in */
+        for (int k = 0; k < c.n; k++)
+            if (c.bytes[k] > cap[k]) {
+                free(msg[k]); cap[k] = 0;
+                msg[k] = (uint8_t *)malloc((size_t)c.bytes[k] + c.bytes[k] / 4);
+                if (!msg[k]) { rc = fail("worker %d: out of memory", f->rank); break; }       /* (cannot even receive: the transport is closed below) */
+                cap[k] = (size_t)c.bytes[k] + c.bytes[k] / 4;
+            }
         if (rc) break;
+        if (gb(f)) { rc = -1; break; }
+        for (int k = 0; k < c.n && !rc; k++) if (f->t.recv(f->t.ctx, 0, msg[k], c.bytes[k])) rc = -1;
+        if (ge(f) || rc) { rc = -1; break; }
+        /* ---- reconstruct; a failure becomes the round's status and the worker keeps serving */
+        if (!f->bk_ctx && !first_err[0]) {
+            if (f->bk.open(&f->bk_ctx, f->device, c.mb_w, c.mb_h, c.n_local_streams, c.slots)) { st.rc = -1; f->bk_ctx = NULL; }
+            else {
+                frame = (size_t)c.mb_w * c.mb_h * 384;
+                out = frames_alloc(frame * FAN_MAX_PER_ROUND, &out_pinned);
+                if (!out) { st.rc = -1; fail("worker %d: out of memory", f->rank); }
+            }
+        }
+        if (first_err[0]) { st.rc = -1; fail("%s", first_err); }      /* an earlier round failed: this worker's frame stores are stale */
+        for (int k = 0; k < c.n && !st.rc; k++) {
+            p264hip_picture_t pic; int ls = 0;
+            if (unpack_picture(msg[k], c.bytes[k], &pic, &ls) || f->bk.reconstruct(f->bk_ctx, ls, &pic, out + frame * (size_t)k)) st.rc = -1;
+        }
+        if (!st.rc && bk_sync(f)) st.rc = -1;
+        if (st.rc) { snprintf(st.msg, sizeof st.msg, "%.240s", g_err[0] ? g_err : "reconstruction failed"); if (!first_err[0]) snprintf(first_err, sizeof first_err, "%.240s", st.msg); }
+        /* ---- status, then the frames */
+        if (gb(f) || f->t.send(f->t.ctx, 0, &st, sizeof st) || ge(f)) { rc = -1; break; }
+        if (st.rc) continue;
         if (gb(f)) { rc = -1; break; }
         for (int k = 0; k < c.n && !rc; k++) if (f->t.send(f->t.ctx, 0, out + frame * (size_t)k, frame)) rc = -1;
         if (ge(f) || rc) { rc = -1; break; }
     }
     for (int k = 0; k < FAN_MAX_PER_ROUND; k++) free(msg[k]);
-    free(out);
+    if (out) frames_free(out, out_pinned);
+    if (!rc && first_err[0]) rc = fail("%s", first_err);    /* the job failed on this worker, even though it left in step */
     return rc;
 }
 
@@ -253,29 +306,93 @@ static const p264hip_picture_t *next_picture(fstream_t *s, int max_pictures, int
     return NULL;
 }
 
-/* the round's pictures are parsed side by side: the streams are independent, and the serial parse is what bounds the
- * fan-out (a 1080p picture takes the parser longer than eight GPUs need to reconstruct one each) */
-typedef struct { fstream_t *st; const p264hip_picture_t **pics; int first, step, n_streams, max_pictures, failed; } parse_job_t;
+/* One round's worth of work, produced by the parse side and consumed by the exchange side: every stream's next picture,
+ * PACKED (the parser's arrays only live until the stream's next call; a packed copy lets the next round be parsed while
+ * this one travels and is reconstructed - for the root's own streams too). */
+typedef struct {
+    uint8_t **msg; size_t *cap, *len;   /* [n_streams]; len 0 = the stream has no picture in this round */
+    int64_t *index;                     /* picture number inside its stream */
+    int n, failed, slots, mb_w, mb_h;
+    char err[200];
+} fan_round_t;
+typedef struct {
+    fstream_t *st; int n_streams, world, max_pictures, threads;
+    fan_round_t rounds[2];
+    int ready[2];                       /* 0 free, 1 filled */
+    int stop;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    double parse_seconds;
+} fan_producer_t;
+
+typedef struct { fan_producer_t *P; fan_round_t *R; int first, step, failed; } parse_job_t;
 static void *parse_worker(void *arg)
 {
     parse_job_t *j = (parse_job_t *)arg;
-    for (int s = j->first; s < j->n_streams; s += j->step) j->pics[s] = next_picture(&j->st[s], j->max_pictures, &j->failed);
+    fan_producer_t *P = j->P; fan_round_t *R = j->R;
+    for (int s = j->first; s < P->n_streams; s += j->step) {
+        R->len[s] = 0;
+        const p264hip_picture_t *pic = next_picture(&P->st[s], P->max_pictures, &j->failed);
+        if (!pic) continue;
+        const size_t need = packed_size(pic);
+        if (need > R->cap[s]) {
+            free(R->msg[s]); R->cap[s] = 0;
+            R->msg[s] = (uint8_t *)malloc(need + need / 4);
+            if (!R->msg[s]) { j->failed = 1; continue; }
+            R->cap[s] = need + need / 4;
+        }
+        pack_picture(R->msg[s], s / P->world, pic);
+        R->len[s] = need;
+        R->index[s] = P->st[s].pictures - 1;
+    }
     return NULL;
 }
-static int parse_round(fstream_t *st, const p264hip_picture_t **pics, int n_streams, int max_pictures, int threads)
+/* the round's pictures are parsed side by side on `threads` host threads: the streams are independent, and the serial
+ * parse of one stream is what bounds the fan-out */
+static void fill_round(fan_producer_t *P, fan_round_t *R)
 {
-    if (threads > n_streams) threads = n_streams;
+    int threads = P->threads;
+    if (threads > P->n_streams) threads = P->n_streams;
     if (threads > 64) threads = 64;
     parse_job_t jobs[64];
     pthread_t tid[64];
-    int started = 0, failed = 0;
-    for (int t = 0; t < threads; t++) jobs[t] = (parse_job_t){ st, pics, t, threads, n_streams, max_pictures, 0 };
+    int started = 0;
+    for (int t = 0; t < threads; t++) jobs[t] = (parse_job_t){ P, R, t, threads, 0 };
     for (int t = 1; t < threads; t++) { if (pthread_create(&tid[t], NULL, parse_worker, &jobs[t])) break; started = t; }
     for (int t = started + 1; t < threads; t++) parse_worker(&jobs[t]);     /* (threads that could not be started: done here) */
     parse_worker(&jobs[0]);
     for (int t = 1; t <= started; t++) pthread_join(tid[t], NULL);
-    for (int t = 0; t < threads; t++) failed |= jobs[t].failed;
-    return failed;
+    R->n = 0; R->failed = 0; R->slots = 0; R->mb_w = R->mb_h = 0; R->err[0] = 0;
+    for (int t = 0; t < threads; t++) if (jobs[t].failed) { R->failed = 1; snprintf(R->err, sizeof R->err, "a stream failed to parse (or the host ran out of memory)"); }
+    for (int s = 0; s < P->n_streams && !R->failed; s++) {
+        if (!R->len[s]) continue;
+        fan_head_t h; memcpy(&h, R->msg[s], sizeof h);
+        if (!R->n) { R->mb_w = h.desc.mb_w; R->mb_h = h.desc.mb_h; }
+        else if (h.desc.mb_w != R->mb_w || h.desc.mb_h != R->mb_h) { R->failed = 1; snprintf(R->err, sizeof R->err, "stream %d has a different picture size (%dx%d macroblocks, the job runs at %dx%d)", s, h.desc.mb_w, h.desc.mb_h, R->mb_w, R->mb_h); }
+        const int sl = p264parse_slots(P->st[s].parser);       /* every rank's frame stores are sized for the stream that needs most */
+        if (sl > R->slots) R->slots = sl;
+        R->n++;
+    }
+}
+static void *producer_main(void *arg)
+{
+    fan_producer_t *P = (fan_producer_t *)arg;
+    for (int k = 0;; k ^= 1) {
+        pthread_mutex_lock(&P->mu);
+        while (P->ready[k] && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
+        const int stop = P->stop;
+        pthread_mutex_unlock(&P->mu);
+        if (stop) break;
+        const double t0 = now_s();
+        fill_round(P, &P->rounds[k]);
+        const int last = P->rounds[k].n == 0 || P->rounds[k].failed;
+        pthread_mutex_lock(&P->mu);
+        P->parse_seconds += now_s() - t0;
+        P->ready[k] = 1;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+        if (last) break;
+    }
+    return NULL;
 }
 
 int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, const int64_t *sizes, int max_pictures,
@@ -284,82 +401,123 @@ int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, co
     if (!f || f->rank != 0 || n_streams < 1 || !annexb || !sizes) return fail("p264fan_root_run: bad argument");
     const int W = f->world;
     if ((n_streams + W - 1) / W > FAN_MAX_PER_ROUND) return fail("p264fan_root_run: more than %d streams per rank", FAN_MAX_PER_ROUND);
-    fstream_t *st = (fstream_t *)calloc((size_t)n_streams, sizeof *st);
+    fan_producer_t P; memset(&P, 0, sizeof P);
+    P.st = (fstream_t *)calloc((size_t)n_streams, sizeof *P.st);
     fan_ctrl_t *ctrl = (fan_ctrl_t *)calloc((size_t)W, sizeof *ctrl);
-    uint8_t **msg = (uint8_t **)calloc((size_t)n_streams, sizeof *msg);      /* packed picture of stream s in this round */
-    size_t *cap = (size_t *)calloc((size_t)n_streams, sizeof *cap);
-    int *has = (int *)calloc((size_t)n_streams, sizeof *has);
-    uint8_t *frames = NULL; size_t frame = 0;
-    int rc = (st && ctrl && msg && cap && has) ? 0 : fail("out of memory");
+    fan_status_t *status = (fan_status_t *)calloc((size_t)W, sizeof *status);
+    uint8_t *frames = NULL; size_t frame = 0; int frames_pinned = 0;
+    int rc = (P.st && ctrl && status) ? 0 : fail("out of memory");
+    for (int k = 0; k < 2 && !rc; k++) {
+        fan_round_t *R = &P.rounds[k];
+        R->msg = (uint8_t **)calloc((size_t)n_streams, sizeof *R->msg); R->cap = (size_t *)calloc((size_t)n_streams, sizeof *R->cap);
+        R->len = (size_t *)calloc((size_t)n_streams, sizeof *R->len); R->index = (int64_t *)calloc((size_t)n_streams, sizeof *R->index);
+        if (!R->msg || !R->cap || !R->len || !R->index) rc = fail("out of memory");
+    }
     for (int s = 0; s < n_streams && !rc; s++) {
-        st[s].parser = p264parse_open(P264PARSE_OPT_QUIET);
-        st[s].in = annexb[s]; st[s].size = sizes[s];
-        if (!st[s].parser) rc = fail("p264parse_open failed");
+        P.st[s].parser = p264parse_open(P264PARSE_OPT_QUIET);
+        P.st[s].in = annexb[s]; P.st[s].size = sizes[s];
+        if (!P.st[s].parser) rc = fail("p264parse_open failed");
     }
     p264fan_stats_t S; memset(&S, 0, sizeof S); S.world = W;
-    int parse_threads = 8;                                    /* P264AMD_FAN_THREADS: host threads parsing a round's pictures */
-    { const char *e = getenv("P264AMD_FAN_THREADS"); if (e && atoi(e) >= 1) parse_threads = atoi(e); }
+    P.n_streams = n_streams; P.world = W; P.max_pictures = max_pictures;
+    P.threads = n_streams;                                   /* one parser thread per stream unless P264AMD_FAN_THREADS says otherwise */
+    { const char *e = getenv("P264AMD_FAN_THREADS"); if (e && atoi(e) >= 1) P.threads = atoi(e); }
+    S.parse_threads = P.threads < n_streams ? P.threads : n_streams;
+    if (S.parse_threads > 64) S.parse_threads = 64;
+    pthread_t producer; int have_producer = 0;
+    if (!rc) {
+        pthread_mutex_init(&P.mu, NULL); pthread_cond_init(&P.cv, NULL);
+        if (pthread_create(&producer, NULL, producer_main, &P)) rc = fail("cannot start the parse thread");
+        else have_producer = 1;
+    }
     const double t0 = now_s();
     int mb_w = 0, mb_h = 0, slots = 0;
-    while (!rc) {
-        /* ---- parse: the next picture of every stream (the serial CPU part; its arrays live until the stream's next call) */
-        const double p0 = now_s();
-        int n = 0;
-        const p264hip_picture_t **pics = (const p264hip_picture_t **)alloca(sizeof(void *) * (size_t)n_streams);
-        const int failed = parse_round(st, pics, n_streams, max_pictures, parse_threads);
-        for (int s = 0; s < n_streams; s++) { has[s] = pics[s] != NULL; n += has[s]; }
-        S.parse_seconds += now_s() - p0;
-        if (failed) { rc = fail("a stream failed to parse"); break; }
-        if (!n) break;
+    for (int k = 0; !rc; k ^= 1) {
+        /* ---- the next round, parsed and packed while the previous one travelled */
+        const double w0 = now_s();
+        pthread_mutex_lock(&P.mu);
+        while (!P.ready[k]) pthread_cond_wait(&P.cv, &P.mu);
+        pthread_mutex_unlock(&P.mu);
+        S.parse_wait_seconds += now_s() - w0;
+        fan_round_t *R = &P.rounds[k];
+        if (R->failed) { rc = fail("%s", R->err); break; }
+        if (!R->n) break;
         if (!mb_w) {
-            for (int s = 0; s < n_streams; s++) if (has[s]) { mb_w = pics[s]->mb_w; mb_h = pics[s]->mb_h; slots = p264parse_slots(st[s].parser); break; }
+            mb_w = R->mb_w; mb_h = R->mb_h; slots = R->slots;
             frame = (size_t)mb_w * mb_h * 384;
-            frames = (uint8_t *)malloc(frame * (size_t)n_streams);
+            frames = frames_alloc(frame * (size_t)n_streams, &frames_pinned);
             if (!frames) { rc = fail("out of memory"); break; }
-            if (f->bk.open(&f->bk_ctx, f->device, mb_w, mb_h, (n_streams + W - 1) / W, slots)) { rc = -1; break; }
+            if (f->bk.open(&f->bk_ctx, f->device, mb_w, mb_h, (n_streams + W - 1) / W, slots)) { f->bk_ctx = NULL; rc = -1; break; }
         }
-        for (int s = 0; s < n_streams; s++) if (has[s] && (pics[s]->mb_w != mb_w || pics[s]->mb_h != mb_h)) { rc = fail("stream %d has a different picture size", s); break; }
-        if (rc) break;
-        /* ---- scatter: control blocks, then the packed pictures of the remote streams */
+        if (R->mb_w != mb_w || R->mb_h != mb_h) { rc = fail("the picture size changed inside the job (%dx%d -> %dx%d macroblocks)", mb_w, mb_h, R->mb_w, R->mb_h); break; }
+        if (R->slots > slots) { rc = fail("a stream now needs %d frame slots, the ranks' frame stores were opened with %d (num_ref_frames grew inside the job)", R->slots, slots); break; }
+        /* ---- scatter: control blocks, then the packed pictures of the remote streams.  From here to the end of the gather
+         *      nothing but the transport may end the round. */
         const double e0 = now_s();
+        int rc_local = 0; char err_local[256] = "";
         for (int r = 1; r < W; r++) { memset(&ctrl[r], 0, sizeof ctrl[r]); ctrl[r].mb_w = mb_w; ctrl[r].mb_h = mb_h; ctrl[r].slots = slots; ctrl[r].n_local_streams = (n_streams + W - 1) / W; }
         for (int s = 0; s < n_streams; s++) {
             const int r = s % W;
-            if (!has[s] || r == 0) continue;
-            const size_t need = packed_size(pics[s]);
-            if (need > cap[s]) { free(msg[s]); cap[s] = need + need / 4; msg[s] = (uint8_t *)malloc(cap[s]); if (!msg[s]) { rc = fail("out of memory"); break; } }
-            pack_picture(msg[s], s / W, pics[s]);
-            ctrl[r].bytes[ctrl[r].n++] = (uint32_t)need;
-            S.bytes_scattered += (int64_t)need; S.pictures_remote++;
+            if (!R->len[s] || r == 0) continue;
+            ctrl[r].bytes[ctrl[r].n++] = (uint32_t)R->len[s];
+            S.bytes_scattered += (int64_t)R->len[s]; S.pictures_remote++;
         }
-        if (rc || gb(f)) { rc = -1; break; }
+        if (gb(f)) { rc = -1; break; }
         for (int r = 1; r < W && !rc; r++) if (f->t.send(f->t.ctx, r, &ctrl[r], sizeof ctrl[r])) rc = -1;
         if (ge(f) || rc || gb(f)) { rc = -1; break; }
-        for (int s = 0; s < n_streams && !rc; s++) if (has[s] && s % W) if (f->t.send(f->t.ctx, s % W, msg[s], packed_size(pics[s]))) rc = -1;
+        for (int s = 0; s < n_streams && !rc; s++) if (R->len[s] && s % W) if (f->t.send(f->t.ctx, s % W, R->msg[s], R->len[s])) rc = -1;
         if (ge(f) || rc) { rc = -1; break; }
         S.exchange_seconds += now_s() - e0;
         /* ---- the root's own streams while the workers are busy */
-        for (int s = 0; s < n_streams && !rc; s += W) if (has[s] && f->bk.reconstruct(f->bk_ctx, s / W, pics[s], frames + frame * (size_t)s)) rc = -1;
-        if (rc) break;
-        /* ---- gather */
+        const double r0 = now_s();
+        for (int s = 0; s < n_streams && !rc_local; s += W) {
+            if (!R->len[s]) continue;
+            p264hip_picture_t pic; int ls = 0;
+            if (unpack_picture(R->msg[s], R->len[s], &pic, &ls) || f->bk.reconstruct(f->bk_ctx, ls, &pic, frames + frame * (size_t)s)) rc_local = -1;
+        }
+        if (!rc_local && bk_sync(f)) rc_local = -1;
+        if (rc_local) snprintf(err_local, sizeof err_local, "root: %.240s", g_err);
+        S.reconstruct_seconds += now_s() - r0;
+        /* ---- gather: every worker's status, then the frames of those that have them */
         const double g0 = now_s();
         if (gb(f)) { rc = -1; break; }
-        for (int s = 0; s < n_streams && !rc; s++) if (has[s] && s % W) { if (f->t.recv(f->t.ctx, s % W, frames + frame * (size_t)s, frame)) rc = -1; S.bytes_gathered += (int64_t)frame; }
+        for (int r = 1; r < W && !rc; r++) if (f->t.recv(f->t.ctx, r, &status[r], sizeof status[r])) rc = -1;
+        if (ge(f) || rc || gb(f)) { rc = -1; break; }
+        for (int s = 0; s < n_streams && !rc; s++)
+            if (R->len[s] && s % W && status[s % W].rc == 0) { if (f->t.recv(f->t.ctx, s % W, frames + frame * (size_t)s, frame)) rc = -1; S.bytes_gathered += (int64_t)frame; }
         if (ge(f) || rc) { rc = -1; break; }
         S.exchange_seconds += now_s() - g0;
-        for (int s = 0; s < n_streams; s++) if (has[s]) { S.pictures++; if (on_frame) on_frame(user, s, st[s].pictures - 1, mb_w * 16, mb_h * 16, frames + frame * (size_t)s); }
+        for (int r = 1; r < W && !rc; r++)
+            if (status[r].rc) { status[r].msg[sizeof status[r].msg - 1] = 0; rc = fail("worker %d: %s", r, status[r].msg); }
+        if (!rc && rc_local) rc = fail("%s", err_local);
+        if (rc) break;
+        for (int s = 0; s < n_streams; s++) if (R->len[s]) { S.pictures++; if (on_frame) on_frame(user, s, R->index[s], mb_w * 16, mb_h * 16, frames + frame * (size_t)s); }
         S.rounds++;
+        pthread_mutex_lock(&P.mu); P.ready[k] = 0; pthread_cond_broadcast(&P.cv); pthread_mutex_unlock(&P.mu);
     }
-    /* ---- tell the workers to leave, whatever happened */
+    /* ---- round boundary (or a dead transport): tell the workers to leave */
+    char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep);
     if (ctrl && f->t.send) {
         gb(f);
         for (int r = 1; r < W; r++) { memset(&ctrl[r], 0, sizeof ctrl[r]); ctrl[r].n = FAN_FINISHED; f->t.send(f->t.ctx, r, &ctrl[r], sizeof ctrl[r]); }
         ge(f);
     }
+    if (rc) memcpy(g_err, keep, sizeof keep);
+    if (have_producer) {
+        pthread_mutex_lock(&P.mu); P.stop = 1; P.ready[0] = P.ready[1] = 0; pthread_cond_broadcast(&P.cv); pthread_mutex_unlock(&P.mu);
+        pthread_join(producer, NULL);
+        pthread_mutex_destroy(&P.mu); pthread_cond_destroy(&P.cv);
+    }
     S.seconds = now_s() - t0;
+    S.parse_seconds = P.parse_seconds;
     if (stats) *stats = S;
-    if (st) for (int s = 0; s < n_streams; s++) { if (st[s].parser) p264parse_close(st[s].parser); free(st[s].rbsp); }
-    if (msg) for (int s = 0; s < n_streams; s++) free(msg[s]);
-    free(st); free(ctrl); free(msg); free(cap); free(has); free(frames);
+    if (P.st) for (int s = 0; s < n_streams; s++) { if (P.st[s].parser) p264parse_close(P.st[s].parser); free(P.st[s].rbsp); }
+    for (int k = 0; k < 2; k++) {
+        fan_round_t *R = &P.rounds[k];
+        if (R->msg) for (int s = 0; s < n_streams; s++) free(R->msg[s]);
+        free(R->msg); free(R->cap); free(R->len); free(R->index);
+    }
+    if (frames) frames_free(frames, frames_pinned);
+    free(P.st); free(ctrl); free(status);
     return rc;
 }

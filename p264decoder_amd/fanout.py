@@ -18,12 +18,13 @@ BK_CLOSE = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class Backend(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("open", BK_OPEN), ("reconstruct", BK_RECON), ("close", BK_CLOSE)]
+    _fields_ = [("ctx", C.c_void_p), ("open", BK_OPEN), ("reconstruct", BK_RECON), ("close", BK_CLOSE), ("sync", C.c_void_p)]
 
 
 class FanStats(C.Structure):
     _fields_ = [("pictures", C.c_int64), ("pictures_remote", C.c_int64), ("bytes_scattered", C.c_int64), ("bytes_gathered", C.c_int64),
-                ("seconds", C.c_double), ("parse_seconds", C.c_double), ("exchange_seconds", C.c_double), ("rounds", C.c_int), ("world", C.c_int)]
+                ("seconds", C.c_double), ("parse_seconds", C.c_double), ("exchange_seconds", C.c_double), ("rounds", C.c_int), ("world", C.c_int),
+                ("parse_wait_seconds", C.c_double), ("reconstruct_seconds", C.c_double), ("parse_threads", C.c_int), ("reserved", C.c_int)]
 
 
 FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_uint8))

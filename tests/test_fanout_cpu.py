@@ -34,6 +34,42 @@ def test_fanout_streams_of_different_length(lib, f26, f26_hashes):
     assert all(got[(1, i)] == cif_h[i] and got[(2, i)] == cif_h[i] for i in range(24))
 
 
+@pytest.mark.parametrize("failing_rank", [0, 1, 2])
+def test_fanout_failure_leaves_nobody_waiting(lib, failing_rank):
+    """A backend that fails on purpose in the middle of the job, on the root or on a worker: every rank must come back
+    with an error naming the failure (no rank waits inside a round for a message that never comes), the failing worker's
+    text reaches the root through the round's status block."""
+    cif = synth_cases.stream_bytes("cif_ip")
+    res = fan_helpers.run_job(3, [cif] * 6, 8, True, 30100 + failing_rank + (os.getpid() % 300), fail=(failing_rank, 5), expect_errors=True)
+    assert len(res) == 3
+    by_rank = {}
+    for kind, a, b in res:
+        if kind == "error":
+            by_rank[int(a.split(":")[0])] = a
+        elif kind == "worker":
+            by_rank[a] = "ok"
+        else:
+            by_rank[0] = "ok"
+    assert by_rank[0] != "ok", "the root must report the failure"
+    if failing_rank:
+        assert ("worker %d" % failing_rank) in by_rank[0] and by_rank[failing_rank] != "ok"
+        assert all(by_rank[r] == "ok" for r in (1, 2) if r != failing_rank), by_rank     # the other worker left in step, on FINISHED
+    else:
+        assert "root" in by_rank[0] and by_rank[1] == "ok" and by_rank[2] == "ok", by_rank
+
+
+def test_fanout_rounds_overlap_parse_and_exchange(lib):
+    """Rounds are double-buffered: while round r is exchanged and reconstructed (the scalar oracle takes tens of
+    milliseconds per 1080p picture), round r+1 is parsed.  The exchange side must have waited for the parser for little
+    more than the first round: the rest of the parse time is hidden."""
+    data = synth_cases.stream_bytes("cfg3_1080p_allp")
+    hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    got, st = fan_helpers.run_job(2, [data] * 4, 8, True, 30500 + (os.getpid() % 300))
+    assert st["pictures"] == 32 and all(got[(s, i)] == hashes[i] for s in range(4) for i in range(8))
+    assert st["parse_threads"] == 4 and st["rounds"] == 8
+    assert st["parse_seconds"] > 0 and st["parse_wait_seconds"] < 0.4 * st["parse_seconds"], st
+
+
 def test_fanout_symbols_and_errors(lib):
     from p264decoder_amd.fanout import FanOut
     for sym in ("p264fan_open", "p264fan_root_run", "p264fan_worker_run", "p264fan_close", "p264fan_tcp_transport",

@@ -1,7 +1,8 @@
 """Stream fan-out with the product backend: two processes (ranks) share the box's MI355X, rank 0 parses and scatters over
 the TCP transport, both reconstruct their streams with the HIP kernels, rank 0 gathers - every picture against the real
-reference decoder's hashes.  (The RCCL transport needs one GPU per rank: it is exercised by bench.py on the multi-GPU
-node; the protocol above it is the same.)"""
+reference decoder's hashes.  The RCCL transport needs one GPU per rank: test_rccl_two_ranks runs wherever at least two
+devices are visible (the driver's multi-GPU node) and skips on a one-GPU box; bench.py's fan-out leg reports the same
+exchange at N > 1."""
 import os
 
 import pytest
@@ -57,3 +58,20 @@ def test_rccl_transport_self_exchange(lib):
         assert end(t.ctx) == 0
         assert np.array_equal(a, ra) and np.array_equal(b, rb)
     close(t.ctx)
+
+
+def test_rccl_two_ranks(lib):
+    """The RCCL transport between two DIFFERENT ranks, one GPU each: ncclCommInitRank(world 2), grouped ncclSend / ncclRecv of
+    control blocks, packed pictures, status blocks and planes, with the product backend on both ranks.  Needs two visible
+    devices: skipped on a one-GPU box (two ranks cannot share a device in one RCCL communicator)."""
+    from p264decoder_amd import device_count, fanout
+    if device_count(lib) < 2:
+        pytest.skip("the RCCL fan-out between ranks needs at least two GPUs (have %d)" % device_count(lib))
+    uid = fanout.rccl_unique_id(lib)
+    hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    data = synth_cases.stream_bytes("cfg3_1080p_allp")
+    got, st = fan_helpers.run_job(2, [data] * 4, 6, False, 0, transport=("rccl", uid))
+    assert st["pictures"] == 24 and st["pictures_remote"] == 12 and st["bytes_gathered"] == 12 * 3133440
+    for s in range(4):
+        for i in range(6):
+            assert got[(s, i)] == hashes[i], "stream %d picture %d differs from the reference decoder" % (s, i)

@@ -36,11 +36,14 @@ enum {
     P264_MB_IPCM   = 2,   /* reserved: rejected by the reference (decoder/macroblock.c:510-514) */
     P264_MB_P_L0   = 3,   /* 16x16, 16x8, 8x16 */
     P264_MB_P_8x8  = 4,
-    P264_MB_P_SKIP = 5
+    P264_MB_P_SKIP = 5,
+    P264_MB_B      = 6    /* any inter macroblock of a B picture (B_L0 / B_L1 / B_Bi / B_8x8 / direct / skip): which list(s)
+                             an 8x8 quadrant predicts from is given by ref_idx[] / ref_idx_l1[] (>= 0 = used); the
+                             reference's partition walk is core/macroblock.c:525-631, 677-765 */
 };
 #define P264_MB_IS_INTRA(t) ((t) <= P264_MB_IPCM)
 
-enum { P264_SLICE_P = 0, P264_SLICE_I = 2 };
+enum { P264_SLICE_P = 0, P264_SLICE_B = 1, P264_SLICE_I = 2 };
 
 enum {
     P264HIP_OK = 0,
@@ -98,11 +101,18 @@ typedef struct p264hip_picture {
     const int8_t       *ref_idx;    /* [mb][4] per 8x8 (raster), -1 for intra */
     const uint8_t      *i4modes;    /* [mb][16] Intra4x4PredMode per block in decode order (0..8) */
     const int16_t      *coefs;      /* [n_coef_blocks][16] */
-    /* Reserved, ignored (an earlier version carried a host-built work list here; the motion-compensation work lists are
-     * built on the device now).  Kept so that the structure layout stays what callers were compiled against. */
-    const uint32_t     *quads;
-    uint32_t            n_quads;
-    uint32_t            reserved;
+    /* ---- B pictures only (slice_type == P264_SLICE_B; ignored otherwise).  A quadrant whose list-X index is negative
+     * does not predict from list X and its list-X vectors must be 0 (the loop filter compares them, core/frame.c:565-577);
+     * both indices >= 0 = bi-prediction: the two predictions are combined as the reference does (core/macroblock.c:543-583):
+     * weighted_bipred == 0: (p0 + p1 + 1) >> 1 (core/mc.c:76-88); != 0: clip((p0 * w + p1 * (64 - w) + 32) >> 6) with
+     * w = bipred_weight[ref_idx * 16 + ref_idx_l1] (core/mc.c:106-132; the implicit weights of core/macroblock.c:1400-1430,
+     * computed by the host from the picture order counts). */
+    const int16_t      *mv_l1;      /* [mb][16][2] */
+    const int8_t       *ref_idx_l1; /* [mb][4] */
+    int32_t             n_ref_l1;   /* list-1 length */
+    int32_t             weighted_bipred;
+    int32_t             ref_slot_l1[P264HIP_MAX_REFS];
+    int16_t             bipred_weight[P264HIP_MAX_REFS * P264HIP_MAX_REFS];   /* [ref_idx][ref_idx_l1], -64 .. 128 */
 } p264hip_picture_t;
 
 typedef struct p264hip_ctx p264hip_ctx;
@@ -153,12 +163,6 @@ int  p264hip_write_frame(p264hip_ctx *ctx, int stream, int slot,
 int  p264hip_submit_async(p264hip_ctx *ctx, int stream, const p264hip_picture_t *pic);
 int  p264hip_read_frame_async(p264hip_ctx *ctx, int stream, int slot,
                               uint8_t *y, int y_stride, uint8_t *u, uint8_t *v, int c_stride);
-
-/* Bi-prediction combine (first piece of the Main-profile path; pf->avg[] / pf->avg_weight[] of the
- * reference, core/mc.c:76-155): frame dst_slot of the stream becomes the sample-wise combination of itself and frame
- * src_slot - weighted = 0: (dst + src + 1) >> 1; weighted = 1: clip((dst * weight1 + src * (64 - weight1) + 32) >> 6), the
- * implicit-weight form (log2 denominator 5, offset 0).  Asynchronous. */
-int  p264hip_bipred_frames(p264hip_ctx *ctx, int stream, int dst_slot, int src_slot, int weighted, int weight1);
 
 /* Timing hooks used by bench.py: HIP events on the context's own stream.
  * kernel index: 0 inter (MC + residual), 1 intra, 2 deblock, 3 whole reconstruct call. */

@@ -17,8 +17,9 @@
  * [4] chroma edge lines with bS>0, [5] of those modified, [6] macroblock edges with bS>0 whose two macroblocks have
  * different QPs (the filter parameters come from the mean), [7] dequantised luma/chroma AC coefficients whose int16 store
  * wrapped (A-Q8). */
-static long long g_stats[8];
-void oracle_stats_reset(void) { memset(g_stats, 0, sizeof g_stats); }
+static long long g_stats[8], g_bipred_blocks;
+void oracle_stats_reset(void) { memset(g_stats, 0, sizeof g_stats); g_bipred_blocks = 0; }
+long long oracle_bipred_blocks(void) { return g_bipred_blocks; }
 void oracle_stats_get(long long out[8]) { memcpy(out, g_stats, sizeof g_stats); }
 
 static inline int clip3(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
@@ -470,18 +471,51 @@ static void recon_chroma_residual(const rc_t *r, const p264hip_mb_t *m, int mbx,
 
 static void recon_inter(const rc_t *r, const p264hip_mb_t *m, int mbx, int mby, int mbi)
 {   /* p264_mb_mc: core/macroblock.c:506-524,633-676.  Done per 4x4 block: each sample depends only
-       on its own motion vector, so this equals the reference's per-partition calls. */
+       on its own motion vector, so this equals the reference's per-partition calls.
+       B pictures: p264_mb_mc_1xywh / p264_mb_mc_01xywh (core/macroblock.c:525-583): a quadrant predicts from list X iff its
+       list-X index is >= 0; with both, the list-0 prediction lands in the picture, the list-1 prediction in a temporary,
+       and pf->avg / pf->avg_weight combine them (weight = bipred_weight[ref0][ref1], applied to the list-0 samples). */
     const p264hip_picture_t *pic = r->pic;
+    const int isB = pic->slice_type == P264_SLICE_B;
     for (int b = 0; b < 16; b++) {
-        int bx = b & 3, by = b >> 2;
-        int ri = pic->ref_idx[mbi*4 + (by >> 1)*2 + (bx >> 1)];
-        if (ri < 0 || ri >= pic->n_ref) ri = 0;
-        int slot = pic->ref_slot[ri];
-        int mvx = pic->mv[(mbi*16 + b)*2], mvy = pic->mv[(mbi*16 + b)*2 + 1];
+        int bx = b & 3, by = b >> 2, q = (by >> 1)*2 + (bx >> 1);
+        int r0 = pic->ref_idx[mbi*4 + q], r1 = isB ? pic->ref_idx_l1[mbi*4 + q] : -1;
         int X = mbx*16 + bx*4, Y = mby*16 + by*4;
-        oracle_mc_luma(r->planes[slot*3], r->w, r->h, X, Y, mvx, mvy, 4, 4, r->y + Y*r->w + X, r->w);
-        oracle_mc_chroma(r->planes[slot*3+1], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, r->u + (Y/2)*r->cw + X/2, r->cw);
-        oracle_mc_chroma(r->planes[slot*3+2], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, r->v + (Y/2)*r->cw + X/2, r->cw);
+        uint8_t *dy = r->y + Y*r->w + X, *du = r->u + (Y/2)*r->cw + X/2, *dv = r->v + (Y/2)*r->cw + X/2;
+        if (!isB || r0 >= 0) {
+            int ri = r0;
+            if (ri < 0 || ri >= pic->n_ref) ri = isB ? clip3(ri, 0, pic->n_ref - 1) : 0;
+            int slot = pic->ref_slot[ri];
+            int mvx = pic->mv[(mbi*16 + b)*2], mvy = pic->mv[(mbi*16 + b)*2 + 1];
+            oracle_mc_luma(r->planes[slot*3], r->w, r->h, X, Y, mvx, mvy, 4, 4, dy, r->w);
+            oracle_mc_chroma(r->planes[slot*3+1], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, du, r->cw);
+            oracle_mc_chroma(r->planes[slot*3+2], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, dv, r->cw);
+        }
+        if (isB && r1 >= 0) {
+            int ri = clip3(r1, 0, pic->n_ref_l1 - 1), slot = pic->ref_slot_l1[ri];
+            int mvx = pic->mv_l1[(mbi*16 + b)*2], mvy = pic->mv_l1[(mbi*16 + b)*2 + 1];
+            if (r0 < 0) {                                                    /* list 1 only: straight into the picture */
+                oracle_mc_luma(r->planes[slot*3], r->w, r->h, X, Y, mvx, mvy, 4, 4, dy, r->w);
+                oracle_mc_chroma(r->planes[slot*3+1], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, du, r->cw);
+                oracle_mc_chroma(r->planes[slot*3+2], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, dv, r->cw);
+            } else {
+                uint8_t ty[16], tu[4], tv[4];
+                int w1 = pic->bipred_weight[clip3(r0, 0, pic->n_ref - 1) * P264HIP_MAX_REFS + ri];
+                oracle_mc_luma(r->planes[slot*3], r->w, r->h, X, Y, mvx, mvy, 4, 4, ty, 4);
+                oracle_mc_chroma(r->planes[slot*3+1], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, tu, 2);
+                oracle_mc_chroma(r->planes[slot*3+2], r->cw, r->ch, X/2, Y/2, mvx, mvy, 2, 2, tv, 2);
+                if (pic->weighted_bipred) {
+                    oracle_bipred_weight(dy, r->w, ty, 4, 4, 4, w1);
+                    oracle_bipred_weight(du, r->cw, tu, 2, 2, 2, w1);
+                    oracle_bipred_weight(dv, r->cw, tv, 2, 2, 2, w1);
+                } else {
+                    oracle_bipred_avg(dy, r->w, ty, 4, 4, 4);
+                    oracle_bipred_avg(du, r->cw, tu, 2, 2, 2);
+                    oracle_bipred_avg(dv, r->cw, tv, 2, 2, 2);
+                }
+                g_bipred_blocks++;                                           /* a bi-predicted 4x4 block */
+            }
+        }
     }
     for (int i = 0; i < 16; i++)
         if (m->coef_mask & (1u << i)) residual_luma_4x4(r, m, mbx, mby, i);
@@ -621,6 +655,11 @@ int oracle_deblock_picture(const p264hip_picture_t *pic, uint8_t **planes)
                             int rp = pic->ref_idx[mbi*4 + (y >> 1)*2 + (x >> 1)], rq = pic->ref_idx[nbi*4 + (yn >> 1)*2 + (xn >> 1)];
                             const int16_t *vp = pic->mv + (mbi*16 + y*4 + x)*2, *vq = pic->mv + (nbi*16 + yn*4 + xn)*2;
                             bS[i] = (rp != rq || iabs(vp[0] - vq[0]) >= 4 || iabs(vp[1] - vq[1]) >= 4) ? 1 : 0;
+                            if (pic->slice_type == P264_SLICE_B && !bS[i]) {             /* the loop over l, core/frame.c:565-577 */
+                                rp = pic->ref_idx_l1[mbi*4 + (y >> 1)*2 + (x >> 1)]; rq = pic->ref_idx_l1[nbi*4 + (yn >> 1)*2 + (xn >> 1)];
+                                vp = pic->mv_l1 + (mbi*16 + y*4 + x)*2; vq = pic->mv_l1 + (nbi*16 + yn*4 + xn)*2;
+                                bS[i] = (rp != rq || iabs(vp[0] - vq[0]) >= 4 || iabs(vp[1] - vq[1]) >= 4) ? 1 : 0;
+                            }
                         }
                     }
                     int qp = m->qp, qpn = n->qp;

@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libp264amd.so")
 MAX_REFS = 16
 NKERNELS = 4
 
-MB_I4x4, MB_I16x16, MB_IPCM, MB_P_L0, MB_P_8x8, MB_P_SKIP = range(6)
-SLICE_P, SLICE_I = 0, 2
+MB_I4x4, MB_I16x16, MB_IPCM, MB_P_L0, MB_P_8x8, MB_P_SKIP, MB_B = range(7)
+SLICE_P, SLICE_B, SLICE_I = 0, 1, 2
 COEF_LUMA_DC = 1 << 24
 COEF_CHROMA_DC = 1 << 25
 AVAIL_LEFT, AVAIL_TOP, AVAIL_TOPRIGHT, AVAIL_TOPLEFT = 1, 2, 4, 8
@@ -41,7 +41,8 @@ class Picture(C.Structure):
         ("n_coef_blocks", C.c_uint32), ("frame_num", C.c_uint32),
         ("mb", C.POINTER(MbInfo)), ("mv", C.POINTER(C.c_int16)), ("ref_idx", C.POINTER(C.c_int8)),
         ("i4modes", C.POINTER(C.c_uint8)), ("coefs", C.POINTER(C.c_int16)),
-        ("quads", C.POINTER(C.c_uint32)), ("n_quads", C.c_uint32), ("reserved", C.c_uint32),
+        ("mv_l1", C.POINTER(C.c_int16)), ("ref_idx_l1", C.POINTER(C.c_int8)), ("n_ref_l1", C.c_int32), ("weighted_bipred", C.c_int32),
+        ("ref_slot_l1", C.c_int32 * MAX_REFS), ("bipred_weight", C.c_int16 * (MAX_REFS * MAX_REFS)),
     ]
 
 

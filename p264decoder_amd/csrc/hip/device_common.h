@@ -23,6 +23,12 @@ struct PicDev {
     uint32_t store_bytes, dst_off; // dst - store
     int32_t n_ref, slice_type, chroma_qp_offset, deblock, alpha_off, beta_off;
     uint32_t ref_off[P264HIP_MAX_REFS];   // reference frame k - store, list-0 order (entries >= n_ref repeat entry 0)
+    // B pictures (slice_type == P264_SLICE_B) only:
+    const int          *mv_l1;     // packed like mv, [mb][16]
+    const int8_t       *ref_idx_l1;// [mb][4]; a quadrant predicts from list X iff its list-X index is >= 0
+    const int16_t      *bipred_w;  // [16][16] weight of the list-0 prediction (used when weighted != 0)
+    int32_t n_ref_l1, weighted;
+    uint32_t ref_off_l1[P264HIP_MAX_REFS];
 };
 
 // Geometry shared by every picture of a context.

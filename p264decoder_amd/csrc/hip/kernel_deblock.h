@@ -54,6 +54,9 @@ __device__ __forceinline__ int bs_motion(int vp, int vq, int rp, int rq)
     return (int)(rp != rq) | (int)(abs(dx) >= 4) | (int)(abs(dy) >= 4);
 }
 
+// TWO_LISTS: the batch holds B pictures - the motion test runs over both lists, as the reference's loop over l does
+// (core/frame.c:565-577; list by list, on the list INDICES, unused list = index -1 and zero vectors)
+template <bool TWO_LISTS>
 __global__ __launch_bounds__(256)
 void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info, uint32_t inv_mbw)
 {
@@ -87,6 +90,22 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
     const int mv[16] = { (int)m0.x, (int)m0.y, (int)m0.z, (int)m0.w, (int)m1.x, (int)m1.y, (int)m1.z, (int)m1.w,
                          (int)m2.x, (int)m2.y, (int)m2.z, (int)m2.w, (int)m3.x, (int)m3.y, (int)m3.z, (int)m3.w };
     const int mvTop[4] = { (int)mT.x, (int)mT.y, (int)mT.z, (int)mT.w };
+    // list 1 of a B picture (everything zero otherwise: the extra test below is then always false)
+    int mv1[16] = { 0 }, mv1Top[4] = { 0 }, mv1L[4] = { 0 };
+    uint32_t refs1 = 0, refs1L = 0, refs1T = 0;
+    if (TWO_LISTS && pd->slice_type == P264_SLICE_B) {
+        const int *m1 = pd->mv_l1;
+        const uint4 a0 = gload4(m1 + mbi * 16), a1 = gload4(m1 + mbi * 16 + 4), a2 = gload4(m1 + mbi * 16 + 8), a3 = gload4(m1 + mbi * 16 + 12);
+        const uint4 aT = gload4(m1 + ti * 16 + 12);
+        const AS1 int *m1g = glob(m1);
+        mv1L[0] = m1g[li * 16 + 3]; mv1L[1] = m1g[li * 16 + 7]; mv1L[2] = m1g[li * 16 + 11]; mv1L[3] = m1g[li * 16 + 15];
+        refs1 = gload1(pd->ref_idx_l1 + mbi * 4); refs1L = gload1(pd->ref_idx_l1 + li * 4); refs1T = gload1(pd->ref_idx_l1 + ti * 4);
+        const int t[16] = { (int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w,
+                            (int)a2.x, (int)a2.y, (int)a2.z, (int)a2.w, (int)a3.x, (int)a3.y, (int)a3.z, (int)a3.w };
+#pragma unroll
+        for (int i = 0; i < 16; i++) mv1[i] = t[i];
+        mv1Top[0] = (int)aT.x; mv1Top[1] = (int)aT.y; mv1Top[2] = (int)aT.z; mv1Top[3] = (int)aT.w;
+    }
 
     const int m_type = rec.x & 255, m_qp = (rec.x >> 8) & 255, m_edges = (rec.w >> 8) & 255;
     const unsigned mmask = rec.y, lmask = recL.y, tmask = recT.y;
@@ -111,6 +130,10 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
                 const int vq = mv[y * 4 + x], vp = !outer ? mv[yn * 4 + xn] : dir == 0 ? mL[y] : mvTop[x];
                 const int rq = ref_of(refs, x, y), rp = ref_of(!outer ? refs : dir == 0 ? refsL : refsT, xn, yn);
                 int bS = bs_motion(vp, vq, rp, rq);
+                if (TWO_LISTS) {
+                    const int wq = mv1[y * 4 + x], wp = !outer ? mv1[yn * 4 + xn] : dir == 0 ? mv1L[y] : mv1Top[x];
+                    bS |= bs_motion(wp, wq, ref_of(!outer ? refs1 : dir == 0 ? refs1L : refs1T, xn, yn), ref_of(refs1, x, y));
+                }
                 if (((mmask >> blk_at(x, y)) | (n_mask >> blk_at(xn, yn))) & 1) bS = 2;
                 if (m_intra | n_intra) bS = outer ? 4 : 3;
                 if (!enabled) bS = 0;

@@ -41,12 +41,17 @@
 // work lists
 // ------------------------------------------------------------------------------------------
 enum { PC_COPY = 0, PC_H = 1, PC_V = 2, PC_DIAG = 3, PC_C = 4, PC_CH = 5, PC_CV = 6, PC_GEN = 7 };
+// PC_GEN | MCY_CLAMP: the 4x4 blocks of the quadrant have different vectors (sub-8x8 partitions), every lane fetches its own
+// window.  PC_GEN without MCY_CLAMP: the macroblock belongs to a B picture and predicts from list 1 somewhere: every lane
+// looks up which lists its quadrant uses, predicts from each of them like the class above and combines the two
+// (p264_mb_mc_1xywh / _01xywh, core/macroblock.c:525-583).
 #define MCY_CLAMP   8               // luma key bits: phase class | window not inside the picture | item has coded luma blocks
 #define MCY_RESID   16
 #define MCY_KEYS    32
 #define MCC_CLAMP   1               // chroma key bits: window not inside the picture (quadrant items: or vectors differing inside) | residual
 #define MCC_RESID   2
-#define MCC_KEYS    4
+#define MCC_BI      4               // | macroblock of a B picture that predicts from list 1 somewhere (quadrant items only)
+#define MCC_KEYS    8
 enum { ML_YM = 0, ML_YQ = 1, ML_CM = 2, ML_CQ = 3, ML_LISTS = 4 };      // luma macroblocks, luma quadrants, chroma macroblocks, chroma quadrants
 #define MC_MAX_BANDS 32
 #define MC_SORT_THREADS 1024
@@ -131,6 +136,23 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
         ri[q] = (int)(int8_t)(refs >> (8 * q));
         if (ri[q] < 0 || ri[q] >= n_ref) ri[q] = 0;        // negative or past the list: entry 0, as the reference's flat lists
         k.info |= (uint32_t)ri[q] << (8 + 4 * q);
+    }
+    // B pictures: a macroblock that uses list 1 anywhere (or lacks list 0 somewhere) goes to the generic two-list class,
+    // all four quadrants of it; one that predicts from list 0 only is an ordinary P-type macroblock for this stage
+    bool two_lists = false;
+    if (pd->slice_type == P264_SLICE_B && (k.info & MCMB_INTER)) {
+        const uint32_t refs1 = gload1(pd->ref_idx_l1 + mbi * 4);
+        two_lists = ((~refs1 | refs) & 0x80808080u) != 0;                      // some list-1 index >= 0, or some list-0 index < 0
+    }
+    if (two_lists) {
+        const int kc = band * MCC_KEYS + MCC_BI + (cc ? MCC_RESID : 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ky = band * MCY_KEYS + (PC_GEN | (((mask >> (4 * q)) & 15) ? MCY_RESID : 0));
+            k.key[q] = (uint32_t)ky | (uint32_t)kc << 16;
+            k.vec[q] = 0;
+        }
+        return k;
     }
     const uint32_t v0 = m0.x;
     const uint32_t diff = (m0.y ^ v0) | (m0.z ^ v0) | (m0.w ^ v0) | (m1.x ^ v0) | (m1.y ^ v0) | (m1.z ^ v0) | (m1.w ^ v0) | (m2.x ^ v0) | (m2.y ^ v0)
@@ -225,7 +247,7 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
     const int b_ym = 0, b_yq = nky, b_cm = 2 * nky, b_cq = 2 * nky + nkc, b_end = 2 * nky + 2 * nkc;     // key slots of the four lists
     const McSortCtx ctx = { pd, cnt, pos, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[ML_YM], ml.off_list[ML_YQ], ml.off_list[ML_CM], ml.off_list[ML_CQ] };
     const int tid = threadIdx.x;
-    if (pd->slice_type != P264_SLICE_P) {                 // wave-uniform
+    if (pd->slice_type == P264_SLICE_I) {                 // wave-uniform
         if (tid < ML_LISTS) gstore1(out + tid, 0);
         return;
     }
@@ -461,8 +483,8 @@ __device__ __forceinline__ uint32_t tap_v4(uint32_t r0, uint32_t r1, uint32_t r2
 }
 
 // ------------------------------------------------------------------------------------------
-// bi-prediction (first piece of the B-slice path): the two ways the reference combines two predictions,
-// four samples at a time.  pixel_avg_wxh (core/mc.c:76-88) is the byte-parallel rounding average above; the implicit-weight
+// bi-prediction (B pictures): the two ways the reference combines two predictions, four samples at a
+// time; used by the two-list class of the luma and chroma quadrant kernels.  pixel_avg_wxh (core/mc.c:76-88) is the byte-parallel rounding average above; the implicit-weight
 // form pixel_avg_weight_wxh (core/mc.c:106-132): clip((a * w1 + b * (64 - w1) + 32) >> 6), weights from -64 to 128.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bipred_avg4(uint32_t a, uint32_t b) { return avg4(a, b); }
@@ -474,15 +496,6 @@ __device__ __forceinline__ uint32_t bipred_weight4(uint32_t a, uint32_t b, int w
     for (int i = 0; i < 4; i++) v[i] = (int)((a >> (8 * i)) & 255u) * w1 + (int)((b >> (8 * i)) & 255u) * w2 + 32;
     return round_pack4<6>(v);
 }
-// whole frames (every dword of the strip layout is four horizontally adjacent samples of one plane)
-__global__ void k_bipred_frames(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, int n_dwords, int weighted, int w1)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_dwords) return;
-    const uint32_t a = dst[i], b = src[i];
-    dst[i] = weighted ? bipred_weight4(a, b, w1) : bipred_avg4(a, b);
-}
-
 // ---- the seven phase classes: out[y] = the four samples of row y of the lane's 4x4 block -----------------------------
 // (ix, iy) = integer position of the block's first sample in the reference, (fx, fy) = quarter-pel phase.
 template <class W> __device__ __forceinline__ void mc_copy(uint32_t (&out)[4], const W &w, int ix, int iy)
@@ -750,19 +763,45 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
             const int16_t *cf = pd->coefs + ((size_t)e.w + coef_slot(mask, blk)) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
         }
-        out[0] = out[1] = out[2] = out[3] = 0;
-        const GWin w = { rs, roff, g };
-        const int mine = phase_class(fx, fy);
+        // one prediction per lane from reference frame `ro` with vector `mv` (lanes with use = false are left alone)
+        auto predict = [&](uint32_t ro, int mv, bool use, uint32_t (&o4)[4]) {
+            const GWin w = { rs, ro, g };
+            const int px = mbx * 16 + bx * 4 + (mv_x(mv) >> 2), py = mby * 16 + by * 4 + (mv_y(mv) >> 2);
+            const int qx = mv_x(mv) & 3, qy = mv_y(mv) & 3;
+            const int mine = phase_class(qx, qy);
+            o4[0] = o4[1] = o4[2] = o4[3] = 0;
 #pragma unroll 1
-        for (int c = 0; c < 7; c++) {
-            if (__ballot(valid && mine == c) == 0) continue;
-            // (the window addresses do not depend on c: without this the compiler computes the clamped addresses of every
-            // class in front of the loop and keeps all of them alive - far more registers than the rest of the kernel needs)
-            int jx = ix, jy = iy;
-            asm volatile("" : "+v"(jx), "+v"(jy));
-            uint32_t o[4];
-            mc_luma_class(c, o, w, jx, jy, fx, fy);
-            if (mine == c) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; }
+            for (int c = 0; c < 7; c++) {
+                if (__ballot(use && mine == c) == 0) continue;
+                // (the window addresses do not depend on c: without this the compiler computes the clamped addresses of every
+                // class in front of the loop and keeps all of them alive - far more registers than the rest of the kernel needs)
+                int jx = px, jy = py;
+                asm volatile("" : "+v"(jx), "+v"(jy));
+                uint32_t o[4];
+                mc_luma_class(c, o, w, jx, jy, qx, qy);
+                if (mine == c) { o4[0] = o[0]; o4[1] = o[1]; o4[2] = o[2]; o4[3] = o[3]; }
+            }
+        };
+        if (key & MCY_CLAMP) predict(roff, mvp, valid, out);
+        else {
+            // B picture, two lists (core/macroblock.c:525-583): which lists the lane's quadrant uses, a prediction from each,
+            // then pixel_avg / pixel_avg_weight (core/mc.c:76-132)
+            const int mbi = mby * g.mb_w + mbx;
+            const int r0 = (int)glob(pd->ref_idx)[mbi * 4 + q], r1 = (int)glob(pd->ref_idx_l1)[mbi * 4 + q];
+            const bool u0 = valid && r0 >= 0, u1 = valid && r1 >= 0;
+            const int r0c = min(max(r0, 0), pd->n_ref - 1), r1c = min(max(r1, 0), pd->n_ref_l1 - 1);
+            const int mv1 = (int)gload1(pd->mv_l1 + mbi * 16 + by * 4 + bx);
+            const uint32_t ro0 = glob(pd->ref_off)[r0c], ro1 = glob(pd->ref_off_l1)[r1c];
+            int wgt = 32;
+            if (pd->weighted) wgt = (int)glob(pd->bipred_w)[r0c * P264HIP_MAX_REFS + r1c];
+            uint32_t p0[4], p1[4];
+            predict(ro0, mvp, u0, p0);
+            predict(ro1, mv1, u1, p1);
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                const uint32_t both = pd->weighted ? bipred_weight4(p0[y], p1[y], wgt) : bipred_avg4(p0[y], p1[y]);
+                out[y] = (u0 && u1) ? both : u0 ? p0[y] : p1[y];
+            }
         }
     }
     // ---- residual (decoder/macroblock.c:839-847) ----
@@ -899,7 +938,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     uint4 la = make_uint4(0, 0, 0, 0), lb = la; uint2 dcl = make_uint2(0, 0);
     // ---- prediction ----
     uint32_t out[4];
-    const bool staged = MB || !(key & MCC_CLAMP);
+    const bool staged = MB || !(key & (MCC_CLAMP | MCC_BI));
     if (staged) {
         // the item's window goes through LDS like the luma windows: 16-byte pieces (8 U, 8 V) of consecutive rows
         const int mvx = mv_x((int)e.y), mvy = mv_y((int)e.y);
@@ -965,22 +1004,43 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
         }
         const int b0 = (q >> 1) * 8 + (q & 1) * 2;
         const int mbi = mby * g.mb_w + mbx;
-        const uint2 va = gload2(pd->mv + mbi * 16 + b0), vb = gload2(pd->mv + mbi * 16 + b0 + 4);
-        const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
-        const int v4[4] = { (int)va.x, (int)va.y, (int)vb.x, (int)vb.y };
-        out[0] = out[1] = out[2] = out[3] = 0;
+        // the lane's 4x4 chroma block from reference frame `ro`, the vectors of the quadrant's four luma blocks at `mvs`
+        auto predict = [&](uint32_t ro, const int *mvs, bool use, uint32_t (&o4)[4]) {
+            const uint2 va = gload2(mvs + mbi * 16 + b0), vb = gload2(mvs + mbi * 16 + b0 + 4);
+            const bool uniform = va.x == va.y && va.x == vb.x && va.x == vb.y;
+            const int v4[4] = { (int)va.x, (int)va.y, (int)vb.x, (int)vb.y };
+            o4[0] = o4[1] = o4[2] = o4[3] = 0;
 #pragma unroll 1
-        for (int sb = 0; sb < 4; sb++) {
-            if (sb > 0 && __ballot(valid && !uniform) == 0) break;
-            const int mv = sb == 0 ? v4[0] : sb == 1 ? v4[1] : sb == 2 ? v4[2] : v4[3];
-            uint32_t o[4];
-            mc_chroma_clamped(o, rs, roff, g, p, CX + (mv_x(mv) >> 3), CY + (mv_y(mv) >> 3), mv_x(mv) & 7, mv_y(mv) & 7);
-            if (uniform) { if (sb == 0) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; } }
-            else {
-                const uint32_t m = (sb & 1) ? 0xffff0000u : 0x0000ffffu;
-                const int r0 = (sb >> 1) * 2;
-                out[0] = r0 == 0 ? (out[0] & ~m) | (o[0] & m) : out[0]; out[1] = r0 == 0 ? (out[1] & ~m) | (o[1] & m) : out[1];
-                out[2] = r0 == 2 ? (out[2] & ~m) | (o[2] & m) : out[2]; out[3] = r0 == 2 ? (out[3] & ~m) | (o[3] & m) : out[3];
+            for (int sb = 0; sb < 4; sb++) {
+                if (sb > 0 && __ballot(use && !uniform) == 0) break;
+                const int mv = sb == 0 ? v4[0] : sb == 1 ? v4[1] : sb == 2 ? v4[2] : v4[3];
+                uint32_t o[4];
+                mc_chroma_clamped(o, rs, ro, g, p, CX + (mv_x(mv) >> 3), CY + (mv_y(mv) >> 3), mv_x(mv) & 7, mv_y(mv) & 7);
+                if (uniform) { if (sb == 0) { o4[0] = o[0]; o4[1] = o[1]; o4[2] = o[2]; o4[3] = o[3]; } }
+                else {
+                    const uint32_t m = (sb & 1) ? 0xffff0000u : 0x0000ffffu;
+                    const int r0 = (sb >> 1) * 2;
+                    o4[0] = r0 == 0 ? (o4[0] & ~m) | (o[0] & m) : o4[0]; o4[1] = r0 == 0 ? (o4[1] & ~m) | (o[1] & m) : o4[1];
+                    o4[2] = r0 == 2 ? (o4[2] & ~m) | (o[2] & m) : o4[2]; o4[3] = r0 == 2 ? (o4[3] & ~m) | (o[3] & m) : o4[3];
+                }
+            }
+        };
+        if (!(key & MCC_BI)) predict(roff, pd->mv, valid, out);
+        else {
+            // B picture, two lists: as in mc_luma_body
+            const int r0 = (int)glob(pd->ref_idx)[mbi * 4 + q], r1 = (int)glob(pd->ref_idx_l1)[mbi * 4 + q];
+            const bool u0 = valid && r0 >= 0, u1 = valid && r1 >= 0;
+            const int r0c = min(max(r0, 0), pd->n_ref - 1), r1c = min(max(r1, 0), pd->n_ref_l1 - 1);
+            const uint32_t ro0 = glob(pd->ref_off)[r0c], ro1 = glob(pd->ref_off_l1)[r1c];
+            int wgt = 32;
+            if (pd->weighted) wgt = (int)glob(pd->bipred_w)[r0c * P264HIP_MAX_REFS + r1c];
+            uint32_t p0[4], p1[4];
+            predict(ro0, pd->mv, u0, p0);
+            predict(ro1, pd->mv_l1, u1, p1);
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                const uint32_t both = pd->weighted ? bipred_weight4(p0[y], p1[y], wgt) : bipred_avg4(p0[y], p1[y]);
+                out[y] = (u0 && u1) ? both : u0 ? p0[y] : p1[y];
             }
         }
     }

@@ -37,7 +37,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct PicSlot {                       // one device-resident parsed picture
     uint8_t *dev = nullptr;
     size_t   cap = 0;                  // bytes allocated
-    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_coef = 0;
+    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_coef = 0, off_l1 = 0;   // off_l1: list-1 vectors, indices, weight table (B pictures)
+    size_t   bytes = 0;                // bytes in use
     p264hip_picture_t meta;            // scalar fields only; pointers unused
     bool     valid = false;
 };
@@ -189,7 +190,17 @@ static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
     if (p->n_ref < 0 || p->n_ref > P264HIP_MAX_REFS) return fail(P264HIP_EINVAL, "n_ref %d out of range", p->n_ref);
     for (int i = 0; i < p->n_ref; i++)
         if (p->ref_slot[i] < 0 || p->ref_slot[i] >= c->slots) return fail(P264HIP_EINVAL, "ref_slot[%d]=%d out of range", i, p->ref_slot[i]);
+    if (p->slice_type != P264_SLICE_P && p->slice_type != P264_SLICE_B && p->slice_type != P264_SLICE_I) return fail(P264HIP_EINVAL, "slice_type %d", p->slice_type);
     if (p->slice_type == P264_SLICE_P && p->n_ref < 1) return fail(P264HIP_EINVAL, "P picture without reference");
+    if (p->slice_type == P264_SLICE_B) {
+        if (p->n_ref < 1 || p->n_ref_l1 < 1 || p->n_ref_l1 > P264HIP_MAX_REFS) return fail(P264HIP_EINVAL, "B picture: list lengths %d / %d", p->n_ref, p->n_ref_l1);
+        if (!p->mv_l1 || !p->ref_idx_l1) return fail(P264HIP_EINVAL, "B picture without list-1 arrays");
+        for (int i = 0; i < p->n_ref_l1; i++)
+            if (p->ref_slot_l1[i] < 0 || p->ref_slot_l1[i] >= c->slots) return fail(P264HIP_EINVAL, "ref_slot_l1[%d]=%d out of range", i, p->ref_slot_l1[i]);
+        if (p->weighted_bipred)
+            for (int i = 0; i < P264HIP_MAX_REFS * P264HIP_MAX_REFS; i++)
+                if (p->bipred_weight[i] < -64 || p->bipred_weight[i] > 128) return fail(P264HIP_EINVAL, "bipred_weight[%d]=%d out of range (-64 .. 128)", i, p->bipred_weight[i]);
+    }
     if (!p->mb || !p->mv || !p->ref_idx || !p->i4modes || (p->n_coef_blocks && !p->coefs)) return fail(P264HIP_EINVAL, "null picture array");
     // every macroblock's packed blocks must lie inside coefs[] (the kernels index it without further checks)
     const int n_mb = c->g.n_mb;
@@ -212,7 +223,9 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
     size_t off_ref = off_mv + align_up(n * 64, 256);
     size_t off_i4 = off_ref + align_up(n * 4, 256);
     size_t off_coef = off_i4 + align_up(n * 16, 256);
-    size_t need = off_coef + align_up((size_t)p->n_coef_blocks * 32, 256) + 256;
+    const bool isB = p->slice_type == P264_SLICE_B;
+    size_t off_l1 = off_coef + align_up((size_t)p->n_coef_blocks * 32, 256) + 256;
+    size_t need = off_l1 + (isB ? align_up(n * 64, 256) + align_up(n * 4, 256) + 512 : 0);
     if (need > s.cap) {
         if (s.dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(s.dev)); s.dev = nullptr; s.cap = 0; }
         size_t cap = need + need / 4;
@@ -220,7 +233,12 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
         if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for picture input: %s", cap, hipGetErrorString(e));
         s.cap = cap;
     }
-    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_coef = off_coef;
+    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_coef = off_coef; s.off_l1 = off_l1; s.bytes = need;
+    if (isB) {
+        HIPCHK(hipMemcpyAsync(s.dev + off_l1, p->mv_l1, n * 64, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.dev + off_l1 + align_up(n * 64, 256), p->ref_idx_l1, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.dev + off_l1 + align_up(n * 64, 256) + align_up(n * 4, 256), p->bipred_weight, sizeof p->bipred_weight, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(s.dev + off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(s.dev + off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -228,7 +246,7 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
     if (p->n_coef_blocks)
         HIPCHK(hipMemcpyAsync(s.dev + off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
     s.meta = *p;
-    s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr; s.meta.quads = nullptr; s.meta.n_quads = 0;
+    s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr; s.meta.mv_l1 = nullptr; s.meta.ref_idx_l1 = nullptr;
     s.valid = true;
     return 0;
 }
@@ -283,7 +301,7 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
         return fail(P264HIP_EINVAL, "p264hip_clone_picture: bad slots %d <- %d", dst, src);
     HIPCHK(hipSetDevice(c->device));
     PicSlot &d = c->pics[(size_t)dst], &s = c->pics[(size_t)src];
-    size_t need = s.off_coef + align_up((size_t)s.meta.n_coef_blocks * 32, 256) + 256;
+    size_t need = s.bytes;
     if (need > d.cap) {
         if (d.dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(d.dev)); d.dev = nullptr; d.cap = 0; }
         hipError_t e = hipMalloc((void **)&d.dev, need);
@@ -291,7 +309,7 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
         d.cap = need;
     }
     HIPCHK(hipMemcpyAsync(d.dev, s.dev, need, hipMemcpyDeviceToDevice, c->stream));
-    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef;
+    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef; d.off_l1 = s.off_l1; d.bytes = s.bytes;
     d.meta = s.meta; d.valid = true;
     return P264HIP_OK;
 }
@@ -333,7 +351,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     const int r = c->ring; c->ring = (c->ring + 1) % BATCH_RING;
     HIPCHK(hipEventSynchronize(c->batch_free[r]));            // the copy that last used this staging buffer is done
     PicDev *hb = c->h_batch[r];
-    bool any_p = false;
+    bool any_p = false, any_b = false;                      // any picture with inter macroblocks / any B picture
     for (int i = 0; i < n; i++) {                          // two pictures of one call must not share a stream: they would race on its frames
         const int st = streams[i];
         if (st < 0 || st >= c->n_streams) return fail(P264HIP_EINVAL, "stream %d out of range", st);
@@ -361,7 +379,17 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         d.n_ref = s.meta.n_ref; d.slice_type = s.meta.slice_type;
         d.chroma_qp_offset = s.meta.chroma_qp_offset; d.deblock = s.meta.deblock;
         d.alpha_off = s.meta.alpha_c0_offset; d.beta_off = s.meta.beta_offset;
-        any_p |= s.meta.slice_type == P264_SLICE_P;
+        if (s.meta.slice_type == P264_SLICE_B) {
+            const size_t n_mb = (size_t)c->g.n_mb;
+            d.mv_l1 = (const int *)(s.dev + s.off_l1);
+            d.ref_idx_l1 = (const int8_t *)(s.dev + s.off_l1 + align_up(n_mb * 64, 256));
+            d.bipred_w = (const int16_t *)(s.dev + s.off_l1 + align_up(n_mb * 64, 256) + align_up(n_mb * 4, 256));
+            d.n_ref_l1 = s.meta.n_ref_l1; d.weighted = s.meta.weighted_bipred;
+            for (int k = 0; k < P264HIP_MAX_REFS; k++)
+                d.ref_off_l1[k] = (uint32_t)(c->frame_bytes * (size_t)(k < s.meta.n_ref_l1 ? s.meta.ref_slot_l1[k] : s.meta.ref_slot_l1[0]));
+            any_b = true;
+        }
+        any_p |= s.meta.slice_type != P264_SLICE_I;
     }
     ScopedStamp whole(c, 3);
     HIPCHK(hipMemcpyAsync(c->d_batch[r], hb, (size_t)n * sizeof(PicDev), hipMemcpyHostToDevice, c->stream));
@@ -371,7 +399,10 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     const uint32_t inv_mbw = (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w);
     // the boundary strengths depend on the parsed arrays only: k_deblock_bs runs beside everything up to the sample filter
     hipStream_t bs_stream = conc ? c->side[3] : c->stream;
-    auto launch_bs = [&]() { hipLaunchKernelGGL(k_deblock_bs, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, bs_stream, c->d_batch[r], g, c->d_edge, inv_mbw); };
+    auto launch_bs = [&]() {
+        if (any_b) hipLaunchKernelGGL(k_deblock_bs<true>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, bs_stream, c->d_batch[r], g, c->d_edge, inv_mbw);
+        else       hipLaunchKernelGGL(k_deblock_bs<false>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, bs_stream, c->d_batch[r], g, c->d_edge, inv_mbw);
+    };
     bool bs_forked = false;
     if (conc) {
         HIPCHK(hipEventRecord(c->ev_fork, c->stream));               // behind the descriptor copy
@@ -446,19 +477,6 @@ extern "C" int p264hip_submit_async(p264hip_ctx *c, int stream, const p264hip_pi
     int rc = p264hip_upload_async(c, stream, pic);
     if (rc) return rc;
     return p264hip_reconstruct(c, &stream, &stream, 1);
-}
-
-extern "C" int p264hip_bipred_frames(p264hip_ctx *c, int stream, int dst_slot, int src_slot, int weighted, int weight1)
-{
-    if (!c || stream < 0 || stream >= c->n_streams || dst_slot < 0 || dst_slot >= c->slots || src_slot < 0 || src_slot >= c->slots || dst_slot == src_slot ||
-        weight1 < -64 || weight1 > 128)
-        return fail(P264HIP_EINVAL, "p264hip_bipred_frames: bad argument (stream %d, slots %d <- %d, weight %d)", stream, dst_slot, src_slot, weight1);
-    HIPCHK(hipSetDevice(c->device));
-    const int n_dw = c->g.n_mb * 96;
-    hipLaunchKernelGGL(k_bipred_frames, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, (uint32_t *)frame_ptr(c, stream, dst_slot),
-                       (const uint32_t *)frame_ptr(c, stream, src_slot), n_dw, weighted, weight1);
-    HIPCHK(hipGetLastError());
-    return P264HIP_OK;
 }
 
 static int drain_stamps(p264hip_ctx *c)

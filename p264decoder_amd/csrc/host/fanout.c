@@ -67,20 +67,23 @@ static size_t pad16(size_t v) { return (v + 15) & ~(size_t)15; }
 static size_t packed_size(const p264hip_picture_t *p)
 {
     const size_t n = (size_t)p->mb_w * p->mb_h;
-    return pad16(sizeof(fan_head_t)) + pad16(n * sizeof(p264hip_mb_t)) + pad16(n * 64) + pad16(n * 4) + pad16(n * 16) + pad16((size_t)p->n_coef_blocks * 32);
+    const size_t l1 = p->slice_type == P264_SLICE_B ? pad16(n * 64) + pad16(n * 4) : 0;          /* list-1 vectors and indices of a B picture */
+    return pad16(sizeof(fan_head_t)) + pad16(n * sizeof(p264hip_mb_t)) + pad16(n * 64) + pad16(n * 4) + pad16(n * 16) + pad16((size_t)p->n_coef_blocks * 32) + l1;
 }
 static void pack_picture(uint8_t *dst, int local_stream, const p264hip_picture_t *p)
 {
     const size_t n = (size_t)p->mb_w * p->mb_h;
     fan_head_t h; memset(&h, 0, sizeof h);
     h.magic = FAN_MAGIC; h.local_stream = local_stream; h.desc = *p; h.n_mb = (uint32_t)n;
-    h.desc.mb = NULL; h.desc.mv = NULL; h.desc.ref_idx = NULL; h.desc.i4modes = NULL; h.desc.coefs = NULL; h.desc.quads = NULL; h.desc.n_quads = 0;
+    h.desc.mb = NULL; h.desc.mv = NULL; h.desc.ref_idx = NULL; h.desc.i4modes = NULL; h.desc.coefs = NULL; h.desc.mv_l1 = NULL; h.desc.ref_idx_l1 = NULL;
     memcpy(dst, &h, sizeof h); dst += pad16(sizeof h);
     memcpy(dst, p->mb, n * sizeof(p264hip_mb_t)); dst += pad16(n * sizeof(p264hip_mb_t));
     memcpy(dst, p->mv, n * 64); dst += pad16(n * 64);
     memcpy(dst, p->ref_idx, n * 4); dst += pad16(n * 4);
     memcpy(dst, p->i4modes, n * 16); dst += pad16(n * 16);
     if (p->n_coef_blocks) memcpy(dst, p->coefs, (size_t)p->n_coef_blocks * 32);
+    dst += pad16((size_t)p->n_coef_blocks * 32);
+    if (p->slice_type == P264_SLICE_B) { memcpy(dst, p->mv_l1, n * 64); dst += pad16(n * 64); memcpy(dst, p->ref_idx_l1, n * 4); }
 }
 /* the picture described by a packed message, its arrays pointing into the message */
 static int unpack_picture(const uint8_t *src, size_t bytes, p264hip_picture_t *out, int *local_stream)
@@ -97,7 +100,9 @@ static int unpack_picture(const uint8_t *src, size_t bytes, p264hip_picture_t *o
     out->mv = (const int16_t *)src; src += pad16(n * 64);
     out->ref_idx = (const int8_t *)src; src += pad16(n * 4);
     out->i4modes = src; src += pad16(n * 16);
-    out->coefs = (const int16_t *)src;
+    out->coefs = (const int16_t *)src; src += pad16((size_t)out->n_coef_blocks * 32);
+    out->mv_l1 = NULL; out->ref_idx_l1 = NULL;
+    if (out->slice_type == P264_SLICE_B) { out->mv_l1 = (const int16_t *)src; src += pad16(n * 64); out->ref_idx_l1 = (const int8_t *)src; }
     return 0;
 }
 

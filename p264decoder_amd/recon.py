@@ -25,8 +25,14 @@ class ParsedPicture:
         self.coefs = np.ctypeslib.as_array(desc.coefs, (nc * 16,)).copy() if nc else np.zeros(16, np.int16)
         d = N.Picture()
         C.memmove(C.byref(d), C.byref(desc), C.sizeof(N.Picture))
-        d.quads = C.POINTER(C.c_uint32)()              # reserved fields of p264hip_picture_t
-        d.n_quads = 0
+        if desc.slice_type == N.SLICE_B:                # list-1 arrays of a B picture
+            self.mv_l1 = np.ctypeslib.as_array(desc.mv_l1, (n * 32,)).copy()
+            self.ref_idx_l1 = np.ctypeslib.as_array(desc.ref_idx_l1, (n * 4,)).copy()
+            d.mv_l1 = C.cast(self.mv_l1.ctypes.data, C.POINTER(C.c_int16))
+            d.ref_idx_l1 = C.cast(self.ref_idx_l1.ctypes.data, C.POINTER(C.c_int8))
+        else:
+            d.mv_l1 = C.POINTER(C.c_int16)()
+            d.ref_idx_l1 = C.POINTER(C.c_int8)()
         d.mb = C.cast(self.mb.ctypes.data, C.POINTER(N.MbInfo))
         d.mv = C.cast(self.mv.ctypes.data, C.POINTER(C.c_int16))
         d.ref_idx = C.cast(self.ref_idx.ctypes.data, C.POINTER(C.c_int8))

@@ -28,6 +28,8 @@ class SeamPicture:
         self.ref_idx = np.zeros(n * 4, np.int8)
         self.i4modes = np.full(n * 16, 2, np.uint8)
         self.coefs = np.zeros(16, np.int16)
+        self.mv_l1 = np.zeros(n * 32, np.int16)        # list 1 (B pictures)
+        self.ref_idx_l1 = np.full(n * 4, -1, np.int8)
         self.desc = N.Picture()
         self.desc.mb_w, self.desc.mb_h = mb_w, mb_h
 
@@ -39,6 +41,8 @@ class SeamPicture:
         d.ref_idx = C.cast(self.ref_idx.ctypes.data, C.POINTER(C.c_int8))
         d.i4modes = C.cast(self.i4modes.ctypes.data, C.POINTER(C.c_uint8))
         d.coefs = C.cast(self.coefs.ctypes.data, C.POINTER(C.c_int16))
+        d.mv_l1 = C.cast(self.mv_l1.ctypes.data, C.POINTER(C.c_int16))
+        d.ref_idx_l1 = C.cast(self.ref_idx_l1.ctypes.data, C.POINTER(C.c_int8))
         return self
 
     @property
@@ -75,8 +79,10 @@ def _levels(rng, n, style):
 
 
 def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=0, level_style="small", qp_mode="random",
-                 mv_range=80, sub8x8=True, intra_share=0.15, slices=1, deblock_offsets=True):
-    """Draw one picture.  qp_mode: 'random' (0..51 per macroblock), 'two' (two values), or an int (constant)."""
+                 mv_range=80, sub8x8=True, intra_share=0.15, slices=1, deblock_offsets=True, b_picture=False, n_ref_l1=1, weighted=None):
+    """Draw one picture.  qp_mode: 'random' (0..51 per macroblock), 'two' (two values), or an int (constant).
+    b_picture: a B picture - every inter macroblock is P264_MB_B, each 8x8 quadrant predicts from list 0, list 1 or both
+    (a negative index = list unused, its vectors 0); weighted: None = drawn, else weighted_bipred on / off."""
     pic = SeamPicture(mb_w, mb_h)
     d = pic.desc
     n = mb_w * mb_h
@@ -84,7 +90,9 @@ def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=
     mv = pic.mv.reshape(n, 16, 2)
     ref = pic.ref_idx.reshape(n, 4)
     i4 = pic.i4modes.reshape(n, 16)
-    d.slice_type = N.SLICE_P if p_picture else N.SLICE_I
+    d.slice_type = N.SLICE_B if (b_picture and p_picture) else N.SLICE_P if p_picture else N.SLICE_I
+    mv1 = pic.mv_l1.reshape(n, 16, 2)
+    ref1 = pic.ref_idx_l1.reshape(n, 4)
     d.chroma_qp_offset = int(rng.integers(-12, 13))
     d.alpha_c0_offset = int(rng.integers(-6, 7)) if deblock_offsets else 0
     d.beta_offset = int(rng.integers(-6, 7)) if deblock_offsets else 0
@@ -93,6 +101,13 @@ def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=
     others = [s for s in range(slots) if s != dst_slot]
     for i in range(d.n_ref):
         d.ref_slot[i] = others[i % len(others)]
+    if d.slice_type == N.SLICE_B:
+        d.n_ref_l1 = n_ref_l1
+        for i in range(n_ref_l1):
+            d.ref_slot_l1[i] = others[(len(others) - 1 - i) % len(others)]      # list 1 walks the store the other way round
+        d.weighted_bipred = int(rng.random() < 0.5) if weighted is None else int(bool(weighted))
+        for i in range(N.MAX_REFS * N.MAX_REFS):                           # implicit weights: 64 - dist_scale_factor, -64 .. 128; often 32
+            d.bipred_weight[i] = 32 if rng.random() < 0.3 else int(rng.integers(-64, 129))
     # slice structure: first macroblock of every slice and its deblocking idc (0 all edges, 1 none, 2 not across slices)
     starts = sorted(set([0] + [int(x) for x in rng.integers(1, max(n, 2), size=slices - 1)])) if slices > 1 and n > 1 else [0]
     idcs = [int(rng.choice([0, 0, 2, 1])) for _ in starts]
@@ -196,6 +211,31 @@ def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=
             if rng.random() < 0.1:          # quarter-pel phase sweep: keep the integer part, force a phase
                 cells = (cells & ~3) | rng.integers(0, 4, size=2)
             mv[m] = cells.reshape(16, 2)
+            if d.slice_type == N.SLICE_B:
+                # direction per quadrant (0 list 0, 1 list 1, 2 both); whole-macroblock directions are as likely as mixed ones
+                r["mb_type"] = N.MB_B
+                dirs = [int(rng.integers(0, 3))] * 4 if rng.random() < 0.5 else [int(x) for x in rng.integers(0, 3, size=4)]
+                c1 = np.zeros((4, 4, 2), np.int64)
+                style1 = rng.random()
+                if style1 < 0.4:
+                    c1[:] = vec()
+                elif style1 < 0.7:
+                    for q in range(4):
+                        c1[(q >> 1) * 2:(q >> 1) * 2 + 2, (q & 1) * 2:(q & 1) * 2 + 2] = vec()
+                else:
+                    c1 = rng.integers(-mv_range, mv_range + 1, size=(4, 4, 2))
+                if skip:                            # (B_Skip / direct: whatever the derivation gave - here: both lists, one vector each)
+                    dirs = [2] * 4
+                for q in range(4):
+                    qy, qx = (q >> 1) * 2, (q & 1) * 2
+                    if dirs[q] == 1:
+                        ref[m, q] = -1
+                        mv[m].reshape(4, 4, 2)[qy:qy + 2, qx:qx + 2] = 0
+                    if dirs[q] == 0:
+                        c1[qy:qy + 2, qx:qx + 2] = 0
+                    else:
+                        ref1[m, q] = int(rng.integers(0, n_ref_l1))
+                mv1[m] = c1.reshape(16, 2)
             cbp_l = 0 if skip else (int(rng.integers(0, 16)) if rng.random() < 0.6 else 0)
             for b in range(16):
                 if (cbp_l >> (b >> 2)) & 1 and rng.random() < 0.6:

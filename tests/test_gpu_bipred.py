@@ -1,47 +1,68 @@
-"""SURVEY 8f rank 4, first piece: the two bi-prediction combines of the reference (pf->avg[] / pf->avg_weight[],
-core/mc.c:76-155) as device functions, through the C ABI (p264hip_bipred_frames) on whole frames, against (1) the
-known-answer vectors recorded from the reference's own function tables and (2) the CPU oracle on random frames."""
-import ctypes as C
+"""the two bi-prediction combines of the reference (pf->avg[] / pf->avg_weight[], core/mc.c:76-155) as
+they run inside the motion-compensation kernels (the two-list class of k_mc, kernel_mc.h): B pictures whose macroblocks
+predict from both lists with zero vectors and no residual, loop filter off, reconstruct to combine(frame A, frame B) -
+checked against (1) the known-answer vectors recorded from the reference's own function tables (kat_bipred.npz) and
+(2) the CPU oracle on random frames."""
 import os
 
 import numpy as np
 import pytest
 
-from p264decoder_amd import HipReconstructor
+from p264decoder_amd import HipReconstructor, _native as N
+from tests import seam_fuzz
 
 pytestmark = pytest.mark.gpu
 
 
-def run(hip, lib, a, b, weighted, w1):
+def bipred_picture(mb_w, mb_h, weighted, w1):
+    """Every macroblock B, both lists (index 0 each), zero vectors, nothing coded, no loop filter: slot 2 = combine(slot 0, slot 1)."""
+    pic = seam_fuzz.SeamPicture(mb_w, mb_h)
+    d = pic.desc
+    d.slice_type = N.SLICE_B
+    d.dst_slot, d.n_ref, d.n_ref_l1 = 2, 1, 1
+    d.ref_slot[0], d.ref_slot_l1[0] = 0, 1
+    d.weighted_bipred = weighted
+    for i in range(N.MAX_REFS * N.MAX_REFS):
+        d.bipred_weight[i] = w1
+    pic.rec["mb_type"] = N.MB_B
+    pic.rec["qp"] = 26
+    pic.ref_idx[:] = 0
+    pic.ref_idx_l1[:] = 0
+    return pic.seal()
+
+
+def run(hip, a, b, weighted, w1):
     hip.write_frame(0, 0, *a)
     hip.write_frame(0, 1, *b)
-    lib.p264hip_bipred_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-    assert lib.p264hip_bipred_frames(hip.h, 0, 0, 1, weighted, w1) == 0
-    return hip.read_frame(0, 0)
+    hip.submit(0, bipred_picture(hip.mb_w, hip.mb_h, weighted, w1))
+    return hip.read_frame(0, 2)
 
 
 def test_bipred_against_reference_vectors(lib):
     kat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_bipred.npz"))
-    hip = HipReconstructor(2, 1, n_streams=1, slots=2, max_pictures=1, lib=lib)           # 32x16 luma: a 16x24 case fits
+    hip = HipReconstructor(2, 1, n_streams=1, slots=3, max_pictures=1, lib=lib)           # 32x16 luma: a 16x24 case fits
     for a, b, want, (which, w, h, weighted, w1) in zip(kat["a"], kat["b"], kat["out"], kat["par"].tolist()):
         ya, yb = np.zeros((16, 32), np.uint8), np.zeros((16, 32), np.uint8)
         ya[:, :24] = a; yb[:, :24] = b
         ca, cb = np.zeros((8, 16), np.uint8), np.zeros((8, 16), np.uint8)
-        ca[:, :12] = a[:8, :12]; cb[:, :12] = b[:8, :12]                                    # the chroma planes go through the same code
-        y, u, v = run(hip, lib, (ya, ca, ca), (yb, cb, cb), weighted, w1)
+        ca[:, :12] = a[:8, :12]; cb[:, :12] = b[:8, :12]                                    # the chroma planes go through the chroma kernel
+        y, u, v = run(hip, (ya, ca, ca), (yb, cb, cb), weighted, w1)
         assert np.array_equal(y[:h, :w], want[:h, :w]), "size %dx%d weighted %d w1 %d" % (w, h, weighted, w1)
+        hc, wc = min(h, 8), min(w, 12)
+        assert np.array_equal(u[:hc, :wc], want[:hc, :wc]) and np.array_equal(v[:hc, :wc], want[:hc, :wc]), "chroma, weighted %d w1 %d" % (weighted, w1)
     hip.close()
 
 
 @pytest.mark.parametrize("weighted,w1", [(0, 0), (1, 32), (1, -64), (1, 128), (1, 17), (1, 0), (1, 64), (1, 99)])
-def test_bipred_frames_against_oracle(lib, oracle, weighted, w1):
+def test_bipred_in_mc_against_oracle(lib, oracle, weighted, w1):
+    import ctypes as C
     rng = np.random.default_rng(1007 + w1)
     mb_w, mb_h = 9, 5
-    hip = HipReconstructor(mb_w, mb_h, n_streams=1, slots=2, max_pictures=1, lib=lib)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=1, slots=3, max_pictures=1, lib=lib)
     shapes = [(mb_h * 16, mb_w * 16), (mb_h * 8, mb_w * 8), (mb_h * 8, mb_w * 8)]
     a = [rng.integers(0, 256, s, dtype=np.uint8) for s in shapes]
     b = [rng.integers(0, 256, s, dtype=np.uint8) for s in shapes]
-    got = run(hip, lib, a, b, weighted, w1)
+    got = run(hip, a, b, weighted, w1)
     oracle.oracle_bipred_avg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     oracle.oracle_bipred_weight.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     for p in range(3):

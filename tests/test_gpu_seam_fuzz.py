@@ -23,6 +23,12 @@ CONFIGS = [
     ("sliced_single_column", 1, 9, 5, dict(level_style="mixed", qp_mode="random", n_ref=1, slots=2, slices=4)),
     ("single_row", 11, 1, 5, dict(level_style="mixed", qp_mode="random", n_ref=1, slots=2, slices=3)),
     ("wide_picture", 67, 3, 4, dict(level_style="small", qp_mode="random", n_ref=2, slots=3)),
+    # B pictures: two lists in the seam, every 8x8 quadrant from list 0, list 1 or both, plain and
+    # implicit-weight averages (core/macroblock.c:525-583, core/mc.c:76-132).  The reference cannot decode B slices: these
+    # are pinned to the oracle, whose two combines are pinned to the reference's function tables (kat_bipred.npz).
+    ("b_pictures", 9, 7, 8, dict(level_style="small", qp_mode="random", n_ref=2, slots=4, b_picture=True, n_ref_l1=2)),
+    ("b_pictures_far_wrap", 7, 6, 6, dict(level_style="mixed", qp_mode="random", n_ref=1, slots=3, b_picture=True, n_ref_l1=2, mv_range=500, slices=2)),
+    ("b_pictures_weighted_smooth", 10, 6, 6, dict(level_style="small", qp_mode="two", n_ref=3, slots=4, b_picture=True, n_ref_l1=1, weighted=True, mv_range=12)),
 ]
 
 
@@ -44,11 +50,11 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
     store = oracle_bind.FrameStore(mb_w, mb_h, slots)
     hip = HipReconstructor(mb_w, mb_h, n_streams=1, slots=slots, max_pictures=1, lib=lib)
     for s in range(slots):
-        f = seam_fuzz.random_frame(rng, mb_w, mb_h, "smooth" if name == "two_qps_smooth" else "noise")
+        f = seam_fuzz.random_frame(rng, mb_w, mb_h, "smooth" if "smooth" in name else "noise")
         for dst, src in zip(store[s], f):
             dst[:] = src
         hip.write_frame(0, s, *f)
-    seen = dict(sub4x4=0, qp_edges=0, wrap=0, phases=set(), multi_ref=0, types=set(), avail=set(), intra4_modes=set())
+    seen = dict(sub4x4=0, qp_edges=0, wrap=0, phases=set(), multi_ref=0, types=set(), avail=set(), intra4_modes=set(), weighted=set(), dirs=set())
     oracle.oracle_stats_reset()
     for i in range(n_pics):
         pic = seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=(i != 2), dst_slot=i % slots, **kw)
@@ -62,6 +68,10 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
         mv = pic.mv.reshape(n, 4, 4, 2)
         inter = rec["mb_type"] > N.MB_IPCM
         seen["types"] |= set(rec["mb_type"].tolist())
+        if pic.desc.slice_type == N.SLICE_B:
+            seen["weighted"].add(int(pic.desc.weighted_bipred))
+            r0, r1 = pic.ref_idx.reshape(n, 4)[inter], pic.ref_idx_l1.reshape(n, 4)[inter]
+            seen["dirs"] |= set(((r0 >= 0).astype(int) + 2 * (r1 >= 0).astype(int)).reshape(-1).tolist())
         seen["avail"] |= set(rec["avail"].tolist())
         for m in np.nonzero(inter)[0]:
             v = mv[m]
@@ -88,7 +98,14 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
         assert st[6] > 0, "no edge was filtered with the mean of two different QPs"
     if kw["level_style"] in ("wrap", "mixed"):
         assert st[7] > 0, "no dequantised coefficient wrapped its int16 store (A-Q8)"
-    assert {N.MB_I4x4, N.MB_I16x16, N.MB_P_L0, N.MB_P_8x8, N.MB_P_SKIP} <= seen["types"]
+    if kw.get("b_picture"):
+        oracle.oracle_bipred_blocks.restype = C.c_longlong
+        assert oracle.oracle_bipred_blocks() > 100, "hardly any bi-predicted block"
+        assert seen["dirs"] == {1, 2, 3}, "not every prediction direction (list 0, list 1, both) occurred: %s" % seen["dirs"]
+        assert seen["weighted"] == ({1} if kw.get("weighted") else {0, 1}), seen["weighted"]
+        assert {N.MB_I4x4, N.MB_I16x16, N.MB_B} <= seen["types"]
+    else:
+        assert {N.MB_I4x4, N.MB_I16x16, N.MB_P_L0, N.MB_P_8x8, N.MB_P_SKIP} <= seen["types"]
     if kw.get("sub8x8", True) and mb_w * mb_h >= 30:
         assert seen["sub4x4"] > 0, "no quadrant with three or more different vectors was drawn"
     if kw.get("mv_range", 80) >= 12 and mb_w * mb_h >= 30:

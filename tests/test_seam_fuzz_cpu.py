@@ -51,7 +51,7 @@ def test_fuzz_configurations_reach_the_paths_they_are_meant_for(oracle):
         slots = kw["slots"]
         store = oracle_bind.FrameStore(mb_w, mb_h, slots)
         for s in range(slots):
-            for dst, src in zip(store[s], seam_fuzz.random_frame(rng, mb_w, mb_h, "smooth" if name == "two_qps_smooth" else "noise")):
+            for dst, src in zip(store[s], seam_fuzz.random_frame(rng, mb_w, mb_h, "smooth" if "smooth" in name else "noise")):
                 dst[:] = src
         oracle.oracle_stats_reset()
         for i in range(n_pics):

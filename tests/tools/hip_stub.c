@@ -22,4 +22,3 @@ int p264hip_timing_read(p264hip_ctx *c, double *a, int64_t *b) { (void)c;(void)a
 int p264hip_timing_reset(p264hip_ctx *c) { (void)c; return -1; }
 int p264hip_submit_async(p264hip_ctx *c, int s, const p264hip_picture_t *p) { (void)c;(void)s;(void)p; return -1; }
 int p264hip_read_frame_async(p264hip_ctx *c, int s, int sl, uint8_t *y, int ys, uint8_t *u, uint8_t *v, int cs) { (void)c;(void)s;(void)sl;(void)y;(void)ys;(void)u;(void)v;(void)cs; return -1; }
-int p264hip_bipred_frames(p264hip_ctx *c, int s, int d, int r, int w, int w1) { (void)c;(void)s;(void)d;(void)r;(void)w;(void)w1; return -1; }

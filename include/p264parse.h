@@ -53,6 +53,16 @@ int p264parse_generation(const p264parse *p);
  * returns 0 at end of buffer. */
 int p264_annexb_next(const uint8_t *buf, int64_t size, int64_t *pos, int64_t *nal_off, int64_t *nal_len);
 
+/* The CABAC arithmetic decoding engine of the entropy layer, driven bin by bin (csrc/host/cabac.h; replaces
+ * p264_cabac_context_init / _decode_init / _decode_decision / _decode_bypass / _decode_terminal, core/cabac.c:819-902).
+ * Contexts are initialised for the slice (9.3.1.1), decoding starts at data[0] (9.3.1.2), then one bin per op:
+ * op >= 0: a decision with context op (< 460); -1: a bypass bin; -2: a terminate bin.  bins[i] receives bin i.
+ * Returns 0, 1 if the ops read past the end of the data (bins beyond it are then undefined), -1 on a bad argument.
+ * This is what the known-answer test of the engine drives; the macroblock-layer binarisations are built on the same
+ * inline functions. */
+int p264cabac_decode_ops(const uint8_t *data, size_t bytes, int is_i_slice, int cabac_init_idc, int slice_qp,
+                         const int16_t *ops, int n_ops, uint8_t *bins);
+
 #ifdef __cplusplus
 }
 #endif

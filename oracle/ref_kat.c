@@ -120,3 +120,28 @@ void refk_deblock(int which, uint8_t *pix, int stride, int alpha, int beta, int8
  *      which = PIXEL_16x16 .. PIXEL_2x2 (core/pixel.h) --------------------------------------------- */
 void refk_avg(int which, uint8_t *dst, int dst_stride, uint8_t *src, int src_stride) { g_h->mc.avg[which](dst, dst_stride, src, src_stride); }
 void refk_avg_weight(int which, uint8_t *dst, int dst_stride, uint8_t *src, int src_stride, int weight1) { g_h->mc.avg_weight[which](dst, dst_stride, src, src_stride, weight1); }
+
+/* ---- CABAC (SURVEY 8c "partial pins"): the reference ENCODES a sequence of bins with its arithmetic coder
+ *      (p264_cabac_context_init / _encode_init / _encode_decision / _encode_bypass / _encode_terminal / _encode_flush,
+ *      core/cabac.c:819-837, 907-1018); a decoder must get the same bins back out of the bytes.  ops[i] >= 0: decision with
+ *      context ops[i] (< 436: the reference initialises no more, core/cabac.c:835); -1 bypass; -2 terminal.
+ *      Returns the number of bytes written. ------------------------------------------------------------------------ */
+int refk_cabac_encode(int slice_type, int qp, int model, const int16_t *ops, const uint8_t *bins, int n, uint8_t *out, int cap)
+{
+    p264_cabac_t cb;
+    bs_t s;
+    memset(out, 0, (size_t)cap);
+    bs_init(&s, out, cap);
+    memset(&cb, 0, sizeof cb);
+    p264_cabac_context_init(&cb, slice_type, qp, model);
+    p264_cabac_encode_init(&cb, &s);
+    for (int i = 0; i < n; i++) {
+        if (ops[i] >= 0) p264_cabac_encode_decision(&cb, ops[i], bins[i]);
+        else if (ops[i] == -1) p264_cabac_encode_bypass(&cb, bins[i]);
+        else p264_cabac_encode_terminal(&cb, bins[i]);
+    }
+    p264_cabac_encode_flush(&cb);
+    return bs_pos(&s) / 8;
+}
+int refk_slice_type_i(void) { return SLICE_TYPE_I; }
+int refk_slice_type_p(void) { return SLICE_TYPE_P; }

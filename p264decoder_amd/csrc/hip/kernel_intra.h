@@ -339,7 +339,11 @@ __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
 {
     __shared__ RowSync sync;
-    __shared__ IntraLds lds[INTRA_ROW_WAVES];
+    // one tile set per wavefront, sized by the launch (dynamic shared memory = wavefronts x sizeof(IntraLds)): with the space of
+    // sixteen wavefronts reserved for every workgroup only seven workgroups fitted a CU whatever their size - a batch of
+    // 1024 pictures (2048 workgroups of 4 wavefronts) then ran as two rounds of workgroups, i.e. took twice a workgroup's time
+    extern __shared__ __attribute__((aligned(16))) uint8_t intra_dyn_lds[];
+    IntraLds *lds = (IntraLds *)intra_dyn_lds;
     const PicDev *pd = pics + blockIdx.x;
     const bool chroma_role = blockIdx.y != 0;               // grid.y = 2: luma and chroma of a picture in separate workgroups
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -436,7 +436,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         if (c->tune_intra_waves >= 1 && c->tune_intra_waves <= INTRA_ROW_WAVES) intra_waves = c->tune_intra_waves;
         // luma and chroma of a picture are independent chains: as two workgroups they run side by side (the kernel is bound by
         // the latency of the macroblock-to-macroblock chain, not by arithmetic)
-        hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), 0, c->stream, c->d_batch[r], g, c->d_status);
+        hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status);
     }
     {
         ScopedStamp t(c, 2);

@@ -26,6 +26,8 @@ typedef struct {
     double  parse_seconds;       /* summed over the threads: time inside the parsers */
     double  submit_seconds;      /* host time spent enqueuing uploads and launches */
     int     rounds, streams, threads;
+    int     reserved;
+    int64_t bytes_uploaded;      /* parsed-picture bytes copied host -> HBM (0 when the parsers run alone) */
 } p264pipe_stats_t;
 
 p264pipe *p264pipe_open(int device, int n_streams, int n_threads);

@@ -52,7 +52,8 @@ assert C.sizeof(MbInfo) == 16
 class PipeStats(C.Structure):
     """p264pipe_stats_t"""
     _fields_ = [("pictures", C.c_int64), ("bytes", C.c_int64), ("seconds", C.c_double), ("parse_seconds", C.c_double),
-                ("submit_seconds", C.c_double), ("rounds", C.c_int), ("streams", C.c_int), ("threads", C.c_int)]
+                ("submit_seconds", C.c_double), ("rounds", C.c_int), ("streams", C.c_int), ("threads", C.c_int), ("reserved", C.c_int),
+                ("bytes_uploaded", C.c_int64)]
 
 _lib = None
 

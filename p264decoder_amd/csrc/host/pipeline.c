@@ -145,7 +145,7 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
     const p264hip_picture_t **pics = (const p264hip_picture_t **)malloc(sizeof(void *) * (size_t)p->n_streams);
     if (!ids || !sts || !pics) { free(ids); free(sts); free(pics); return -1; }
     int markers[2] = { -1, -1 }, rounds = 0, rc = 0;
-    int64_t pictures = 0;
+    int64_t pictures = 0, uploaded = 0;
     double submit = 0;
     const double t0 = now_s();
     start_round(p);                                          /* round 0 */
@@ -173,6 +173,7 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
             for (int k = 0; k < n && !rc; k++) {
                 if (pics[k]->mb_w != p->mb_w || pics[k]->mb_h != p->mb_h) { fprintf(stderr, "p264pipe_run: stream %d has a different picture size\n", sts[k]); rc = -1; }
                 else if (p264hip_upload_async(p->ctx, ids[k], pics[k])) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
+                else uploaded += (int64_t)p->mb_w * p->mb_h * (16 + 64 + 4 + 16) + (int64_t)pics[k]->n_coef_blocks * 32;
             }
             if (!rc && p264hip_reconstruct(p->ctx, ids, sts, n)) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
             if (!rc) { markers[r & 1] = p264hip_marker(p->ctx); if (markers[r & 1] < 0) rc = -1; }
@@ -185,7 +186,7 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->pictures = pictures; stats->seconds = t1 - t0; stats->parse_seconds = p->parse_seconds; stats->submit_seconds = submit;
-        stats->rounds = rounds; stats->streams = p->n_streams; stats->threads = p->n_threads;
+        stats->rounds = rounds; stats->streams = p->n_streams; stats->threads = p->n_threads; stats->bytes_uploaded = uploaded;
         for (int i = 0; i < p->n_streams; i++) stats->bytes += p->st[i].pos;
     }
     free(ids); free(sts); free(pics);

@@ -23,8 +23,15 @@ CASES = {
     # --maxlevel 12 keeps the centre half-pel samples inside the reference's clip LUT (core/clip1.h);
     # beyond it the reference reads past its table (undefined), see DESIGN.md "A-Q13".
     "cfg3_1080p_ip": ("--mbw 120 --mbh 68 --frames 60 --gop 30 --seed 3 --coded 12 --maxlevel 12 --crop-bottom 4", 4),
+    # config 3 with the level range SURVEY 8d gives it (+-32): seed 305 is one whose 30 pictures contain no centre half-pel
+    # sample outside the reference's clip table (A-Q13; found by search, the oracle counts such samples and the CPU test
+    # asserts there are none) - so the reference is defined on it and pins it
+    "cfg3_1080p_ip_l32": ("--mbw 120 --mbh 68 --frames 30 --gop 30 --seed 305 --coded 12 --maxlevel 32 --crop-bottom 4", 3),
     # the throughput stream of the north star: 1 IDR + P pictures only
     "cfg3_1080p_allp": ("--mbw 120 --mbh 68 --frames 30 --gop 0 --seed 33 --coded 12 --maxlevel 12 --crop-bottom 4", 3),
+    # the same stream at the length SURVEY 8d specifies for it: 1 IDR + 299 P pictures (the first 30 are the stream above);
+    # bench.py takes its golden pictures from here when --warmup + --steps go past 29
+    "cfg3_1080p_allp_300": ("--mbw 120 --mbh 68 --frames 300 --gop 0 --seed 33 --coded 12 --maxlevel 12 --crop-bottom 4", 2),
     # small cases for the edges of the arithmetic
     "cif_ip": ("--mbw 22 --mbh 18 --frames 24 --gop 8 --seed 7 --coded 20 --maxlevel 12", None),
     "tiny_1x1": ("--mbw 1 --mbh 1 --frames 10 --gop 5 --seed 11 --coded 40 --maxlevel 8", None),
@@ -52,7 +59,7 @@ CASES = {
     "uhd_2160p_allp": ("--mbw 240 --mbh 135 --frames 3 --gop 0 --seed 61 --qp 29 --qp-delta 3 --coded 12 --maxlevel 10", 2),
     "mv_far": ("--mbw 10 --mbh 8 --frames 10 --gop 10 --seed 28 --mvmax 64 --coded 5 --maxlevel 6", None),
 }
-BIG = ("cfg2_720p_intra", "cfg3_1080p_ip", "cfg3_1080p_allp", "qpd_1080p", "uhd_2160p_allp")
+BIG = ("cfg2_720p_intra", "cfg3_1080p_ip", "cfg3_1080p_ip_l32", "cfg3_1080p_allp", "cfg3_1080p_allp_300", "qpd_1080p", "uhd_2160p_allp")
 
 
 def ensure_tool():

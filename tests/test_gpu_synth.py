@@ -49,8 +49,19 @@ def test_config3_1080p_ip(lib, oracle):
     run_case(lib, oracle, "cfg3_1080p_ip", with_oracle=False)      # 60 pictures: reference hashes only
 
 
+def test_config3_1080p_ip_levels_32(lib, oracle):
+    """config 3 with levels up to +-32 (SURVEY 8d's range) on a stream that stays inside the reference's clip table"""
+    run_case(lib, oracle, "cfg3_1080p_ip_l32", with_oracle=False)
+
+
 def test_config3_1080p_allp_vs_oracle(lib, oracle):
     run_case(lib, oracle, "cfg3_1080p_allp")
+
+
+def test_config3_1080p_allp_300_pictures(lib, oracle):
+    """The throughput stream at the length SURVEY 8d gives it - 1 IDR + 299 P pictures - every picture against the real
+    reference decoder's hash."""
+    run_case(lib, oracle, "cfg3_1080p_allp_300", with_oracle=False)
 
 
 def test_per_macroblock_qp_1080p(lib, oracle):

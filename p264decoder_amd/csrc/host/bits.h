@@ -73,7 +73,7 @@ static inline int  br_eof(const bitrd_t *b)       { return (b->consumed >> 3) >=
 
 static inline uint32_t br_ue(bitrd_t *b)
 {
-    /* leading zeros of the next 32 bits in one step (the window always holds at least 57 valid bits; past the end of the
+    /* leading zeros of the next 32 bits in one step (the window always holds at least 33 valid bits; past the end of the
      * buffer it is zero-padded, so a truncated code reads as "32 zeros" and is rejected by the callers' range checks) */
     const uint32_t w = br_peek(b, 32);
     const int zeros = w ? __builtin_clz(w) : 32;

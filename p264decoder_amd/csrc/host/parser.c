@@ -290,12 +290,15 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
                 const unsigned op = br_ue(b);
                 if (op == 0) break;
                 if (op > 6 || sh->n_mmco >= 33 || br_overrun(b)) { ERR(p, "bad memory_management_control_operation %u", op); return -1; }
-                int a = 0, c = 0;
-                if (op == 1 || op == 3) a = (int)br_ue(b);          /* difference_of_pic_nums_minus1 */
-                if (op == 2) a = (int)br_ue(b);                     /* long_term_pic_num */
-                if (op == 3 || op == 6) c = (int)br_ue(b);          /* long_term_frame_idx */
-                if (op == 4) a = (int)br_ue(b);                     /* max_long_term_frame_idx_plus1 */
-                sh->mmco[sh->n_mmco].op = (int)op; sh->mmco[sh->n_mmco].a = a; sh->mmco[sh->n_mmco].b = c;
+                /* operands are bounded by the syntax (7.4.3.3): picture-number differences below MaxFrameNum, long-term
+                 * indices at most num_ref_frames - anything else is a broken stream, not something to compute with */
+                unsigned a = 0, c = 0;
+                const unsigned max_fn_u = 1u << sps->log2_max_frame_num, max_lt = (unsigned)(sps->num_ref_frames > 0 ? sps->num_ref_frames : 1);
+                if (op == 1 || op == 3) { a = br_ue(b); if (a >= max_fn_u) { ERR(p, "difference_of_pic_nums_minus1 %u out of range", a); return -1; } }
+                if (op == 2) { a = br_ue(b); if (a >= 2 * max_lt) { ERR(p, "long_term_pic_num %u out of range", a); return -1; } }
+                if (op == 3 || op == 6) { c = br_ue(b); if (c >= max_lt) { ERR(p, "long_term_frame_idx %u out of range (num_ref_frames %u)", c, max_lt); return -1; } }
+                if (op == 4) { a = br_ue(b); if (a > max_lt) { ERR(p, "max_long_term_frame_idx_plus1 %u out of range", a); return -1; } }
+                sh->mmco[sh->n_mmco].op = (int)op; sh->mmco[sh->n_mmco].a = (int)a; sh->mmco[sh->n_mmco].b = (int)c;
                 sh->n_mmco++;
             }
         }
@@ -367,7 +370,7 @@ static void finish_picture_marking(p264parse *p)
     const sps_t *sps = &p->sps[p->active_sps];
     int max_fn = 1 << sps->log2_max_frame_num;
     dpb_frame_t *cur = &p->dpb[p->cur_slot];
-    int cur_long = 0, cur_long_idx = 0;
+    int cur_long = 0, cur_long_idx = 0, had_mmco5 = 0;
     if (p->pic_is_idr) {
         for (int i = 0; i < p->slots; i++) if (i != p->cur_slot) p->dpb[i].used = 0;
         if (p->sh0.long_term_flag) { cur_long = 1; cur_long_idx = 0; }
@@ -394,6 +397,7 @@ static void finish_picture_marking(p264parse *p)
                 for (int i = 0; i < p->slots; i++) if (p->dpb[i].used && p->dpb[i].is_long && p->dpb[i].long_idx >= a && i != p->cur_slot) p->dpb[i].used = 0;
             } else if (op == 5) {
                 for (int i = 0; i < p->slots; i++) if (i != p->cur_slot) p->dpb[i].used = 0;
+                had_mmco5 = 1;
             } else if (op == 6) {
                 for (int j = 0; j < p->slots; j++) if (j != p->cur_slot && p->dpb[j].used && p->dpb[j].is_long && p->dpb[j].long_idx == b) p->dpb[j].used = 0;
                 cur_long = 1; cur_long_idx = b;
@@ -412,7 +416,9 @@ static void finish_picture_marking(p264parse *p)
         int cap = sps->num_ref_frames > 0 ? sps->num_ref_frames : 1;
         if (cnt >= cap && oldest >= 0) p->dpb[oldest].used = 0;
     }
-    if (p->pic_ref_idc) { cur->used = 1; cur->frame_num = p->sh0.frame_num; cur->is_long = cur_long; cur->long_idx = cur_long_idx; }
+    /* after memory_management_control_operation 5 the picture is inferred to have had frame_num 0 (H.264 7.4.3, 8.2.1): the
+     * pictures that follow compute their PicNums against that */
+    if (p->pic_ref_idc) { cur->used = 1; cur->frame_num = had_mmco5 ? 0 : p->sh0.frame_num; cur->is_long = cur_long; cur->long_idx = cur_long_idx; }
     /* next picture goes into a slot that holds no reference */
     int next = -1;
     for (int i = 0; i < p->slots; i++) if (!p->dpb[i].used) { next = i; break; }

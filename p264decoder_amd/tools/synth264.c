@@ -101,7 +101,7 @@ static int8_t  *i4m;                        /* [mb][16], 2 for non-I4x4 */
 static int cur;                             /* current MB index */
 
 static int opt_pps_alt = 0, cur_pps = 0;
-static int opt_mmco = 0;
+static int opt_mmco = 0, opt_mmco5 = 0, had_mmco5 = 0;   /* --mmco5: also memory_management_control_operation 5; had_mmco5: the picture just written carried one */
 /* the writer's own model of the decoded picture buffer (H.264 8.2.4, 8.2.5) */
 typedef struct { int used, pic, frame_num, is_long, long_idx; } wdpb_t;
 static wdpb_t wdpb[8];
@@ -483,7 +483,7 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         else {
             int n_short = 0, n_long = 0, cnt = 0;
             for (int i = 0; i < 8; i++) if (wdpb[i].used) { cnt++; if (wdpb[i].is_long) n_long++; else n_short++; }
-            const int want = pct(60) ? 1 + rnd(4) : 0;        /* 1: drop a short-term, 2: short -> long, 3: drop a long-term, 4: current -> long */
+            const int want = pct(60) ? 1 + rnd(opt_mmco5 ? 5 : 4) : 0;   /* 1: drop a short-term, 2: short -> long, 3: drop a long-term, 4: current -> long, 5: drop everything */
             int pick = -1;
             if (want == 1 || want == 2) { int k = n_short ? rnd(n_short) : -1; for (int i = 0; i < 8 && k >= 0; i++) if (wdpb[i].used && !wdpb[i].is_long && k-- == 0) pick = i; }
             if (want == 3) { int k = n_long ? rnd(n_long) : -1; for (int i = 0; i < 8 && k >= 0; i++) if (wdpb[i].used && wdpb[i].is_long && k-- == 0) pick = i; }
@@ -497,6 +497,12 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
                 wdpb[pick].is_long = 1; wdpb[pick].long_idx = li;
             } else if (want == 3 && pick >= 0 && cnt > 1) {
                 cmd[n_cmd][0] = 2; cmd[n_cmd][1] = wdpb[pick].long_idx; n_cmd++; wdpb[pick].used = 0;
+            } else if (want == 5) {
+                /* operation 5: every other reference goes, and the picture counts as frame_num 0 from here on (7.4.3, 8.2.1):
+                 * the next picture is written with frame_num 1 (main loop) */
+                cmd[n_cmd][0] = 5; n_cmd++;
+                for (int i = 0; i < 8; i++) wdpb[i].used = 0;
+                had_mmco5 = 1;
             } else if (want == 4) {
                 const int li = rnd(2);
                 cmd[n_cmd][0] = 6; cmd[n_cmd][2] = li; n_cmd++;
@@ -517,7 +523,7 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
                 if (cnt >= opt_refs && old >= 0) wdpb[old].used = 0;
             }
         }
-        for (int i = 0; i < 8; i++) if (!wdpb[i].used) { wdpb[i].used = 1; wdpb[i].pic = pic_no; wdpb[i].frame_num = frame_num; wdpb[i].is_long = cur_long; wdpb[i].long_idx = cur_long_idx; break; }
+        for (int i = 0; i < 8; i++) if (!wdpb[i].used) { wdpb[i].used = 1; wdpb[i].pic = pic_no; wdpb[i].frame_num = had_mmco5 ? 0 : frame_num; wdpb[i].is_long = cur_long; wdpb[i].long_idx = cur_long_idx; break; }
     }
     for (int sl = 0; sl < opt_slices; sl++) {
         const int first = (int)((long)NMB * sl / opt_slices), end = (int)((long)NMB * (sl + 1) / opt_slices);
@@ -605,6 +611,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--reorder")) opt_reorder = 1;
         else if (!strcmp(a, "--pps-alt")) opt_pps_alt = 1;
         else if (!strcmp(a, "--mmco")) opt_mmco = 1;
+        else if (!strcmp(a, "--mmco5")) opt_mmco = opt_mmco5 = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
     if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > (opt_mmco ? 4 : 2) || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
@@ -641,10 +648,11 @@ int main(int argc, char **argv)
         int idr = intra_only || n == 0 || (gop > 0 && n % gop == 0);
         if (idr) { frame_num = 0; since_idr = 0; }
         cur_pps = opt_pps_alt ? (n & 1) : 0;
+        had_mmco5 = 0;
         put_slice(f, idr, !idr, frame_num, idr_id, log2_fn, since_idr, n);   /* since_idr = reference pictures available (sliding window) */
         since_idr++;
         if (idr) idr_id = (idr_id + 1) & 0xffff;
-        frame_num = (frame_num + 1) & ((1 << log2_fn) - 1);
+        frame_num = had_mmco5 ? 1 : (frame_num + 1) & ((1 << log2_fn) - 1);
     }
     fclose(f);
     if (dump_mv) fclose(dump_mv);

@@ -1,7 +1,7 @@
 """The two row-wavefront kernels pick their workgroup shape from the batch size (pictures vs compute units):
 k_deblock walks bands of 8 / 4 / 2 macroblock rows with 1 / 2 / 4 pictures per workgroup, k_intra uses 16 or 8
 wavefronts per picture.  A test batch is far smaller than an MI355X, so every shape is forced through the
-P264AMD_* knobs (read at each launch) and checked against the CPU oracle, picture by picture, on every stream."""
+P264AMD_* knobs (read once, when the context is created) and checked against the CPU oracle, picture by picture, on every stream."""
 import os
 
 import numpy as np
@@ -37,6 +37,31 @@ def test_workgroup_shapes(lib, oracle, case, rb, per_wg, intra_waves, monkeypatc
             got = hip.read_frame(s, p.desc.dst_slot)
             for plane, (a, b) in enumerate(zip(got, want)):
                 assert np.array_equal(a, b), "%s shape (%s,%s,%s): picture %d stream %d plane %d differs" % (case, rb, per_wg, intra_waves, i, s, plane)
+    hip.close()
+
+
+@pytest.mark.parametrize("band_log2,wgs,concurrent", [("0", "4", "1"), ("2", "7", "1"), ("6", "200", "0"), ("1", "16", "0")])
+def test_mc_launch_knobs(lib, oracle, band_log2, wgs, concurrent, monkeypatch):
+    """The other launch paths no default run takes: locality bands of the motion-compensation lists of 1 / 4 / 64 macroblock
+    rows (more or fewer keys and chunks), few or many workgroups per picture in the fused launch (down to one workgroup per
+    role), and the side-stream fork / join of k_deblock_bs (P264AMD_CONCURRENT)."""
+    monkeypatch.setenv("P264AMD_MC_BAND_LOG2", band_log2)
+    monkeypatch.setenv("P264AMD_MC_WGS_PER_PIC", wgs)
+    monkeypatch.setenv("P264AMD_CONCURRENT", concurrent)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("cif_ip"))[:10]
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    S = 5
+    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=parser.slots, max_pictures=len(pics), lib=lib)
+    hip.upload(0, pics)
+    for i, p in enumerate(pics):
+        want = oracle_bind.reconstruct(oracle, store, p)
+        hip.reconstruct([i] * S, list(range(S)))
+        for s in (0, S - 1):
+            got = hip.read_frame(s, p.desc.dst_slot)
+            for plane, (a, b) in enumerate(zip(got, want)):
+                assert np.array_equal(a, b), "band %s wgs %s concurrent %s: picture %d stream %d plane %d differs" % (band_log2, wgs, concurrent, i, s, plane)
     hip.close()
 
 

@@ -5,10 +5,13 @@
  * HIP layer uploads as they are.
  *
  * Supported subset = what the reference decodes: CAVLC, I and P slices,
- * frame MBs, one reference list.  Beyond it we follow ITU-T H.264 where that is cheap
- * (several slices per picture, multiple reference frames, list-0 reordering of short-term
- * pictures, sub-8x8 partitions); everything else is rejected with -1 and a line on stderr,
- * the reference's error convention (decoder/decoder.c:558-577,780-795).
+ * frame MBs, one reference list.  Beyond it we follow ITU-T H.264 (several slices per picture,
+ * multiple reference frames, list reordering, sub-8x8 partitions, memory management control
+ * operations, and - SURVEY 8f rank 4, where the reference stops at decoder/lists.c:136 and
+ * decoder/macroblock.c:168-171 - CAVLC B slices: two lists ordered by picture order count,
+ * every B macroblock and sub-macroblock type, spatial and temporal direct prediction, implicit
+ * bi-prediction weights); everything else is rejected with -1 and a line on stderr, the
+ * reference's error convention (decoder/decoder.c:558-577,780-795).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,7 +33,7 @@ typedef struct {
     int valid, profile_idc, level_idc;
     int log2_max_frame_num, poc_type, log2_max_poc_lsb;
     int delta_pic_order_always_zero, num_ref_frames_in_poc_cycle;
-    int num_ref_frames, gaps_allowed, mb_w, mb_h, frame_mbs_only;
+    int num_ref_frames, gaps_allowed, mb_w, mb_h, frame_mbs_only, direct_8x8_inference;
     int crop[4];
 } sps_t;
 
@@ -44,14 +47,18 @@ typedef struct {
     int first_mb, type, pps_id, frame_num, idr_pic_id;
     int num_ref_idx, qp, disable_deblock, alpha_off, beta_off;
     int n_reorder; struct { int idc, arg; } reorder[34];
+    int num_ref_idx_l1, n_reorder1; struct { int idc, arg; } reorder1[34];   /* B slices: list 1 */
+    int poc_lsb, delta_poc_bottom, direct_spatial;
     int no_output_of_prior, long_term_flag, adaptive_marking;
     int n_mmco; struct { int op, a, b; } mmco[34];   /* memory_management_control_operation 1..6 and its operands */
 } slice_t;
 
-typedef struct { int used, frame_num, pic_num, is_long, long_idx; } dpb_frame_t;   /* long_idx = LongTermFrameIdx (= LongTermPicNum for frames) */
+typedef struct { int used, frame_num, pic_num, is_long, long_idx;   /* long_idx = LongTermFrameIdx (= LongTermPicNum for frames) */
+                 int poc; uint32_t uid; } dpb_frame_t;              /* picture order count; uid: which decoded picture the slot holds */
 
 typedef struct {
     p264hip_mb_t *mb; int16_t *mv; int8_t *ref; uint8_t *i4; int16_t *coef;
+    int16_t *mv1; int8_t *ref1;               /* list 1 (B pictures; allocated with the others for non-Baseline streams) */
     size_t coef_cap, coef_n;
     void *(*alloc)(size_t); void (*release)(void *);   /* where the arrays live (p264parse_set_allocator) */
 } picbuf_t;
@@ -76,6 +83,17 @@ struct p264parse {
     slice_t sh0;                              /* first slice of the picture */
     int pic_deblock, pic_alpha, pic_beta;     /* loop filter of the picture: on if any slice enables it, offsets of the first such slice */
     int list0[P264HIP_MAX_REFS], n_list0;
+    int list1[P264HIP_MAX_REFS], n_list1;     /* B pictures */
+    int16_t bipred_weight[P264HIP_MAX_REFS * P264HIP_MAX_REFS];   /* implicit weights of the picture (8.4.2.3.1) */
+    int weighted_bipred;
+    /* picture order count (8.2.1) */
+    int cur_poc, prev_poc_msb, prev_poc_lsb, prev_frame_num, frame_num_offset;
+    uint32_t next_uid, cur_uid;
+    /* motion of every reference picture, kept for the direct prediction of later B pictures (the co-located picture is
+     * RefPicList1[0]): per frame-store slot, per 4x4 block the vector, per 8x8 the reference index it used and the uid of the
+     * picture that index meant (-1 = intra) */
+    int has_col;
+    int16_t *col_mv[P264HIP_MAX_REFS + 1]; int8_t *col_ref[P264HIP_MAX_REFS + 1]; int32_t *col_uid[P264HIP_MAX_REFS + 1];
 
     dpb_frame_t dpb[P264HIP_MAX_REFS + 1];
     int cur_slot;
@@ -84,7 +102,7 @@ struct p264parse {
 
     /* current MB */
     int mbx, mby, mbi;
-    unsigned mv_done;                         /* bit (y*4+x): that 4x4 of the current MB has its MV */
+    unsigned mv_done, mv_done1;               /* bit (y*4+x): that 4x4 of the current MB has its list-0 / list-1 motion */
     int      cur_avail;                       /* P264_AVAIL_* of the current MB (set by begin_mb) */
     int skip_run;
 };
@@ -128,7 +146,7 @@ static int parse_sps(p264parse *p, bitrd_t *b)
     s->mb_h = (int)br_ue(b) + 1;
     s->frame_mbs_only = (int)br_u1(b);
     if (!s->frame_mbs_only) br_u1(b);
-    br_u1(b);                                       /* direct_8x8_inference */
+    s->direct_8x8_inference = (int)br_u1(b);
     if (br_u1(b)) for (int i = 0; i < 4; i++) s->crop[i] = (int)br_ue(b);   /* parsed, never applied (A-Q1) */
     br_u1(b);                                       /* vui_parameters_present: not parsed, like set.c:136-144 */
     if (br_eof(b)) { ERR(p, "incomplete SPS"); return -1; }
@@ -183,7 +201,7 @@ static int parse_pps(p264parse *p, bitrd_t *b)
 /* ---------------------------------------------------------------- context --------------- */
 static void release_bufs(picbuf_t *q)
 {
-    if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); }
+    if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); if (q->mv1) q->release(q->mv1); if (q->ref1) q->release(q->ref1); }
     memset(q, 0, sizeof *q);
 }
 /* A caller may still be reading the last completed picture's arrays when the next slice re-initialises the context (the
@@ -198,6 +216,8 @@ static void free_context(p264parse *p, int final)
     }
     free(p->nnz); p->nnz = NULL;
     free(p->slice_of); p->slice_of = NULL;
+    for (int i = 0; i <= P264HIP_MAX_REFS; i++) { free(p->col_mv[i]); free(p->col_ref[i]); free(p->col_uid[i]); p->col_mv[i] = NULL; p->col_ref[i] = NULL; p->col_uid[i] = NULL; }
+    p->has_col = 0;
 }
 
 /* decoder/decoder.c:304-343: (re)size everything when the active SPS/PPS pair changes */
@@ -221,6 +241,19 @@ static int init_context(p264parse *p, int sps_id, int pps_id)
         if (!q->mb || !q->mv || !q->ref || !q->i4 || !q->coef) return -1;
         memset(q->mb, 0, n * sizeof(p264hip_mb_t)); memset(q->mv, 0, n * 32 * sizeof(int16_t));
         memset(q->ref, 0, n * 4); memset(q->i4, 0, n * 16);
+        if (s->profile_idc != 66) {                 /* anything but Baseline may carry B slices: list-1 arrays */
+            q->mv1 = (int16_t *)q->alloc(n * 32 * sizeof(int16_t)); q->ref1 = (int8_t *)q->alloc(n * 4);
+            if (!q->mv1 || !q->ref1) return -1;
+            memset(q->mv1, 0, n * 32 * sizeof(int16_t)); memset(q->ref1, -1, n * 4);
+        }
+    }
+    if (s->profile_idc != 66) {
+        for (int i = 0; i < p->slots; i++) {
+            p->col_mv[i] = (int16_t *)calloc(n * 32, sizeof(int16_t)); p->col_ref[i] = (int8_t *)malloc(n * 4); p->col_uid[i] = (int32_t *)malloc(n * 4 * sizeof(int32_t));
+            if (!p->col_mv[i] || !p->col_ref[i] || !p->col_uid[i]) return -1;
+            memset(p->col_ref[i], -1, n * 4); memset(p->col_uid[i], 0xff, n * 4 * sizeof(int32_t));
+        }
+        p->has_col = 1;
     }
     p->nnz = (uint8_t *)calloc(n, 24);
     p->slice_of = (uint16_t *)malloc(n * sizeof(uint16_t));
@@ -249,36 +282,43 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
     const pps_t *pps = &p->pps[sh->pps_id];
     if (!p->sps[pps->sps_id].valid) { ERR(p, "slice refers to missing sps %d", pps->sps_id); return -1; }
     const sps_t *sps = &p->sps[pps->sps_id];
-    if (sh->type != P264_SLICE_P && sh->type != P264_SLICE_I) { ERR(p, "only I/P slices supported (type %d)", sh->type); return -1; }
+    if (sh->type != P264_SLICE_P && sh->type != P264_SLICE_I && sh->type != P264_SLICE_B) { ERR(p, "only I, P and B slices supported (type %d)", sh->type); return -1; }
+    if (sh->type == P264_SLICE_B && (sps->profile_idc == 66 || nal_type == NAL_SLICE_IDR)) { ERR(p, "B slice in a Baseline stream or an IDR picture"); return -1; }
+    if (sh->type == P264_SLICE_B && sps->poc_type == 1) { ERR(p, "B slices with pic_order_cnt_type 1 unsupported"); return -1; }
     if (pps->cabac) { ERR(p, "CABAC unsupported (decoder/macroblock.c:594-597)"); return -1; }
     if (!sps->frame_mbs_only) { ERR(p, "field/MBAFF coding unsupported"); return -1; }
 
     sh->frame_num = (int)br_u(b, sps->log2_max_frame_num);
     if (nal_type == NAL_SLICE_IDR) sh->idr_pic_id = (int)br_ue(b);
     if (sps->poc_type == 0) {
-        br_u(b, sps->log2_max_poc_lsb);
-        if (pps->pic_order_present) br_se(b);
+        sh->poc_lsb = (int)br_u(b, sps->log2_max_poc_lsb);
+        if (pps->pic_order_present) sh->delta_poc_bottom = br_se(b);
     } else if (sps->poc_type == 1 && !sps->delta_pic_order_always_zero) {
         br_se(b);
         if (pps->pic_order_present) br_se(b);
     }
     if (pps->redundant_pic_cnt && br_ue(b) != 0) return 1;       /* redundant picture: ignore the slice */
     sh->num_ref_idx = 0;
-    if (sh->type == P264_SLICE_P) {
-        sh->num_ref_idx = pps->num_ref_idx_l0;
-        if (br_u1(b)) sh->num_ref_idx = (int)br_ue(b) + 1;
+    if (sh->type == P264_SLICE_B) sh->direct_spatial = (int)br_u1(b);
+    if (sh->type == P264_SLICE_P || sh->type == P264_SLICE_B) {
+        sh->num_ref_idx = pps->num_ref_idx_l0; sh->num_ref_idx_l1 = pps->num_ref_idx_l1;
+        if (br_u1(b)) { sh->num_ref_idx = (int)br_ue(b) + 1; if (sh->type == P264_SLICE_B) sh->num_ref_idx_l1 = (int)br_ue(b) + 1; }
         if (sh->num_ref_idx < 1 || sh->num_ref_idx > P264HIP_MAX_REFS) { ERR(p, "num_ref_idx_l0_active %d too large", sh->num_ref_idx); return -1; }
-        if (br_u1(b)) {                                           /* ref_pic_list_reordering_flag_l0 */
+        if (sh->type == P264_SLICE_B && (sh->num_ref_idx_l1 < 1 || sh->num_ref_idx_l1 > P264HIP_MAX_REFS)) { ERR(p, "num_ref_idx_l1_active %d too large", sh->num_ref_idx_l1); return -1; }
+        for (int l = 0; l < (sh->type == P264_SLICE_B ? 2 : 1); l++) {
+            if (!br_u1(b)) continue;                              /* ref_pic_list_reordering_flag_l0 / _l1 */
             for (;;) {
                 unsigned idc = br_ue(b);
+                int *n = l ? &sh->n_reorder1 : &sh->n_reorder;
                 if (idc == 3) break;
-                if (idc > 3 || sh->n_reorder >= 33 || br_overrun(b)) { ERR(p, "wrong reordering of pic nums idc"); return -1; }
-                sh->reorder[sh->n_reorder].idc = (int)idc;
-                sh->reorder[sh->n_reorder].arg = (int)br_ue(b);
-                sh->n_reorder++;
+                if (idc > 3 || *n >= 33 || br_overrun(b)) { ERR(p, "wrong reordering of pic nums idc"); return -1; }
+                if (l) { sh->reorder1[*n].idc = (int)idc; sh->reorder1[*n].arg = (int)br_ue(b); }
+                else   { sh->reorder[*n].idc = (int)idc; sh->reorder[*n].arg = (int)br_ue(b); }
+                (*n)++;
             }
         }
-        if (pps->weighted_pred) { ERR(p, "weighted prediction unsupported (decoder/decoder.c:259-262)"); return -1; }
+        if (pps->weighted_pred && sh->type == P264_SLICE_P) { ERR(p, "weighted prediction unsupported (decoder/decoder.c:259-262)"); return -1; }
+        if (pps->weighted_bipred == 1 && sh->type == P264_SLICE_B) { ERR(p, "explicit weighted bi-prediction unsupported (decoder/decoder.c:259-262)"); return -1; }
     }
     if (nal_ref_idc != 0) {
         if (nal_type == NAL_SLICE_IDR) { sh->no_output_of_prior = (int)br_u1(b); sh->long_term_flag = (int)br_u1(b); }
@@ -313,44 +353,96 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
 }
 
 /* ---------------------------------------------------------------- frame store ----------- */
-/* List 0 of a P picture (H.264 8.2.4.2.1, 8.2.4.3): short-term pictures by descending PicNum (decoder/lists.c:72-143),
- * then long-term pictures by ascending LongTermPicNum, then the slice's reordering commands (short-term: idc 0 / 1,
- * long-term: idc 2; the reference ignores them, decoder/lists.c:146-149). */
-static int build_list0(p264parse *p, const slice_t *sh)
+/* Picture order count of the picture whose first slice header is sh (H.264 8.2.1; frames only: PicOrderCnt =
+ * Min(TopFieldOrderCnt, BottomFieldOrderCnt)).  Types 0 and 2; type 1 is only ever met in streams without B slices,
+ * where nothing depends on the count.  The state behind it (prevPicOrderCntMsb / Lsb, prevFrameNumOffset) moves on in
+ * finish_picture_marking. */
+static int poc_msb_of(const p264parse *p, const sps_t *sps, const slice_t *sh, int idr)
+{
+    const int max_lsb = 1 << sps->log2_max_poc_lsb, prev_msb = idr ? 0 : p->prev_poc_msb, prev_lsb = idr ? 0 : p->prev_poc_lsb;
+    if (sh->poc_lsb < prev_lsb && prev_lsb - sh->poc_lsb >= max_lsb / 2) return prev_msb + max_lsb;
+    if (sh->poc_lsb > prev_lsb && sh->poc_lsb - prev_lsb > max_lsb / 2) return prev_msb - max_lsb;
+    return prev_msb;
+}
+static int frame_num_offset_of(const p264parse *p, const sps_t *sps, const slice_t *sh, int idr)
+{
+    if (idr) return 0;
+    return p->prev_frame_num > sh->frame_num ? p->frame_num_offset + (1 << sps->log2_max_frame_num) : p->frame_num_offset;
+}
+static int picture_order_count(const p264parse *p, const slice_t *sh, int idr, int nal_ref_idc)
 {
     const sps_t *sps = &p->sps[p->active_sps];
-    int max_fn = 1 << sps->log2_max_frame_num;
-    int idx[P264HIP_MAX_REFS + 1], n = 0, n_short;
-    for (int i = 0; i < p->slots; i++) {
-        if (!p->dpb[i].used || p->dpb[i].is_long || i == p->cur_slot) continue;
-        p->dpb[i].pic_num = p->dpb[i].frame_num > sh->frame_num ? p->dpb[i].frame_num - max_fn : p->dpb[i].frame_num;
-        int j = n++;
-        while (j > 0 && p->dpb[idx[j-1]].pic_num < p->dpb[i].pic_num) { idx[j] = idx[j-1]; j--; }
-        idx[j] = i;
+    if (sps->poc_type == 0) {
+        const int top = poc_msb_of(p, sps, sh, idr) + sh->poc_lsb, bottom = top + sh->delta_poc_bottom;
+        return top < bottom ? top : bottom;
     }
-    n_short = n;
-    for (int i = 0; i < p->slots; i++) {
-        if (!p->dpb[i].used || !p->dpb[i].is_long || i == p->cur_slot) continue;
-        int j = n++;
-        while (j > n_short && p->dpb[idx[j-1]].long_idx > p->dpb[i].long_idx) { idx[j] = idx[j-1]; j--; }
-        idx[j] = i;
+    if (sps->poc_type == 2) return idr ? 0 : 2 * (frame_num_offset_of(p, sps, sh, idr) + sh->frame_num) - (nal_ref_idc == 0);
+    return 0;
+}
+
+/* Reference list X of the slice (H.264 8.2.4.2, 8.2.4.3).  Initial order - P slices: short-term pictures by descending
+ * PicNum (decoder/lists.c:72-143); B slices (the reference stops at decoder/lists.c:136): list 0 the short-term pictures
+ * before the current one in output order, nearest first, then those after it, nearest first - list 1 the other way round;
+ * both: then the long-term pictures by ascending LongTermPicNum; a list 1 of more than one entry that equals list 0 gets its
+ * first two entries swapped.  Then the slice's reordering commands (short-term: idc 0 / 1, long-term: idc 2; the reference
+ * ignores them, decoder/lists.c:146-149). */
+static int build_list(p264parse *p, const slice_t *sh, int X, int *out)
+{
+    const sps_t *sps = &p->sps[p->active_sps];
+    const int max_fn = 1 << sps->log2_max_frame_num, isB = sh->type == P264_SLICE_B;
+    int idx[2][P264HIP_MAX_REFS + 1], n = 0, n_short;
+    for (int L = 0; L < (isB ? 2 : 1); L++) {
+        n = 0;
+        for (int i = 0; i < p->slots; i++) {
+            if (!p->dpb[i].used || p->dpb[i].is_long || i == p->cur_slot) continue;
+            p->dpb[i].pic_num = p->dpb[i].frame_num > sh->frame_num ? p->dpb[i].frame_num - max_fn : p->dpb[i].frame_num;
+            int j = n++;
+            if (!isB) while (j > 0 && p->dpb[idx[L][j-1]].pic_num < p->dpb[i].pic_num) { idx[L][j] = idx[L][j-1]; j--; }
+            else {
+                /* order key: list 0 wants POC below the current one first, descending, then the rest ascending; list 1 the mirror image */
+                const int before_i = p->dpb[i].poc < p->cur_poc;
+                for (; j > 0; j--) {
+                    const dpb_frame_t *o = &p->dpb[idx[L][j-1]];
+                    const int before_o = o->poc < p->cur_poc;
+                    int i_first;
+                    if (before_i != before_o) i_first = L == 0 ? before_i : !before_i;
+                    else i_first = before_i ? p->dpb[i].poc > o->poc : p->dpb[i].poc < o->poc;     /* nearest first on either side */
+                    if (!i_first) break;
+                    idx[L][j] = idx[L][j-1];
+                }
+            }
+            idx[L][j] = i;
+        }
+        n_short = n;
+        for (int i = 0; i < p->slots; i++) {
+            if (!p->dpb[i].used || !p->dpb[i].is_long || i == p->cur_slot) continue;
+            int j = n++;
+            while (j > n_short && p->dpb[idx[L][j-1]].long_idx > p->dpb[i].long_idx) { idx[L][j] = idx[L][j-1]; j--; }
+            idx[L][j] = i;
+        }
     }
-    if (n == 0) { ERR(p, "P slice without a reference picture"); return -1; }
-    int len = sh->num_ref_idx;
+    n_short = 0;
+    for (int i = 0; i < p->slots; i++) if (p->dpb[i].used && !p->dpb[i].is_long && i != p->cur_slot) n_short++;
+    if (n == 0) { ERR(p, "%s slice without a reference picture", isB ? "B" : "P"); return -1; }
+    if (isB && n > 1 && !memcmp(idx[0], idx[1], sizeof(int) * (size_t)n)) { const int t = idx[1][0]; idx[1][0] = idx[1][1]; idx[1][1] = t; }
+    const int *ini = idx[isB ? X : 0];
+    const int len = X ? sh->num_ref_idx_l1 : sh->num_ref_idx;
+    const int n_cmd = X ? sh->n_reorder1 : sh->n_reorder;
     int list[P264HIP_MAX_REFS + 1];
-    for (int i = 0; i < len; i++) list[i] = idx[i < n ? i : n - 1];
+    for (int i = 0; i < len; i++) list[i] = ini[i < n ? i : n - 1];
     int pred = sh->frame_num, at = 0;
-    for (int k = 0; k < sh->n_reorder && at < len; k++) {
-        int idc = sh->reorder[k].idc, slot = -1;
+    for (int k = 0; k < n_cmd && at < len; k++) {
+        const int idc = X ? sh->reorder1[k].idc : sh->reorder[k].idc, arg = X ? sh->reorder1[k].arg : sh->reorder[k].arg;
+        int slot = -1;
         if (idc == 2) {                                   /* long_term_pic_num */
-            for (int i = n_short; i < n; i++) if (p->dpb[idx[i]].long_idx == sh->reorder[k].arg) slot = idx[i];
+            for (int i = n_short; i < n; i++) if (p->dpb[ini[i]].long_idx == arg) slot = ini[i];
         } else {
-            int d = sh->reorder[k].arg + 1;
+            int d = arg + 1;
             pred = idc == 0 ? pred - d : pred + d;
             if (pred < 0) pred += max_fn;
             if (pred >= max_fn) pred -= max_fn;
             int want = pred > sh->frame_num ? pred - max_fn : pred;
-            for (int i = 0; i < n_short; i++) if (p->dpb[idx[i]].pic_num == want) slot = idx[i];
+            for (int i = 0; i < p->slots; i++) if (p->dpb[i].used && !p->dpb[i].is_long && i != p->cur_slot && p->dpb[i].pic_num == want) slot = i;
         }
         if (slot < 0) { ERR(p, "reordering names a picture that is not in the frame store"); return -1; }
         for (int i = len; i > at; i--) list[i] = list[i-1];
@@ -358,9 +450,29 @@ static int build_list0(p264parse *p, const slice_t *sh)
         int w = at;
         for (int r = at; r <= len; r++) if (list[r] != slot) list[w++] = list[r];
     }
-    p->n_list0 = len;
-    for (int i = 0; i < len; i++) p->list0[i] = list[i];
-    return 0;
+    for (int i = 0; i < len; i++) out[i] = list[i];
+    return len;
+}
+
+/* Implicit bi-prediction weights of the picture (H.264 8.4.2.3.1 with weighted_bipred_idc 2; the reference computes the same
+ * numbers in p264_macroblock_bipred_init, core/macroblock.c:1400-1430): weight of the list-0 prediction for every pair of
+ * reference indices; 32 (the plain average) where the distances do not give a weight in -64 .. 128. */
+static void implicit_weights(p264parse *p)
+{
+    for (int r0 = 0; r0 < P264HIP_MAX_REFS; r0++)
+        for (int r1 = 0; r1 < P264HIP_MAX_REFS; r1++) {
+            int w0 = 32;
+            if (p->weighted_bipred && r0 < p->n_list0 && r1 < p->n_list1) {
+                const dpb_frame_t *f0 = &p->dpb[p->list0[r0]], *f1 = &p->dpb[p->list1[r1]];
+                const int td = clip3i(f1->poc - f0->poc, -128, 127), tb = clip3i(p->cur_poc - f0->poc, -128, 127);
+                if (td != 0 && !f0->is_long && !f1->is_long) {
+                    const int tx = (16384 + (td < 0 ? -td : td) / 2) / td;
+                    const int dsf = clip3i((tb * tx + 32) >> 6, -1024, 1023) >> 2;
+                    if (dsf >= -64 && dsf <= 128) w0 = 64 - dsf;
+                }
+            }
+            p->bipred_weight[r0 * P264HIP_MAX_REFS + r1] = (int16_t)w0;
+        }
 }
 
 /* Reference picture marking (H.264 8.2.5; the reference implements the sliding window only, decoder/lists.c:152-228) and
@@ -419,6 +531,32 @@ static void finish_picture_marking(p264parse *p)
     /* after memory_management_control_operation 5 the picture is inferred to have had frame_num 0 (H.264 7.4.3, 8.2.1): the
      * pictures that follow compute their PicNums against that */
     if (p->pic_ref_idc) { cur->used = 1; cur->frame_num = had_mmco5 ? 0 : p->sh0.frame_num; cur->is_long = cur_long; cur->long_idx = cur_long_idx; }
+    /* picture order count: what the pictures behind this one measure theirs against (8.2.1; after operation 5 the picture
+     * counts as POC 0 - frames, bottom not below top) */
+    cur->poc = had_mmco5 ? 0 : p->cur_poc; cur->uid = p->cur_uid;
+    if (sps->poc_type == 0 && p->pic_ref_idc) {
+        p->prev_poc_msb = had_mmco5 ? 0 : poc_msb_of(p, sps, &p->sh0, p->pic_is_idr);
+        p->prev_poc_lsb = had_mmco5 ? 0 : p->sh0.poc_lsb;
+    }
+    if (sps->poc_type == 2) { p->frame_num_offset = had_mmco5 ? 0 : frame_num_offset_of(p, sps, &p->sh0, p->pic_is_idr); p->prev_frame_num = had_mmco5 ? 0 : p->sh0.frame_num; }
+    /* the motion of a reference picture is what the direct prediction of later B pictures reads (8.4.1.2) */
+    if (p->pic_ref_idc && p->has_col) {
+        const picbuf_t *q = &p->buf[p->cur];
+        int16_t *cm = p->col_mv[p->cur_slot]; int8_t *cr = p->col_ref[p->cur_slot]; int32_t *cu = p->col_uid[p->cur_slot];
+        const int isB = p->sh0.type == P264_SLICE_B;
+        for (int i = 0; i < p->n_mb * 4; i++) {
+            const int r0 = q->ref[i], r1 = isB ? q->ref1[i] : -1;
+            const int mbi = i >> 2, q8 = i & 3, b0 = (q8 >> 1) * 8 + (q8 & 1) * 2;
+            const int16_t *src = r0 >= 0 || r1 < 0 ? q->mv : q->mv1;                          /* the list-0 motion if there is one, else list 1 */
+            const int r = r0 >= 0 ? r0 : r1;
+            cr[i] = (int8_t)r;
+            cu[i] = r < 0 ? -1 : (int32_t)p->dpb[r0 >= 0 ? p->list0[r0 < p->n_list0 ? r0 : 0] : p->list1[r1 < p->n_list1 ? r1 : 0]].uid;
+            for (int k = 0; k < 4; k++) {
+                const int blk = b0 + (k >> 1) * 4 + (k & 1);
+                cm[(mbi * 16 + blk) * 2] = r < 0 ? 0 : src[(mbi * 16 + blk) * 2]; cm[(mbi * 16 + blk) * 2 + 1] = r < 0 ? 0 : src[(mbi * 16 + blk) * 2 + 1];
+            }
+        }
+    }
     /* next picture goes into a slot that holds no reference */
     int next = -1;
     for (int i = 0; i < p->slots; i++) if (!p->dpb[i].used) { next = i; break; }
@@ -446,28 +584,30 @@ static inline int mb_avail(const p264parse *p, int mbx, int mby)
 typedef struct { int ref, mvx, mvy; } nbmv_t;      /* ref: -2 unavailable, -1 intra */
 
 /* motion data of the 4x4 block at picture position (x4,y4), as a predictor for the current MB */
-static nbmv_t nb_motion(const p264parse *p, int x4, int y4)
+static nbmv_t nb_motion_l(const p264parse *p, int x4, int y4, int list)
 {
     nbmv_t r = { -2, 0, 0 };
     if (x4 < 0 || y4 < 0) return r;
     int mx = x4 >> 2, my = y4 >> 2;
     if (mx >= p->mb_w || my >= p->mb_h) return r;
     int i = my * p->mb_w + mx, sub = (y4 & 3) * 4 + (x4 & 3);
-    if (i == p->mbi) { if (!((p->mv_done >> sub) & 1)) return r; }
+    if (i == p->mbi) { if (!(((list ? p->mv_done1 : p->mv_done) >> sub) & 1)) return r; }
     else if (!(i < p->mbi && p->slice_of[i] == (uint16_t)p->slice_no)) return r;
     const picbuf_t *q = &p->buf[p->cur];
-    r.ref = q->ref[i * 4 + ((y4 & 2) | ((x4 >> 1) & 1))];
-    r.mvx = q->mv[(i * 16 + sub) * 2]; r.mvy = q->mv[(i * 16 + sub) * 2 + 1];
+    const int8_t *ref = list ? q->ref1 : q->ref; const int16_t *mv = list ? q->mv1 : q->mv;
+    r.ref = ref[i * 4 + ((y4 & 2) | ((x4 >> 1) & 1))];     /* -1: intra, or (B pictures) this list is not used there */
+    r.mvx = mv[(i * 16 + sub) * 2]; r.mvy = mv[(i * 16 + sub) * 2 + 1];
     return r;
 }
+static nbmv_t nb_motion(const p264parse *p, int x4, int y4) { return nb_motion_l(p, x4, y4, 0); }
 
 /* H.264 8.4.1.3 (core/macroblock.c:87-175).  (bx,by,bw) in 4x4 units inside the MB;
  * dir: 0 none, 1 = 16x8 upper, 2 = 16x8 lower, 3 = 8x16 left, 4 = 8x16 right. */
-static void predict_mv(const p264parse *p, int bx, int by, int bw, int ref, int dir, int *px, int *py)
+static void predict_mv_l(const p264parse *p, int bx, int by, int bw, int ref, int dir, int *px, int *py, int list)
 {
     int x0 = p->mbx * 4 + bx, y0 = p->mby * 4 + by;
-    nbmv_t a = nb_motion(p, x0 - 1, y0), b = nb_motion(p, x0, y0 - 1), c = nb_motion(p, x0 + bw, y0 - 1);
-    if (c.ref == -2) c = nb_motion(p, x0 - 1, y0 - 1);
+    nbmv_t a = nb_motion_l(p, x0 - 1, y0, list), b = nb_motion_l(p, x0, y0 - 1, list), c = nb_motion_l(p, x0 + bw, y0 - 1, list);
+    if (c.ref == -2) c = nb_motion_l(p, x0 - 1, y0 - 1, list);
     if (dir == 1 && b.ref == ref) { *px = b.mvx; *py = b.mvy; return; }
     if (dir == 2 && a.ref == ref) { *px = a.mvx; *py = a.mvy; return; }
     if (dir == 3 && a.ref == ref) { *px = a.mvx; *py = a.mvy; return; }
@@ -480,17 +620,20 @@ static void predict_mv(const p264parse *p, int bx, int by, int bw, int ref, int 
     if (hits == 0 && b.ref == -2 && c.ref == -2 && a.ref != -2) { *px = a.mvx; *py = a.mvy; return; }
     *px = median3(a.mvx, b.mvx, c.mvx); *py = median3(a.mvy, b.mvy, c.mvy);
 }
+static void predict_mv(const p264parse *p, int bx, int by, int bw, int ref, int dir, int *px, int *py) { predict_mv_l(p, bx, by, bw, ref, dir, px, py, 0); }
 
-static void set_motion(p264parse *p, int bx, int by, int bw, int bh, int mvx, int mvy)
+static void set_motion_l(p264parse *p, int bx, int by, int bw, int bh, int mvx, int mvy, int list)
 {
     picbuf_t *q = &p->buf[p->cur];
+    int16_t *mv = list ? q->mv1 : q->mv;
     for (int y = by; y < by + bh; y++)
         for (int x = bx; x < bx + bw; x++) {
-            q->mv[(p->mbi * 16 + y * 4 + x) * 2] = (int16_t)mvx;
-            q->mv[(p->mbi * 16 + y * 4 + x) * 2 + 1] = (int16_t)mvy;
-            p->mv_done |= 1u << (y * 4 + x);
+            mv[(p->mbi * 16 + y * 4 + x) * 2] = (int16_t)mvx;
+            mv[(p->mbi * 16 + y * 4 + x) * 2 + 1] = (int16_t)mvy;
+            if (list) p->mv_done1 |= 1u << (y * 4 + x); else p->mv_done |= 1u << (y * 4 + x);
         }
 }
+static void set_motion(p264parse *p, int bx, int by, int bw, int bh, int mvx, int mvy) { set_motion_l(p, bx, by, bw, bh, mvx, mvy, 0); }
 
 /* total_coeff predictor nC (H.264 9.2.1; core/macroblock.c:53-65).  blk: 0-15 luma, 16-23 chroma */
 static int predict_nc(const p264parse *p, int blk)
@@ -601,7 +744,7 @@ static int store_coefs(p264parse *p, p264hip_mb_t *m, const mbcoef_t *cf)
 static void begin_mb(p264parse *p, p264hip_mb_t *m)
 {
     memset(m, 0, sizeof *m);
-    p->mv_done = 0;
+    p->mv_done = 0; p->mv_done1 = 0;
     int a = 0;
     if (mb_avail(p, p->mbx - 1, p->mby))     a |= P264_AVAIL_LEFT;
     if (mb_avail(p, p->mbx, p->mby - 1))     a |= P264_AVAIL_TOP;
@@ -651,16 +794,14 @@ static void decode_pskip(p264parse *p)
     finish_mb_qp(p, m, 0, p->sh.qp);
 }
 
-static int parse_mb(p264parse *p, bitrd_t *b)
+/* t: mb_type as read (P slices), intra_t >= 0: the macroblock is intra with that I-slice type (I slices; P / B slices after
+ * their offset of 5 / 23) */
+static int parse_mb_t(p264parse *p, bitrd_t *b, unsigned t, int intra_t)
 {
     picbuf_t *q = &p->buf[p->cur];
     p264hip_mb_t *m = &q->mb[p->mbi];
     mbcoef_t cf; cf.mask = 0;
     begin_mb(p, m);
-    unsigned t = br_ue(b);
-    int intra_t = -1;
-    if (p->sh.type == P264_SLICE_I) intra_t = (int)t;
-    else if (t >= 5) intra_t = (int)t - 5;
     int8_t *ref = q->ref + p->mbi * 4;
     uint8_t *i4 = q->i4 + p->mbi * 16;
 
@@ -670,6 +811,7 @@ static int parse_mb(p264parse *p, bitrd_t *b)
         if (intra_t == 25) { ERR(p, "unsupport i_pcm mb"); return -1; }
         memset(ref, -1, 4);
         memset(q->mv + p->mbi * 32, 0, 64);
+        if (q->mv1) { memset(q->ref1 + p->mbi * 4, -1, 4); memset(q->mv1 + p->mbi * 32, 0, 64); }
         if (intra_t == 0) {
             m->mb_type = P264_MB_I4x4;
             for (int i = 0; i < 16; i++) {
@@ -746,6 +888,225 @@ static int parse_mb(p264parse *p, bitrd_t *b)
     return 0;
 }
 
+/* ---------------------------------------------------------------- B macroblocks ---------- */
+/* The reference has none of this (decoder/macroblock.c:168-171 rejects B macroblock types; its encoder-side helpers
+ * core/macroblock.c:254-429 are not reachable from the decoder): H.264 7.3.5, 7.4.5 (tables 7-14, 7-18), 8.4.1.2. */
+
+/* Direct prediction of the current macroblock (B_Skip, B_Direct_16x16, and the direct 8x8 quadrants of B_8x8): reference
+ * indices per 8x8 quadrant and vectors per 4x4 block for both lists, into dr[2][4] / dm[2][16][2].  Nothing is stored:
+ * the caller copies the quadrants that are direct. */
+typedef struct { int8_t ref[2][4]; int16_t mv[2][16][2]; } direct_t;
+
+static int min_positive(int a, int b) { return (a >= 0 && b >= 0) ? (a < b ? a : b) : (a > b ? a : b); }
+
+static void direct_spatial(const p264parse *p, direct_t *d)
+{   /* 8.4.1.2.2: the reference indices from the neighbours A, B, C of the MACROBLOCK, the vectors from the ordinary 16x16
+     * prediction with them, zero where the co-located block does not move */
+    const int x0 = p->mbx * 4, y0 = p->mby * 4;
+    int ref[2], mv[2][2] = { { 0, 0 }, { 0, 0 } };
+    for (int l = 0; l < 2; l++) {
+        nbmv_t a = nb_motion_l(p, x0 - 1, y0, l), b = nb_motion_l(p, x0, y0 - 1, l), c = nb_motion_l(p, x0 + 4, y0 - 1, l);
+        if (c.ref == -2) c = nb_motion_l(p, x0 - 1, y0 - 1, l);
+        ref[l] = min_positive(a.ref < 0 ? -1 : a.ref, min_positive(b.ref < 0 ? -1 : b.ref, c.ref < 0 ? -1 : c.ref));
+    }
+    const int zero_pred = ref[0] < 0 && ref[1] < 0;
+    if (zero_pred) ref[0] = ref[1] = 0;
+    else for (int l = 0; l < 2; l++) if (ref[l] >= 0) predict_mv_l(p, 0, 0, 4, ref[l], 0, &mv[l][0], &mv[l][1], l);
+    /* colZeroFlag: RefPicList1[0] is a short-term picture and the co-located block used reference index 0 with a vector
+     * inside +-1 (direct_8x8_inference: the corner block of the quadrant speaks for it) */
+    const int col_slot = p->list1[0];
+    const int col_short = !p->dpb[col_slot].is_long;
+    const int8_t *cr = p->col_ref[col_slot] + p->mbi * 4; const int16_t *cm = p->col_mv[col_slot] + p->mbi * 32;
+    const int inf = p->sps[p->active_sps].direct_8x8_inference;
+    for (int blk = 0; blk < 16; blk++) {
+        const int bx = blk & 3, by = blk >> 2, q = (by >> 1) * 2 + (bx >> 1);
+        const int cb = inf ? ((by >> 1) * 3) * 4 + (bx >> 1) * 3 : blk;                          /* corner 4x4 of the quadrant: (0|3, 0|3) */
+        const int col_zero = col_short && cr[q] == 0 && cm[cb * 2] >= -1 && cm[cb * 2] <= 1 && cm[cb * 2 + 1] >= -1 && cm[cb * 2 + 1] <= 1;
+        for (int l = 0; l < 2; l++) {
+            d->ref[l][q] = (int8_t)ref[l];
+            const int z = zero_pred || ref[l] < 0 || (ref[l] == 0 && col_zero);
+            d->mv[l][blk][0] = (int16_t)(z ? 0 : mv[l][0]); d->mv[l][blk][1] = (int16_t)(z ? 0 : mv[l][1]);
+        }
+    }
+}
+
+static void direct_temporal(const p264parse *p, direct_t *d)
+{   /* 8.4.1.2.3: list 0 points at the picture the co-located block referred to, list 1 at RefPicList1[0]; the co-located
+     * vector split in proportion to the picture distances */
+    const int col_slot = p->list1[0];
+    const int8_t *cr = p->col_ref[col_slot] + p->mbi * 4; const int32_t *cu = p->col_uid[col_slot] + p->mbi * 4;
+    const int16_t *cm = p->col_mv[col_slot] + p->mbi * 32;
+    const int inf = p->sps[p->active_sps].direct_8x8_inference;
+    for (int q = 0; q < 4; q++) {
+        int r0 = 0, scale = 0, use_col = 0;                       /* intra co-located block: both indices 0, zero vectors */
+        if (cr[q] >= 0) {
+            r0 = -1;
+            for (int i = 0; i < p->n_list0 && r0 < 0; i++) if ((int32_t)p->dpb[p->list0[i]].uid == cu[q]) r0 = i;   /* lowest index that names that picture */
+            if (r0 < 0) r0 = 0;                                   /* (a stream that dropped it from list 0: not conformant; stay defined) */
+            const dpb_frame_t *f0 = &p->dpb[p->list0[r0]], *f1 = &p->dpb[col_slot];
+            const int tb = clip3i(p->cur_poc - f0->poc, -128, 127), td = clip3i(f1->poc - f0->poc, -128, 127);
+            use_col = 1;
+            if (f0->is_long || td == 0) scale = -1;               /* mvL0 = mvCol, mvL1 = 0 */
+            else { const int tx = (16384 + (td < 0 ? -td : td) / 2) / td; scale = clip3i((tb * tx + 32) >> 6, -1024, 1023); }
+        }
+        d->ref[0][q] = (int8_t)r0; d->ref[1][q] = 0;
+        for (int k = 0; k < 4; k++) {
+            const int bx = (q & 1) * 2 + (k & 1), by = (q >> 1) * 2 + (k >> 1), blk = by * 4 + bx;
+            const int cb = inf ? ((q >> 1) * 3) * 4 + (q & 1) * 3 : blk;
+            const int cx = use_col ? cm[cb * 2] : 0, cy = use_col ? cm[cb * 2 + 1] : 0;
+            int m0x = cx, m0y = cy, m1x = 0, m1y = 0;
+            if (use_col && scale != -1) { m0x = (scale * cx + 128) >> 8; m0y = (scale * cy + 128) >> 8; m1x = m0x - cx; m1y = m0y - cy; }
+            d->mv[0][blk][0] = (int16_t)m0x; d->mv[0][blk][1] = (int16_t)m0y;
+            d->mv[1][blk][0] = (int16_t)m1x; d->mv[1][blk][1] = (int16_t)m1y;
+        }
+    }
+}
+
+static void direct_predict(const p264parse *p, direct_t *d)
+{
+    if (p->sh.direct_spatial) direct_spatial(p, d); else direct_temporal(p, d);
+}
+/* copy quadrant q of a direct prediction into the picture arrays (vectors of an unused list are zero, its index -1) */
+static void store_direct_quadrant(p264parse *p, const direct_t *d, int q, int list)
+{
+    picbuf_t *b = &p->buf[p->cur];
+    (list ? b->ref1 : b->ref)[p->mbi * 4 + q] = d->ref[list][q];
+    for (int k = 0; k < 4; k++) {
+        const int bx = (q & 1) * 2 + (k & 1), by = (q >> 1) * 2 + (k >> 1), blk = by * 4 + bx;
+        const int used = d->ref[list][q] >= 0;
+        set_motion_l(p, bx, by, 1, 1, used ? d->mv[list][blk][0] : 0, used ? d->mv[list][blk][1] : 0, list);
+    }
+}
+
+static void decode_bskip(p264parse *p)
+{
+    picbuf_t *q = &p->buf[p->cur];
+    p264hip_mb_t *m = &q->mb[p->mbi];
+    begin_mb(p, m);
+    m->mb_type = P264_MB_B;
+    memset(p->nnz + (size_t)p->mbi * 24, 0, 24);
+    memset(q->i4 + p->mbi * 16, 2, 16);
+    direct_t d;
+    direct_predict(p, &d);
+    for (int l = 0; l < 2; l++) for (int k = 0; k < 4; k++) store_direct_quadrant(p, &d, k, l);
+    m->coef_index = (uint32_t)q->coef_n;
+    finish_mb_qp(p, m, 0, p->sh.qp);
+}
+
+/* which lists a partition predicts from: bit 0 list 0, bit 1 list 1 */
+enum { PRED_L0 = 1, PRED_L1 = 2, PRED_BI = 3 };
+static const uint8_t b_pair[9][2] = {           /* mb_type 4..21, table 7-14: (type - 4) >> 1 -> prediction of the two partitions */
+    { PRED_L0, PRED_L0 }, { PRED_L1, PRED_L1 }, { PRED_L0, PRED_L1 }, { PRED_L1, PRED_L0 }, { PRED_L0, PRED_BI },
+    { PRED_L1, PRED_BI }, { PRED_BI, PRED_L0 }, { PRED_BI, PRED_L1 }, { PRED_BI, PRED_BI } };
+static const uint8_t b_sub_pred[13] = { 0, PRED_L0, PRED_L1, PRED_BI, PRED_L0, PRED_L0, PRED_L1, PRED_L1, PRED_BI, PRED_BI, PRED_L0, PRED_L1, PRED_BI };   /* table 7-18; 0 = direct */
+static const uint8_t b_sub_w[13] = { 2, 2, 2, 2, 2, 1, 2, 1, 2, 1, 1, 1, 1 }, b_sub_h[13] = { 2, 2, 2, 2, 1, 2, 1, 2, 1, 2, 1, 1, 1 };    /* sub-partition size in 4x4 units */
+
+static int parse_mb_b(p264parse *p, bitrd_t *b)
+{
+    picbuf_t *q = &p->buf[p->cur];
+    p264hip_mb_t *m = &q->mb[p->mbi];
+    unsigned t = br_ue(b);
+    if (t >= 23) {                                            /* intra macroblock in a B slice: the I-slice syntax with the type offset */
+        return parse_mb_t(p, b, t, (int)t - 23);
+    }
+    mbcoef_t cf; cf.mask = 0;
+    begin_mb(p, m);
+    m->mb_type = P264_MB_B;
+    int8_t *ref[2] = { q->ref + p->mbi * 4, q->ref1 + p->mbi * 4 };
+    memset(q->i4 + p->mbi * 16, 2, 16);
+    memset(ref[0], -1, 4); memset(ref[1], -1, 4);
+    memset(q->mv + p->mbi * 32, 0, 64); memset(q->mv1 + p->mbi * 32, 0, 64);
+    const int nref[2] = { p->sh.num_ref_idx, p->sh.num_ref_idx_l1 };
+    int direct_all = 0;
+    if (t == 0) {                                             /* B_Direct_16x16: like B_Skip, with a residual */
+        direct_t d;
+        direct_predict(p, &d);
+        for (int l = 0; l < 2; l++) for (int k = 0; k < 4; k++) store_direct_quadrant(p, &d, k, l);
+        direct_all = 1;
+    } else if (t <= 21) {
+        /* one or two partitions: geometry and which lists each uses */
+        int nparts, geo[2][4], pred[2];
+        if (t <= 3) { nparts = 1; geo[0][0] = 0; geo[0][1] = 0; geo[0][2] = 4; geo[0][3] = 4; pred[0] = t == 1 ? PRED_L0 : t == 2 ? PRED_L1 : PRED_BI; pred[1] = 0; }
+        else {
+            nparts = 2;
+            const int tall = (int)t & 1;                      /* odd types: 8x16 */
+            for (int k = 0; k < 2; k++) { geo[k][0] = tall ? 2 * k : 0; geo[k][1] = tall ? 0 : 2 * k; geo[k][2] = tall ? 2 : 4; geo[k][3] = tall ? 4 : 2; pred[k] = b_pair[(t - 4) >> 1][k]; }
+        }
+        int r[2][2] = { { -1, -1 }, { -1, -1 } };
+        for (int l = 0; l < 2; l++)                           /* all ref_idx_l0, then all ref_idx_l1 */
+            for (int k = 0; k < nparts; k++) {
+                if (!(pred[k] & (1 << l))) continue;
+                r[l][k] = 0;
+                if (nref[l] > 1) { r[l][k] = (int)br_te(b, nref[l] - 1); if (r[l][k] >= nref[l]) { ERR(p, "ref_idx out of range"); return -1; } }
+            }
+        for (int l = 0; l < 2; l++)
+            for (int k = 0; k < nparts; k++)
+                for (int y = geo[k][1] >> 1; y < (geo[k][1] + geo[k][3]) >> 1; y++)
+                    for (int x = geo[k][0] >> 1; x < (geo[k][0] + geo[k][2]) >> 1; x++) ref[l][y * 2 + x] = (int8_t)r[l][k];
+        for (int l = 0; l < 2; l++)                           /* all mvd_l0, then all mvd_l1; a partition that does not use the list still
+                                                               * becomes "decoded" for it (index -1, zero vector) when its turn comes */
+            for (int k = 0; k < nparts; k++) {
+                if (!(pred[k] & (1 << l))) { set_motion_l(p, geo[k][0], geo[k][1], geo[k][2], geo[k][3], 0, 0, l); continue; }
+                int dx = br_se(b), dy = br_se(b), px, py;
+                const int dir = nparts == 1 ? 0 : geo[0][2] == 4 ? 1 + k : 3 + k;
+                predict_mv_l(p, geo[k][0], geo[k][1], geo[k][2], r[l][k], dir, &px, &py, l);
+                set_motion_l(p, geo[k][0], geo[k][1], geo[k][2], geo[k][3], px + dx, py + dy, l);
+            }
+    } else {                                                  /* 22: B_8x8 */
+        int sub[4], any_direct = 0;
+        for (int k = 0; k < 4; k++) { sub[k] = (int)br_ue(b); if (sub[k] > 12) { ERR(p, "invalid B sub_mb_type %d", sub[k]); return -1; } any_direct |= sub[k] == 0; }
+        direct_t d;
+        if (any_direct) direct_predict(p, &d);                /* from the macroblock's neighbours, before any of its own motion exists */
+        int r[2][4];
+        for (int l = 0; l < 2; l++)
+            for (int k = 0; k < 4; k++) {
+                r[l][k] = -1;
+                if (!(b_sub_pred[sub[k]] & (1 << l))) continue;
+                r[l][k] = 0;
+                if (nref[l] > 1) { r[l][k] = (int)br_te(b, nref[l] - 1); if (r[l][k] >= nref[l]) { ERR(p, "ref_idx out of range"); return -1; } }
+            }
+        for (int l = 0; l < 2; l++) for (int k = 0; k < 4; k++) if (sub[k]) ref[l][k] = (int8_t)r[l][k];
+        for (int l = 0; l < 2; l++)
+            for (int k = 0; k < 4; k++) {
+                const int ox = (k & 1) * 2, oy = (k >> 1) * 2;
+                if (sub[k] == 0) { store_direct_quadrant(p, &d, k, l); continue; }             /* its turn: the derived motion becomes visible */
+                if (!(b_sub_pred[sub[k]] & (1 << l))) { set_motion_l(p, ox, oy, 2, 2, 0, 0, l); continue; }
+                const int sw = b_sub_w[sub[k]], shh = b_sub_h[sub[k]];
+                for (int sy = 0; sy < 2; sy += shh)
+                    for (int sx = 0; sx < 2; sx += sw) {
+                        int dx = br_se(b), dy = br_se(b), px, py;
+                        predict_mv_l(p, ox + sx, oy + sy, sw, r[l][k], 0, &px, &py, l);
+                        set_motion_l(p, ox + sx, oy + sy, sw, shh, px + dx, py + dy, l);
+                    }
+            }
+    }
+    (void)direct_all;
+    /* ---- coded_block_pattern, mb_qp_delta, residual: as in P macroblocks ---- */
+    unsigned c = br_ue(b);
+    if (c >= 48) { ERR(p, "invalid cbp"); return -1; }
+    m->cbp = cbp_inter_of_code[c];
+    int qp = p->sh.qp, has_res = m->cbp != 0;
+    if (has_res) {
+        int dqp = br_se(b);
+        if (p->opts & P264PARSE_OPT_STRICT) qp = (p->qp_pred + dqp + 52) % 52;
+        else qp = p->sh.qp + dqp;
+        if (parse_residual(p, b, m, &cf) < 0) { ERR(p, "read residual data failed"); return -1; }
+    } else memset(p->nnz + (size_t)p->mbi * 24, 0, 24);
+    if (store_coefs(p, m, &cf) < 0) return -1;
+    finish_mb_qp(p, m, has_res, qp);
+    if (br_overrun(b)) { ERR(p, "macroblock overruns the slice data"); return -1; }
+    return 0;
+}
+
+static int parse_mb(p264parse *p, bitrd_t *b)
+{
+    const unsigned t = br_ue(b);
+    int intra_t = -1;
+    if (p->sh.type == P264_SLICE_I) intra_t = (int)t;
+    else if (t >= 5) intra_t = (int)t - 5;
+    return parse_mb_t(p, b, t, intra_t);
+}
+
 /* position of the rbsp_stop_one_bit, in bits from the start of the payload */
 static long rbsp_stop_bit(const uint8_t *buf, int size)
 {
@@ -774,6 +1135,13 @@ static void publish_picture(p264parse *p)
     d->n_coef_blocks = (uint32_t)q->coef_n;
     d->frame_num = (uint32_t)p->sh0.frame_num;
     d->mb = q->mb; d->mv = q->mv; d->ref_idx = q->ref; d->i4modes = q->i4; d->coefs = q->coef;
+    if (p->sh0.type == P264_SLICE_B) {
+        d->mv_l1 = q->mv1; d->ref_idx_l1 = q->ref1;
+        d->n_ref_l1 = p->n_list1;
+        for (int i = 0; i < p->n_list1; i++) d->ref_slot_l1[i] = p->list1[i];
+        d->weighted_bipred = p->weighted_bipred;
+        memcpy(d->bipred_weight, p->bipred_weight, sizeof d->bipred_weight);
+    }
 }
 
 /* decoder/decoder.c:502-593,598-664 */
@@ -811,7 +1179,10 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
         p->pic_deblock = 0; p->pic_alpha = p->pic_beta = 0;
         p->buf[p->cur].coef_n = 0;
         memset(p->slice_of, 0xff, (size_t)p->n_mb * sizeof(uint16_t));
-        p->n_list0 = 0;
+        p->n_list0 = 0; p->n_list1 = 0;
+        p->cur_poc = picture_order_count(p, &sh, p->pic_is_idr, nal_ref_idc);
+        p->cur_uid = ++p->next_uid;
+        if (p->buf[p->cur].ref1) memset(p->buf[p->cur].ref1, -1, (size_t)p->n_mb * 4);   /* nothing predicts from list 1 until a B macroblock says so */
     } else {
         if (sh.first_mb != p->next_mb) { ERR(p, "slice starts at MB %d, expected %d", sh.first_mb, p->next_mb); return -1; }
         p->slice_no++;
@@ -821,13 +1192,24 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
         else if (sh.alpha_off != p->pic_alpha || sh.beta_off != p->pic_beta) { ERR(p, "per-slice deblocking offsets unsupported"); return -1; }
     }
     p->sh = sh;
-    if (sh.type == P264_SLICE_P) {
-        int prev[P264HIP_MAX_REFS], n_prev = p->n_list0;
-        memcpy(prev, p->list0, sizeof prev);
-        if (build_list0(p, &sh) < 0) return -1;
-        /* reference indices are resolved through ONE list per picture on the device */
+    if (sh.type == P264_SLICE_P || sh.type == P264_SLICE_B) {
+        int prev[P264HIP_MAX_REFS], n_prev = p->n_list0, prev1[P264HIP_MAX_REFS], n_prev1 = p->n_list1;
+        memcpy(prev, p->list0, sizeof prev); memcpy(prev1, p->list1, sizeof prev1);
+        if ((p->n_list0 = build_list(p, &sh, 0, p->list0)) < 0) { p->n_list0 = 0; return -1; }
+        /* reference indices are resolved through ONE list 0 (and one list 1) per picture on the device */
         if (n_prev && (n_prev != p->n_list0 || memcmp(prev, p->list0, sizeof(int) * (size_t)n_prev))) { ERR(p, "slices of one picture with different reference lists unsupported"); return -1; }
-        p->sh0.type = P264_SLICE_P;               /* a picture with any P slice is reconstructed as P */
+        if (sh.type == P264_SLICE_B) {
+            if (!p->has_col) { ERR(p, "B slice without list-1 storage (Baseline parameter set)"); return -1; }
+            if ((p->n_list1 = build_list(p, &sh, 1, p->list1)) < 0) { p->n_list1 = 0; return -1; }
+            if (n_prev1 && (n_prev1 != p->n_list1 || memcmp(prev1, p->list1, sizeof(int) * (size_t)n_prev1))) { ERR(p, "slices of one picture with different reference lists unsupported"); return -1; }
+            if (p->sh0.type != P264_SLICE_B && p->slice_no > 0 && p->sh0.type == P264_SLICE_P) { ERR(p, "P and B slices in one picture unsupported"); return -1; }
+            p->sh0.type = P264_SLICE_B;           /* a picture with any B slice is reconstructed as B */
+            p->weighted_bipred = pps->weighted_bipred == 2;
+            implicit_weights(p);
+        } else {
+            if (p->sh0.type == P264_SLICE_B) { ERR(p, "P and B slices in one picture unsupported"); return -1; }
+            p->sh0.type = P264_SLICE_P;           /* a picture with any P slice is reconstructed as P */
+        }
     }
     p->qp_pred = sh.qp;
 
@@ -836,16 +1218,16 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
     while (p->next_mb < p->n_mb) {
         p->mbi = p->next_mb; p->mbx = p->mbi % p->mb_w; p->mby = p->mbi / p->mb_w;
         if (p->skip_run <= 0 && (long)b.consumed >= stop) break;   /* !more_rbsp_data(): the slice ends here */
-        if (sh.type == P264_SLICE_P && p->skip_run < 0) {
+        if (sh.type != P264_SLICE_I && p->skip_run < 0) {
             p->skip_run = (int)br_ue(&b);
             if (p->skip_run > p->n_mb - p->next_mb) { ERR(p, "mb_skip_run %d runs past the picture", p->skip_run); p->pic_open = 0; return -1; }
         }
         if (p->skip_run > 0) {
-            decode_pskip(p);
+            if (sh.type == P264_SLICE_B) decode_bskip(p); else decode_pskip(p);
             p->skip_run--;
         } else {
             if ((long)b.consumed >= stop) break;
-            if (parse_mb(p, &b) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
+            if ((sh.type == P264_SLICE_B ? parse_mb_b(p, &b) : parse_mb(p, &b)) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
             p->skip_run = -1;
         }
         p->slice_of[p->mbi] = (uint16_t)p->slice_no;

@@ -28,6 +28,11 @@
  *                            short-term pictures dropped early, turned into long-term ones, long-term ones dropped, the current
  *                            picture stored as long-term) and long-term IDR pictures; --dump-mv then also records list 0 of every
  *                            picture as the writer means it: one byte n, then n 16-bit picture numbers (decode order)
+ *            [--bframes N]   Main profile with N non-reference B pictures between consecutive reference pictures (needs --refs >= 2):
+ *                            every B macroblock / sub-macroblock type, B_Skip and direct prediction - spatial, or temporal with
+ *                            [--temporal]; [--d8inf] direct_8x8_inference; [--implicit] weighted_bipred_idc 2.  The reference
+ *                            decodes none of this (decoder/macroblock.c:168-171): see synth264_b.h.  --dump-mv then records per
+ *                            picture both lists' vectors and indices, both lists as picture numbers and the implicit weights
  *            [--pps-alt]     two identical PPS (ids 0 and 1), pictures alternate between them: every picture re-activates a
  *                            parameter set (context re-initialisation in the decoder, decoder/decoder.c:304-343)
  */
@@ -103,35 +108,43 @@ static int cur;                             /* current MB index */
 static int opt_pps_alt = 0, cur_pps = 0;
 static int opt_mmco = 0, opt_mmco5 = 0, had_mmco5 = 0;   /* --mmco5: also memory_management_control_operation 5; had_mmco5: the picture just written carried one */
 /* the writer's own model of the decoded picture buffer (H.264 8.2.4, 8.2.5) */
-typedef struct { int used, pic, frame_num, is_long, long_idx; } wdpb_t;
+typedef struct { int used, pic, frame_num, is_long, long_idx;
+                 int poc; int16_t *cmv; int8_t *cref; int *cpic; } wdpb_t;   /* --bframes: picture order count; the picture's motion for direct prediction:
+                                                                              * per 4x4 block its vector, reference index and the picture that index named (-1 intra) */
 static wdpb_t wdpb[8];
 static int wlist[8], wlist_n;                /* list 0 of the current picture: picture numbers in decode order */
 static int opt_qpdelta = 0, opt_alpha = 0, opt_beta = 0, opt_sub8x8 = 0, opt_reorder = 0, slice_reordered;
 static int opt_idc = 0;                     /* --deblock-idc 2: no filtering across slice boundaries */
+/* --bframes N: N non-reference B pictures between consecutive reference pictures (Main profile, picture order count type 0) */
+static int opt_bframes = 0, opt_temporal = 0, opt_implicit = 0, opt_d8inf = 0;
+static int cur_poc, n_active1 = 1, blist[2][8], blist_n[2], cur_entry = -1;      /* B picture: its order count and its two lists as indices into wdpb */
 static int opt_slices = 1, slice_first;     /* --slices: equal runs of macroblocks; slice_first = first MB of the current slice */
 /* a neighbour is usable for prediction when it was coded earlier IN THE SAME SLICE (H.264 6.4.x) */
 static int avail(int mbx, int mby) { return mbx >= 0 && mby >= 0 && mbx < W && mby < H && mby * W + mbx < cur && mby * W + mbx >= slice_first; }
 
-typedef struct { int ref, x, y; } nb_t;     /* ref -2 unavailable, -1 intra, >= 0 reference index */
-static unsigned mv_done;
-static nb_t nb_motion(int x4, int y4)
+typedef struct { int ref, x, y; } nb_t;     /* ref -2 unavailable, -1 intra (or, B pictures: the list is not used there), >= 0 reference index */
+static unsigned mv_done, mv_done1;          /* 4x4 blocks of the current macroblock whose list-0 / list-1 motion is decided */
+static int16_t *mvs1; static int8_t *refs1; /* list 1 of the current picture (--bframes) */
+static nb_t nb_motion_l(int x4, int y4, int l)
 {
     nb_t r = { -2, 0, 0 };
     if (x4 < 0 || y4 < 0 || (x4 >> 2) >= W || (y4 >> 2) >= H) return r;
     int i = (y4 >> 2) * W + (x4 >> 2), sub = (y4 & 3) * 4 + (x4 & 3);
-    if (i == cur) { if (!((mv_done >> sub) & 1)) return r; }
+    if (i == cur) { if (!(((l ? mv_done1 : mv_done) >> sub) & 1)) return r; }
     else if (i > cur || i < slice_first) return r;
     if (i != cur && mb_type[i] <= T_I16) { r.ref = -1; return r; }
-    r.ref = refs[i * 16 + sub]; r.x = mvs[(i * 16 + sub) * 2]; r.y = mvs[(i * 16 + sub) * 2 + 1];
+    const int8_t *rf = l ? refs1 : refs; const int16_t *mv = l ? mvs1 : mvs;
+    r.ref = rf[i * 16 + sub]; r.x = mv[(i * 16 + sub) * 2]; r.y = mv[(i * 16 + sub) * 2 + 1];
     return r;
 }
+static nb_t nb_motion(int x4, int y4) { return nb_motion_l(x4, y4, 0); }
 static int med3(int a, int b, int c) { int lo = a < b ? a : b, hi = a < b ? b : a; return c < lo ? lo : c > hi ? hi : c; }
 /* H.264 8.4.1.3: dir 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right; ref = reference index of the partition */
-static void predict_mv(int mbx, int mby, int bx, int by, int bw, int dir, int ref, int *px, int *py)
+static void predict_mv_l(int mbx, int mby, int bx, int by, int bw, int dir, int ref, int *px, int *py, int l)
 {
     int x0 = mbx * 4 + bx, y0 = mby * 4 + by;
-    nb_t a = nb_motion(x0 - 1, y0), b = nb_motion(x0, y0 - 1), c = nb_motion(x0 + bw, y0 - 1);
-    if (c.ref == -2) c = nb_motion(x0 - 1, y0 - 1);
+    nb_t a = nb_motion_l(x0 - 1, y0, l), b = nb_motion_l(x0, y0 - 1, l), c = nb_motion_l(x0 + bw, y0 - 1, l);
+    if (c.ref == -2) c = nb_motion_l(x0 - 1, y0 - 1, l);
     if (dir == 1 && b.ref == ref) { *px = b.x; *py = b.y; return; }
     if (dir == 2 && a.ref == ref) { *px = a.x; *py = a.y; return; }
     if (dir == 3 && a.ref == ref) { *px = a.x; *py = a.y; return; }
@@ -145,15 +158,18 @@ static void predict_mv(int mbx, int mby, int bx, int by, int bw, int dir, int re
     if (c.ref < 0) c.x = c.y = 0;
     *px = med3(a.x, b.x, c.x); *py = med3(a.y, b.y, c.y);
 }
-static void set_mv(int bx, int by, int bw, int bh, int mx, int my, int ref)
+static void predict_mv(int mbx, int mby, int bx, int by, int bw, int dir, int ref, int *px, int *py) { predict_mv_l(mbx, mby, bx, by, bw, dir, ref, px, py, 0); }
+static void set_mv_l(int bx, int by, int bw, int bh, int mx, int my, int ref, int l)
 {
+    int8_t *rf = l ? refs1 : refs; int16_t *mv = l ? mvs1 : mvs;
     for (int y = by; y < by + bh; y++)
         for (int x = bx; x < bx + bw; x++) {
-            refs[cur * 16 + y * 4 + x] = (int8_t)ref;
-            mvs[(cur * 16 + y * 4 + x) * 2] = (int16_t)mx; mvs[(cur * 16 + y * 4 + x) * 2 + 1] = (int16_t)my;
-            mv_done |= 1u << (y * 4 + x);
+            rf[cur * 16 + y * 4 + x] = (int8_t)ref;
+            mv[(cur * 16 + y * 4 + x) * 2] = (int16_t)mx; mv[(cur * 16 + y * 4 + x) * 2 + 1] = (int16_t)my;
+            if (l) mv_done1 |= 1u << (y * 4 + x); else mv_done |= 1u << (y * 4 + x);
         }
 }
+static void set_mv(int bx, int by, int bw, int bh, int mx, int my, int ref) { set_mv_l(bx, by, bw, bh, mx, my, ref, 0); }
 /* keep every referenced sample within ~19 samples of the picture (A-Q9 allows 24) */
 static int mv_ok(int mbx, int mby, int bx, int by, int bw, int bh, int mx, int my)
 {
@@ -442,6 +458,8 @@ static int try_skip(int mbx, int mby)
     return 1;
 }
 
+#include "synth264_b.h"
+
 /* ---------------------------------------------------------------- pictures -------------- */
 /* list 0 of the picture about to be written, from the writer's frame-store model: short-term pictures by descending PicNum,
  * then long-term ones by ascending index (8.2.4.2.1) */
@@ -466,16 +484,20 @@ static int model_list0(int frame_num, int max_fn, int *list)
     return n;
 }
 
-static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int log2_fn, int refs_available, int pic_no)
+static void put_slice(FILE *f, int idr, int is_p, int is_b, int frame_num, int idr_id, int log2_fn, int refs_available, int pic_no)
 {
     const int max_fn = 1 << log2_fn;
     int full[8], n_full = 0;
-    if (opt_mmco) { n_full = is_p ? model_list0(frame_num, max_fn, full) : 0; refs_available = n_full; }
+    if (opt_mmco || opt_bframes) { n_full = is_p ? model_list0(frame_num, max_fn, full) : 0; refs_available = n_full; }
     n_active = is_p && opt_refs > 1 && refs_available > 1 ? (refs_available < opt_refs ? refs_available : opt_refs) : 1;
     if (!opt_mmco && n_active > 2) n_active = 2;
     slice_reordered = opt_reorder && n_active > 1 && pct(50);
     wlist_n = 0;
-    if (opt_mmco && is_p) { wlist_n = n_active; for (int i = 0; i < n_active; i++) wlist[i] = full[i < n_full ? i : n_full - 1]; }
+    if ((opt_mmco || opt_bframes) && is_p) { wlist_n = n_active; for (int i = 0; i < n_active; i++) wlist[i] = full[i < n_full ? i : n_full - 1]; }
+    if (is_b) {                                     /* the two lists of a B picture, all of them active (at most four entries each) */
+        b_build_lists();
+        n_active = blist_n[0] > 4 ? 4 : blist_n[0]; n_active1 = blist_n[1] > 4 ? 4 : blist_n[1];
+    }
     /* ---- reference picture marking of this picture (decided once, written into every slice header) ---- */
     int n_cmd = 0, cmd[8][3], idr_long = 0, cur_long = 0, cur_long_idx = 0;
     if (opt_mmco) {
@@ -525,16 +547,29 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         }
         for (int i = 0; i < 8; i++) if (!wdpb[i].used) { wdpb[i].used = 1; wdpb[i].pic = pic_no; wdpb[i].frame_num = had_mmco5 ? 0 : frame_num; wdpb[i].is_long = cur_long; wdpb[i].long_idx = cur_long_idx; break; }
     }
+    if (opt_bframes && !opt_mmco && !is_b) {        /* reference picture under the sliding window; its motion is saved when it is finished */
+        if (idr) for (int i = 0; i < 8; i++) wdpb[i].used = 0;
+        int cnt = 0, old = -1, old_num = 0;
+        for (int i = 0; i < 8; i++) if (wdpb[i].used) { cnt++; const int num = wdpb[i].frame_num > frame_num ? wdpb[i].frame_num - max_fn : wdpb[i].frame_num; if (old < 0 || num < old_num) { old = i; old_num = num; } }
+        if (cnt >= opt_refs && old >= 0) wdpb[old].used = 0;
+        for (int i = 0; i < 8; i++) if (!wdpb[i].used) { wdpb[i].used = 1; wdpb[i].pic = pic_no; wdpb[i].frame_num = frame_num; wdpb[i].is_long = 0; wdpb[i].poc = cur_poc; cur_entry = i; break; }
+    }
     for (int sl = 0; sl < opt_slices; sl++) {
         const int first = (int)((long)NMB * sl / opt_slices), end = (int)((long)NMB * (sl + 1) / opt_slices);
         if (first == end) continue;
         slice_first = first;
         bw_t b = { 0 };
         bw_ue(&b, (uint32_t)first);                 /* first_mb_in_slice */
-        bw_ue(&b, is_p ? 5 : 7);                    /* slice_type: all slices of the picture alike */
+        bw_ue(&b, is_b ? 6 : is_p ? 5 : 7);         /* slice_type: all slices of the picture alike */
         bw_ue(&b, (uint32_t)cur_pps);               /* pps id */
         bw_put(&b, log2_fn, (uint32_t)frame_num);
         if (idr) bw_ue(&b, (uint32_t)idr_id);
+        if (opt_bframes) bw_put(&b, 8, (uint32_t)(cur_poc & 255));    /* pic_order_cnt_lsb (type 0, 8 bits) */
+        if (is_b) {
+            bw_put(&b, 1, (uint32_t)!opt_temporal);                   /* direct_spatial_mv_pred_flag */
+            bw_put(&b, 1, 1); bw_ue(&b, (uint32_t)(n_active - 1)); bw_ue(&b, (uint32_t)(n_active1 - 1));   /* num_ref_idx_active_override */
+            bw_put(&b, 1, 0); bw_put(&b, 1, 0);                       /* no reordering of list 0, list 1 */
+        }
         if (is_p) {
             if (opt_refs > 1) { bw_put(&b, 1, 1); bw_ue(&b, (uint32_t)(n_active - 1)); }   /* num_ref_idx_active_override */
             else bw_put(&b, 1, 0);
@@ -543,7 +578,8 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
                 bw_put(&b, 1, 1); bw_ue(&b, 0); bw_ue(&b, 1); bw_ue(&b, 3);
             } else bw_put(&b, 1, 0);                        /* no reordering */
         }
-        if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, (uint32_t)idr_long); }    /* no_output_of_prior_pics, long_term_reference */
+        if (is_b) { }                               /* a non-reference picture: no dec_ref_pic_marking */
+        else if (idr) { bw_put(&b, 1, 0); bw_put(&b, 1, (uint32_t)idr_long); }    /* no_output_of_prior_pics, long_term_reference */
         else if (n_cmd) {
             bw_put(&b, 1, 1);                               /* adaptive_ref_pic_marking_mode */
             for (int k = 0; k < n_cmd; k++) {
@@ -559,7 +595,15 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         int skip_run = 0;
         for (cur = first; cur < end; cur++) {
             int mbx = cur % W, mby = cur / W;
-            mv_done = 0;
+            mv_done = 0; mv_done1 = 0;
+            if (opt_bframes) { memset(refs1 + cur * 16, -1, 16); memset(mvs1 + cur * 32, 0, 64); }
+            if (is_b) {
+                int k = rnd(100);
+                if (k < 18) { b_skip(mbx, mby); skip_run++; continue; }
+                bw_ue(&b, (uint32_t)skip_run); skip_run = 0;
+                if (k >= 95) put_intra(&b, mbx, mby, 23); else put_b_mb(&b, mbx, mby);
+                continue;
+            }
             if (!is_p) { put_intra(&b, mbx, mby, 0); continue; }
             int k = rnd(100);
             if (k < 20 && try_skip(mbx, mby)) { skip_run++; continue; }
@@ -568,12 +612,24 @@ static void put_slice(FILE *f, int idr, int is_p, int frame_num, int idr_id, int
         }
         if (skip_run) bw_ue(&b, (uint32_t)skip_run);
         bw_trailing(&b);
-        write_nal(f, 3, idr ? 5 : 1, &b);
+        write_nal(f, is_b ? 0 : 3, idr ? 5 : 1, &b);
         free(b.buf);
     }
     slice_first = 0;
+    if (opt_bframes && !is_b && cur_entry >= 0) b_save_col(&wdpb[cur_entry], !is_p);
     if (dump_mv) {
         fwrite(mvs, 2, (size_t)NMB * 32, dump_mv); fwrite(refs, 1, (size_t)NMB * 16, dump_mv);
+        if (opt_bframes) {
+            /* list 1, then both lists as the writer means them (one byte n, n 16-bit picture numbers each), then the
+             * implicit weight of the list-0 prediction for every pair of indices (16-bit each, n0 x n1) */
+            fwrite(mvs1, 2, (size_t)NMB * 32, dump_mv); fwrite(refs1, 1, (size_t)NMB * 16, dump_mv);
+            const int n0 = is_b ? n_active : is_p ? wlist_n : 0, n1 = is_b ? n_active1 : 0;
+            fputc(n0, dump_mv);
+            for (int i = 0; i < n0; i++) { const int pn = is_b ? wdpb[blist[0][i]].pic : wlist[i]; fputc(pn & 255, dump_mv); fputc(pn >> 8, dump_mv); }
+            fputc(n1, dump_mv);
+            for (int i = 0; i < n1; i++) { const int pn = wdpb[blist[1][i]].pic; fputc(pn & 255, dump_mv); fputc(pn >> 8, dump_mv); }
+            for (int i = 0; i < n0 && is_b; i++) for (int j = 0; j < n1; j++) { const int w = b_weight(i, j); fputc(w & 255, dump_mv); fputc((w >> 8) & 255, dump_mv); }
+        }
         if (opt_reorder) fputc(slice_reordered, dump_mv);
         if (opt_mmco) { fputc(wlist_n, dump_mv); for (int i = 0; i < wlist_n; i++) { fputc(wlist[i] & 255, dump_mv); fputc(wlist[i] >> 8, dump_mv); } }
     }
@@ -610,11 +666,15 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--sub8x8")) opt_sub8x8 = 1;
         else if (!strcmp(a, "--reorder")) opt_reorder = 1;
         else if (!strcmp(a, "--pps-alt")) opt_pps_alt = 1;
+        else if (!strcmp(a, "--bframes")) { opt_bframes = v; i++; }
+        else if (!strcmp(a, "--temporal")) opt_temporal = 1;
+        else if (!strcmp(a, "--implicit")) opt_implicit = 1;
+        else if (!strcmp(a, "--d8inf")) opt_d8inf = 1;
         else if (!strcmp(a, "--mmco")) opt_mmco = 1;
         else if (!strcmp(a, "--mmco5")) opt_mmco = opt_mmco5 = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
-    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > (opt_mmco ? 4 : 2) || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
+    if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > ((opt_mmco || opt_bframes) ? 4 : 2) || (opt_bframes && (opt_refs < 2 || opt_bframes > 4)) || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
     NMB = W * H;
     g_rng = seed * 0x9e3779b97f4a7c15ull + 264;
     mb_type = calloc((size_t)NMB, 1); mvs = calloc((size_t)NMB * 32, 2); nnz = calloc((size_t)NMB, 24); i4m = calloc((size_t)NMB, 16); refs = calloc((size_t)NMB, 16);
@@ -623,11 +683,14 @@ int main(int argc, char **argv)
     const int log2_fn = 8;
     {   /* SPS: Baseline, POC type 2, one reference frame */
         bw_t b = { 0 };
-        bw_put(&b, 8, 66); bw_put(&b, 8, 0xc0); bw_put(&b, 8, 40);
-        bw_ue(&b, 0); bw_ue(&b, log2_fn - 4); bw_ue(&b, 2);
+        if (opt_bframes) { bw_put(&b, 8, 77); bw_put(&b, 8, 0x40); bw_put(&b, 8, 40); }      /* Main profile */
+        else { bw_put(&b, 8, 66); bw_put(&b, 8, 0xc0); bw_put(&b, 8, 40); }
+        bw_ue(&b, 0); bw_ue(&b, log2_fn - 4);
+        if (opt_bframes) { bw_ue(&b, 0); bw_ue(&b, 8 - 4); }   /* pic_order_cnt_type 0, log2_max_pic_order_cnt_lsb 8 */
+        else bw_ue(&b, 2);
         bw_ue(&b, (uint32_t)opt_refs); bw_put(&b, 1, 0);    /* num_ref_frames */
         bw_ue(&b, (uint32_t)(W - 1)); bw_ue(&b, (uint32_t)(H - 1));
-        bw_put(&b, 1, 1); bw_put(&b, 1, 1);
+        bw_put(&b, 1, 1); bw_put(&b, 1, (uint32_t)(opt_bframes ? opt_d8inf : 1));    /* frame_mbs_only, direct_8x8_inference */
         if (crop_bottom) { bw_put(&b, 1, 1); bw_ue(&b, 0); bw_ue(&b, 0); bw_ue(&b, 0); bw_ue(&b, (uint32_t)crop_bottom); }
         else bw_put(&b, 1, 0);
         bw_put(&b, 1, 0);
@@ -637,19 +700,36 @@ int main(int argc, char **argv)
     for (int pps = 0; pps <= opt_pps_alt; pps++) {   /* PPS: CAVLC, deblocking control present */
         bw_t b = { 0 };
         bw_ue(&b, (uint32_t)pps); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 1, 0); bw_ue(&b, 0);
-        bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 2, 0);
+        bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 2, (uint32_t)(opt_implicit ? 2 : 0));   /* weighted_pred 0, weighted_bipred_idc */
         bw_se(&b, opt_qp - 26); bw_se(&b, 0); bw_se(&b, opt_cqo);
         bw_put(&b, 1, 1); bw_put(&b, 1, 0); bw_put(&b, 1, 0);
         bw_trailing(&b);
         write_nal(f, 3, 8, &b); free(b.buf);
     }
     int frame_num = 0, idr_id = 0, since_idr = 0;
+    if (opt_bframes) {
+        /* decode order: the IDR picture, then groups of one P picture followed by the N B pictures that are displayed in front
+         * of it; picture order count = 2 x display position; B pictures are not references, so they carry the frame_num the
+         * next reference picture will carry too (7.4.3) */
+        mvs1 = calloc((size_t)NMB * 32, 2); refs1 = malloc((size_t)NMB * 16); memset(refs1, -1, (size_t)NMB * 16);
+        for (int n = 0; n < frames; n++) {
+            const int idr = n == 0, pos = idr ? 0 : (n - 1) % (opt_bframes + 1), group = idr ? 0 : (n - 1) / (opt_bframes + 1) + 1;
+            const int is_b = !idr && pos > 0;
+            cur_poc = 2 * (is_b ? (group - 1) * (opt_bframes + 1) + pos : group * (opt_bframes + 1));
+            cur_entry = -1;
+            put_slice(f, idr, !idr && !is_b, is_b, frame_num, idr_id, log2_fn, since_idr, n);
+            if (!is_b && (idr || pos == 0)) frame_num = (frame_num + 1) & ((1 << log2_fn) - 1);
+        }
+        fclose(f);
+        if (dump_mv) fclose(dump_mv);
+        return 0;
+    }
     for (int n = 0; n < frames; n++) {
         int idr = intra_only || n == 0 || (gop > 0 && n % gop == 0);
         if (idr) { frame_num = 0; since_idr = 0; }
         cur_pps = opt_pps_alt ? (n & 1) : 0;
         had_mmco5 = 0;
-        put_slice(f, idr, !idr, frame_num, idr_id, log2_fn, since_idr, n);   /* since_idr = reference pictures available (sliding window) */
+        put_slice(f, idr, !idr, 0, frame_num, idr_id, log2_fn, since_idr, n);   /* since_idr = reference pictures available (sliding window) */
         since_idr++;
         if (idr) idr_id = (idr_id + 1) & 0xffff;
         frame_num = had_mmco5 ? 1 : (frame_num + 1) & ((1 << log2_fn) - 1);

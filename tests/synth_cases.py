@@ -59,6 +59,21 @@ CASES = {
     "uhd_2160p_allp": ("--mbw 240 --mbh 135 --frames 3 --gop 0 --seed 61 --qp 29 --qp-delta 3 --coded 12 --maxlevel 10", 2),
     "mv_far": ("--mbw 10 --mbh 8 --frames 10 --gop 10 --seed 28 --mvmax 64 --coded 5 --maxlevel 6", None),
 }
+# Streams the reference cannot decode (B pictures): pinned to the CPU ORACLE's output instead (tests/golden/oracle_<name>.sha256,
+# made by tests/golden/make_oracle_golden.py) - parity with the reference is unpinned for them
+ORACLE_CASES = {
+    # what BASELINE config 4 is with the CAVLC entropy coder: 1920x1088 Main profile, I + P + B (two B pictures between
+    # reference pictures), spatial direct prediction, implicit weights, deblocking
+    "main_1080p_ipb": "--mbw 120 --mbh 68 --frames 13 --seed 91 --refs 2 --bframes 2 --implicit --d8inf --coded 12 --maxlevel 12 --crop-bottom 4",
+}
+
+
+def oracle_golden(name):
+    """(stream sha256, [per-picture sha256 of the oracle's output ...])"""
+    lines = open(os.path.join(GOLDEN, "oracle_%s.sha256" % name)).read().split()
+    return lines[0], lines[1:]
+
+
 BIG = ("cfg2_720p_intra", "cfg3_1080p_ip", "cfg3_1080p_ip_l32", "cfg3_1080p_allp", "cfg3_1080p_allp_300", "qpd_1080p", "uhd_2160p_allp")
 
 

@@ -22,6 +22,22 @@ for trial in range(60):
     except Exception as e:
         pass
 print("fuzz ok")
+# B streams (two lists, direct prediction from stored co-located motion, implicit weights), whole and damaged
+BARGS = ["--mbw 8 --mbh 6 --frames 16 --seed 82 --refs 3 --bframes 3 --sub8x8 --implicit --coded 10 --maxlevel 6",
+         "--mbw 7 --mbh 5 --frames 13 --seed 85 --refs 4 --bframes 3 --temporal --d8inf --implicit --slices 2 --coded 8 --maxlevel 6"]
+for a in BARGS:
+    bs = open(synth_cases.generate(a), "rb").read()
+    print("B stream", len(Parser(quiet=True, lib=lib).parse_stream(bs)))
+    for trial in range(60):
+        d = bytearray(bs)
+        for _ in range(random.randrange(1, 20)):
+            d[random.randrange(30, len(d))] = random.randrange(256)
+        d = bytes(d[:random.randrange(100, len(d))])
+        try:
+            Parser(quiet=True, lib=lib).parse_stream(d)
+        except Exception as e:
+            pass
+print("B fuzz ok")
 # the same kind of damage through the C start-code scanner and emulation-prevention strip (pipeline, parse only)
 for trial in range(40):
     d = bytearray(synth_cases.stream_bytes("cif_ip"))

@@ -22,3 +22,7 @@ int p264hip_timing_read(p264hip_ctx *c, double *a, int64_t *b) { (void)c;(void)a
 int p264hip_timing_reset(p264hip_ctx *c) { (void)c; return -1; }
 int p264hip_submit_async(p264hip_ctx *c, int s, const p264hip_picture_t *p) { (void)c;(void)s;(void)p; return -1; }
 int p264hip_read_frame_async(p264hip_ctx *c, int s, int sl, uint8_t *y, int ys, uint8_t *u, uint8_t *v, int cs) { (void)c;(void)s;(void)sl;(void)y;(void)ys;(void)u;(void)v;(void)cs; return -1; }
+/* the RCCL transport lives with the HIP code: not part of the host-only build */
+#include "p264fan.h"
+int p264fan_rccl_unique_id(uint8_t id[128]) { (void)id; return -1; }
+int p264fan_rccl_transport(p264fan_transport_t *t, int r, int w, const uint8_t id[128], int d) { (void)t;(void)r;(void)w;(void)id;(void)d; return -1; }

@@ -20,6 +20,7 @@
 #include "bits.h"
 #include "vlc.h"
 #include "cavlc_tables.h"
+#include "cabac.h"
 
 #define NAL_SLICE     1
 #define NAL_SLICE_DPA 2
@@ -48,7 +49,7 @@ typedef struct {
     int num_ref_idx, qp, disable_deblock, alpha_off, beta_off;
     int n_reorder; struct { int idc, arg; } reorder[34];
     int num_ref_idx_l1, n_reorder1; struct { int idc, arg; } reorder1[34];   /* B slices: list 1 */
-    int poc_lsb, delta_poc_bottom, direct_spatial;
+    int poc_lsb, delta_poc_bottom, direct_spatial, cabac_init_idc;
     int no_output_of_prior, long_term_flag, adaptive_marking;
     int n_mmco; struct { int op, a, b; } mmco[34];   /* memory_management_control_operation 1..6 and its operands */
 } slice_t;
@@ -105,6 +106,11 @@ struct p264parse {
     unsigned mv_done, mv_done1;               /* bit (y*4+x): that 4x4 of the current MB has its list-0 / list-1 motion */
     int      cur_avail;                       /* P264_AVAIL_* of the current MB (set by begin_mb) */
     int skip_run;
+    /* CABAC (parser_cabac.h): the engine, and what context selection needs from earlier macroblocks */
+    int cabac_on, last_dqp;
+    p264cabac_t cb;
+    uint16_t *cinfo;                          /* [n_mb] CI_* */
+    uint8_t *mvd_abs[2];                      /* [n_mb][16][2] |mvd| per list, 4x4 block and component, saturated at 255 */
 };
 
 #define ERR(p, ...) do { fprintf(stderr, "p264amd: " __VA_ARGS__); fputc('\n', stderr); } while (0)
@@ -216,6 +222,7 @@ static void free_context(p264parse *p, int final)
     }
     free(p->nnz); p->nnz = NULL;
     free(p->slice_of); p->slice_of = NULL;
+    free(p->cinfo); p->cinfo = NULL; free(p->mvd_abs[0]); free(p->mvd_abs[1]); p->mvd_abs[0] = p->mvd_abs[1] = NULL;
     for (int i = 0; i <= P264HIP_MAX_REFS; i++) { free(p->col_mv[i]); free(p->col_ref[i]); free(p->col_uid[i]); p->col_mv[i] = NULL; p->col_ref[i] = NULL; p->col_uid[i] = NULL; }
     p->has_col = 0;
 }
@@ -254,6 +261,8 @@ static int init_context(p264parse *p, int sps_id, int pps_id)
             memset(p->col_ref[i], -1, n * 4); memset(p->col_uid[i], 0xff, n * 4 * sizeof(int32_t));
         }
         p->has_col = 1;
+        p->cinfo = (uint16_t *)calloc(n, sizeof(uint16_t)); p->mvd_abs[0] = (uint8_t *)calloc(n, 32); p->mvd_abs[1] = (uint8_t *)calloc(n, 32);
+        if (!p->cinfo || !p->mvd_abs[0] || !p->mvd_abs[1]) return -1;
     }
     p->nnz = (uint8_t *)calloc(n, 24);
     p->slice_of = (uint16_t *)malloc(n * sizeof(uint16_t));
@@ -285,7 +294,7 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
     if (sh->type != P264_SLICE_P && sh->type != P264_SLICE_I && sh->type != P264_SLICE_B) { ERR(p, "only I, P and B slices supported (type %d)", sh->type); return -1; }
     if (sh->type == P264_SLICE_B && (sps->profile_idc == 66 || nal_type == NAL_SLICE_IDR)) { ERR(p, "B slice in a Baseline stream or an IDR picture"); return -1; }
     if (sh->type == P264_SLICE_B && sps->poc_type == 1) { ERR(p, "B slices with pic_order_cnt_type 1 unsupported"); return -1; }
-    if (pps->cabac) { ERR(p, "CABAC unsupported (decoder/macroblock.c:594-597)"); return -1; }
+    if (pps->cabac && sps->profile_idc == 66) { ERR(p, "CABAC in a Baseline stream"); return -1; }
     if (!sps->frame_mbs_only) { ERR(p, "field/MBAFF coding unsupported"); return -1; }
 
     sh->frame_num = (int)br_u(b, sps->log2_max_frame_num);
@@ -343,6 +352,7 @@ static int parse_slice_header(p264parse *p, bitrd_t *b, int nal_type, int nal_re
             }
         }
     }
+    if (pps->cabac && sh->type != P264_SLICE_I) { sh->cabac_init_idc = (int)br_ue(b); if (sh->cabac_init_idc > 2) { ERR(p, "cabac_init_idc %d out of range", sh->cabac_init_idc); return -1; } }
     sh->qp = pps->pic_init_qp + br_se(b);
     if (pps->deblock_ctrl) {
         sh->disable_deblock = (int)br_ue(b);
@@ -689,6 +699,8 @@ static int coef_reserve(picbuf_t *q, size_t more)
     return 0;
 }
 
+#include "parser_cabac.h"
+
 /* residual( ) - decoder/macroblock.c:410-486 */
 static int parse_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *cf)
 {
@@ -726,6 +738,11 @@ static int parse_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *c
     return 0;
 }
 
+static int rd_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *cf)
+{
+    return p->cabac_on ? parse_residual_cabac(p, m, cf) : parse_residual(p, b, m, cf);
+}
+
 static int store_coefs(p264parse *p, p264hip_mb_t *m, const mbcoef_t *cf)
 {
     picbuf_t *q = &p->buf[p->cur];
@@ -745,6 +762,7 @@ static void begin_mb(p264parse *p, p264hip_mb_t *m)
 {
     memset(m, 0, sizeof *m);
     p->mv_done = 0; p->mv_done1 = 0;
+    if (p->cabac_on) { p->cinfo[p->mbi] = 0; memset(p->mvd_abs[0] + p->mbi * 32, 0, 32); memset(p->mvd_abs[1] + p->mbi * 32, 0, 32); }
     int a = 0;
     if (mb_avail(p, p->mbx - 1, p->mby))     a |= P264_AVAIL_LEFT;
     if (mb_avail(p, p->mbx, p->mby - 1))     a |= P264_AVAIL_TOP;
@@ -792,6 +810,8 @@ static void decode_pskip(p264parse *p)
     set_motion(p, 0, 0, 4, 4, mvx, mvy);
     m->coef_index = (uint32_t)q->coef_n;
     finish_mb_qp(p, m, 0, p->sh.qp);
+    p->last_dqp = 0;
+    if (p->cabac_on) p->cinfo[p->mbi] |= CI_SKIP;
 }
 
 /* t: mb_type as read (P slices), intra_t >= 0: the macroblock is intra with that I-slice type (I slices; P / B slices after
@@ -814,18 +834,14 @@ static int parse_mb_t(p264parse *p, bitrd_t *b, unsigned t, int intra_t)
         if (q->mv1) { memset(q->ref1 + p->mbi * 4, -1, 4); memset(q->mv1 + p->mbi * 32, 0, 64); }
         if (intra_t == 0) {
             m->mb_type = P264_MB_I4x4;
-            for (int i = 0; i < 16; i++) {
-                int pred = predict_i4mode(p, i);
-                if (br_u1(b)) i4[i] = (uint8_t)pred;
-                else { int rem = (int)br_u(b, 3); i4[i] = (uint8_t)(rem >= pred ? rem + 1 : rem); }
-            }
+            for (int i = 0; i < 16; i++) i4[i] = (uint8_t)rd_intra4x4_mode(p, b, predict_i4mode(p, i));
         } else {
             m->mb_type = P264_MB_I16x16;
             m->intra_modes = (uint8_t)((intra_t - 1) & 3);
             m->cbp = (uint8_t)((((intra_t - 1) >> 2) % 3) << 4 | (intra_t > 12 ? 15 : 0));
             memset(i4, 2, 16);
         }
-        unsigned cm = br_ue(b);
+        unsigned cm = rd_chroma_pred_mode(p, b);
         if (cm > 3) { ERR(p, "invalid intra chroma pred mode %u", cm); return -1; }
         m->intra_modes |= (uint8_t)(cm << 4);
     } else {
@@ -837,12 +853,15 @@ static int parse_mb_t(p264parse *p, bitrd_t *b, unsigned t, int intra_t)
             static const int8_t geo[3][2][4] = {   /* x, y, w, h in 4x4 units */
                 { {0,0,4,4}, {0,0,0,0} }, { {0,0,4,2}, {0,2,4,2} }, { {0,0,2,4}, {2,0,2,4} } };
             int nparts = t == 0 ? 1 : 2, r[2] = { 0, 0 };
-            for (int k = 0; k < nparts; k++) if (nref > 1) { r[k] = (int)br_te(b, nref - 1); if (r[k] >= nref) { ERR(p, "ref_idx out of range"); return -1; } }
-            for (int k = 0; k < nparts; k++)
-                for (int y = geo[t][k][1] >> 1; y < (geo[t][k][1] + geo[t][k][3]) >> 1; y++)
-                    for (int x = geo[t][k][0] >> 1; x < (geo[t][k][0] + geo[t][k][2]) >> 1; x++) ref[y * 2 + x] = (int8_t)r[k];
             for (int k = 0; k < nparts; k++) {
-                int dx = br_se(b), dy = br_se(b), px, py;
+                r[k] = rd_ref_idx(p, b, 0, geo[t][k][0], geo[t][k][1], nref);
+                if (r[k] < 0 || r[k] >= nref) { ERR(p, "ref_idx out of range"); return -1; }
+                for (int y = geo[t][k][1] >> 1; y < (geo[t][k][1] + geo[t][k][3]) >> 1; y++)      /* (at once: the next partition's context looks at it) */
+                    for (int x = geo[t][k][0] >> 1; x < (geo[t][k][0] + geo[t][k][2]) >> 1; x++) ref[y * 2 + x] = (int8_t)r[k];
+            }
+            for (int k = 0; k < nparts; k++) {
+                int dx, dy, px, py;
+                if (rd_mvd(p, b, 0, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], &dx, &dy) < 0) { ERR(p, "mvd out of range"); return -1; }
                 int dir = t == 0 ? 0 : t == 1 ? 1 + k : 3 + k;
                 predict_mv(p, geo[t][k][0], geo[t][k][1], geo[t][k][2], r[k], dir, &px, &py);
                 set_motion(p, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], px + dx, py + dy);
@@ -850,10 +869,11 @@ static int parse_mb_t(p264parse *p, bitrd_t *b, unsigned t, int intra_t)
         } else {
             m->mb_type = P264_MB_P_8x8;
             int sub[4];
-            for (int k = 0; k < 4; k++) { sub[k] = (int)br_ue(b); if (sub[k] > 3) { ERR(p, "invalid i_sub_partition"); return -1; } }
+            for (int k = 0; k < 4; k++) { sub[k] = rd_sub_mb_type(p, b); if (sub[k] > 3) { ERR(p, "invalid i_sub_partition"); return -1; } }
+            memset(ref, 0, 4);
             for (int k = 0; k < 4; k++) {
                 int r = 0;
-                if (nref > 1 && t == 3) { r = (int)br_te(b, nref - 1); if (r >= nref) { ERR(p, "ref_idx out of range"); return -1; } }
+                if (nref > 1 && t == 3) { r = rd_ref_idx(p, b, 0, (k & 1) * 2, (k >> 1) * 2, nref); if (r < 0 || r >= nref) { ERR(p, "ref_idx out of range"); return -1; } }
                 ref[k] = (int8_t)r;
             }
             for (int k = 0; k < 4; k++) {
@@ -861,7 +881,8 @@ static int parse_mb_t(p264parse *p, bitrd_t *b, unsigned t, int intra_t)
                 int sw = (sub[k] == 0 || sub[k] == 1) ? 2 : 1, shh = (sub[k] == 0 || sub[k] == 2) ? 2 : 1;
                 for (int sy = 0; sy < 2; sy += shh)
                     for (int sx = 0; sx < 2; sx += sw) {
-                        int dx = br_se(b), dy = br_se(b), px, py;
+                        int dx, dy, px, py;
+                        if (rd_mvd(p, b, 0, ox + sx, oy + sy, sw, shh, &dx, &dy) < 0) { ERR(p, "mvd out of range"); return -1; }
                         predict_mv(p, ox + sx, oy + sy, sw, ref[k], 0, &px, &py);
                         set_motion(p, ox + sx, oy + sy, sw, shh, px + dx, py + dy);
                     }
@@ -871,17 +892,18 @@ static int parse_mb_t(p264parse *p, bitrd_t *b, unsigned t, int intra_t)
 
     /* ---- coded_block_pattern, mb_qp_delta, residual (decoder/macroblock.c:540-587) ---- */
     if (m->mb_type != P264_MB_I16x16) {
-        unsigned c = br_ue(b);
-        if (c >= 48) { ERR(p, "invalid cbp"); return -1; }
-        m->cbp = m->mb_type == P264_MB_I4x4 ? cbp_intra_of_code[c] : cbp_inter_of_code[c];
+        const int c = rd_cbp(p, b, m->mb_type == P264_MB_I4x4);
+        if (c < 0) { ERR(p, "invalid cbp"); return -1; }
+        m->cbp = (uint8_t)c;
     }
     int qp = p->sh.qp, has_res = (m->cbp != 0 || m->mb_type == P264_MB_I16x16);
     if (has_res) {
-        int dqp = br_se(b);
+        int dqp = rd_mb_qp_delta(p, b);
+        if (dqp < -52 || dqp > 52) { ERR(p, "mb_qp_delta out of range"); return -1; }
         if (p->opts & P264PARSE_OPT_STRICT) qp = (p->qp_pred + dqp + 52) % 52;
         else qp = p->sh.qp + dqp;                 /* delta is NOT accumulated: decoder/macroblock.c:568 */
-        if (parse_residual(p, b, m, &cf) < 0) { ERR(p, "read residual data failed"); return -1; }
-    } else memset(p->nnz + (size_t)p->mbi * 24, 0, 24);
+        if (rd_residual(p, b, m, &cf) < 0) { ERR(p, "read residual data failed"); return -1; }
+    } else { memset(p->nnz + (size_t)p->mbi * 24, 0, 24); p->last_dqp = 0; }
     if (store_coefs(p, m, &cf) < 0) return -1;
     finish_mb_qp(p, m, has_res, qp);
     if (br_overrun(b)) { ERR(p, "macroblock overruns the slice data"); return -1; }
@@ -991,6 +1013,8 @@ static void decode_bskip(p264parse *p)
     for (int l = 0; l < 2; l++) for (int k = 0; k < 4; k++) store_direct_quadrant(p, &d, k, l);
     m->coef_index = (uint32_t)q->coef_n;
     finish_mb_qp(p, m, 0, p->sh.qp);
+    p->last_dqp = 0;
+    if (p->cabac_on) p->cinfo[p->mbi] |= CI_SKIP | CI_DIRECT16 | CI_D8(0) | CI_D8(1) | CI_D8(2) | CI_D8(3);
 }
 
 /* which lists a partition predicts from: bit 0 list 0, bit 1 list 1 */
@@ -1001,11 +1025,10 @@ static const uint8_t b_pair[9][2] = {           /* mb_type 4..21, table 7-14: (t
 static const uint8_t b_sub_pred[13] = { 0, PRED_L0, PRED_L1, PRED_BI, PRED_L0, PRED_L0, PRED_L1, PRED_L1, PRED_BI, PRED_BI, PRED_L0, PRED_L1, PRED_BI };   /* table 7-18; 0 = direct */
 static const uint8_t b_sub_w[13] = { 2, 2, 2, 2, 2, 1, 2, 1, 2, 1, 1, 1, 1 }, b_sub_h[13] = { 2, 2, 2, 2, 1, 2, 1, 2, 1, 2, 1, 1, 1 };    /* sub-partition size in 4x4 units */
 
-static int parse_mb_b(p264parse *p, bitrd_t *b)
+static int parse_mb_b_t(p264parse *p, bitrd_t *b, unsigned t)
 {
     picbuf_t *q = &p->buf[p->cur];
     p264hip_mb_t *m = &q->mb[p->mbi];
-    unsigned t = br_ue(b);
     if (t >= 23) {                                            /* intra macroblock in a B slice: the I-slice syntax with the type offset */
         return parse_mb_t(p, b, t, (int)t - 23);
     }
@@ -1023,6 +1046,7 @@ static int parse_mb_b(p264parse *p, bitrd_t *b)
         direct_predict(p, &d);
         for (int l = 0; l < 2; l++) for (int k = 0; k < 4; k++) store_direct_quadrant(p, &d, k, l);
         direct_all = 1;
+        if (p->cabac_on) p->cinfo[p->mbi] |= CI_DIRECT16 | CI_D8(0) | CI_D8(1) | CI_D8(2) | CI_D8(3);
     } else if (t <= 21) {
         /* one or two partitions: geometry and which lists each uses */
         int nparts, geo[2][4], pred[2];
@@ -1036,25 +1060,29 @@ static int parse_mb_b(p264parse *p, bitrd_t *b)
         for (int l = 0; l < 2; l++)                           /* all ref_idx_l0, then all ref_idx_l1 */
             for (int k = 0; k < nparts; k++) {
                 if (!(pred[k] & (1 << l))) continue;
-                r[l][k] = 0;
-                if (nref[l] > 1) { r[l][k] = (int)br_te(b, nref[l] - 1); if (r[l][k] >= nref[l]) { ERR(p, "ref_idx out of range"); return -1; } }
-            }
-        for (int l = 0; l < 2; l++)
-            for (int k = 0; k < nparts; k++)
-                for (int y = geo[k][1] >> 1; y < (geo[k][1] + geo[k][3]) >> 1; y++)
+                r[l][k] = rd_ref_idx(p, b, l, geo[k][0], geo[k][1], nref[l]);
+                if (r[l][k] < 0 || r[l][k] >= nref[l]) { ERR(p, "ref_idx out of range"); return -1; }
+                for (int y = geo[k][1] >> 1; y < (geo[k][1] + geo[k][3]) >> 1; y++)          /* (at once: the next partition's context looks at it) */
                     for (int x = geo[k][0] >> 1; x < (geo[k][0] + geo[k][2]) >> 1; x++) ref[l][y * 2 + x] = (int8_t)r[l][k];
+            }
         for (int l = 0; l < 2; l++)                           /* all mvd_l0, then all mvd_l1; a partition that does not use the list still
                                                                * becomes "decoded" for it (index -1, zero vector) when its turn comes */
             for (int k = 0; k < nparts; k++) {
                 if (!(pred[k] & (1 << l))) { set_motion_l(p, geo[k][0], geo[k][1], geo[k][2], geo[k][3], 0, 0, l); continue; }
-                int dx = br_se(b), dy = br_se(b), px, py;
+                int dx, dy, px, py;
+                if (rd_mvd(p, b, l, geo[k][0], geo[k][1], geo[k][2], geo[k][3], &dx, &dy) < 0) { ERR(p, "mvd out of range"); return -1; }
                 const int dir = nparts == 1 ? 0 : geo[0][2] == 4 ? 1 + k : 3 + k;
                 predict_mv_l(p, geo[k][0], geo[k][1], geo[k][2], r[l][k], dir, &px, &py, l);
                 set_motion_l(p, geo[k][0], geo[k][1], geo[k][2], geo[k][3], px + dx, py + dy, l);
             }
     } else {                                                  /* 22: B_8x8 */
         int sub[4], any_direct = 0;
-        for (int k = 0; k < 4; k++) { sub[k] = (int)br_ue(b); if (sub[k] > 12) { ERR(p, "invalid B sub_mb_type %d", sub[k]); return -1; } any_direct |= sub[k] == 0; }
+        for (int k = 0; k < 4; k++) {
+            sub[k] = rd_sub_mb_type(p, b);
+            if (sub[k] > 12) { ERR(p, "invalid B sub_mb_type %d", sub[k]); return -1; }
+            any_direct |= sub[k] == 0;
+            if (p->cabac_on && sub[k] == 0) p->cinfo[p->mbi] |= CI_D8(k);
+        }
         direct_t d;
         if (any_direct) direct_predict(p, &d);                /* from the macroblock's neighbours, before any of its own motion exists */
         int r[2][4];
@@ -1062,10 +1090,10 @@ static int parse_mb_b(p264parse *p, bitrd_t *b)
             for (int k = 0; k < 4; k++) {
                 r[l][k] = -1;
                 if (!(b_sub_pred[sub[k]] & (1 << l))) continue;
-                r[l][k] = 0;
-                if (nref[l] > 1) { r[l][k] = (int)br_te(b, nref[l] - 1); if (r[l][k] >= nref[l]) { ERR(p, "ref_idx out of range"); return -1; } }
+                r[l][k] = rd_ref_idx(p, b, l, (k & 1) * 2, (k >> 1) * 2, nref[l]);
+                if (r[l][k] < 0 || r[l][k] >= nref[l]) { ERR(p, "ref_idx out of range"); return -1; }
+                ref[l][k] = (int8_t)r[l][k];
             }
-        for (int l = 0; l < 2; l++) for (int k = 0; k < 4; k++) if (sub[k]) ref[l][k] = (int8_t)r[l][k];
         for (int l = 0; l < 2; l++)
             for (int k = 0; k < 4; k++) {
                 const int ox = (k & 1) * 2, oy = (k >> 1) * 2;
@@ -1074,7 +1102,8 @@ static int parse_mb_b(p264parse *p, bitrd_t *b)
                 const int sw = b_sub_w[sub[k]], shh = b_sub_h[sub[k]];
                 for (int sy = 0; sy < 2; sy += shh)
                     for (int sx = 0; sx < 2; sx += sw) {
-                        int dx = br_se(b), dy = br_se(b), px, py;
+                        int dx, dy, px, py;
+                        if (rd_mvd(p, b, l, ox + sx, oy + sy, sw, shh, &dx, &dy) < 0) { ERR(p, "mvd out of range"); return -1; }
                         predict_mv_l(p, ox + sx, oy + sy, sw, r[l][k], 0, &px, &py, l);
                         set_motion_l(p, ox + sx, oy + sy, sw, shh, px + dx, py + dy, l);
                     }
@@ -1082,25 +1111,30 @@ static int parse_mb_b(p264parse *p, bitrd_t *b)
     }
     (void)direct_all;
     /* ---- coded_block_pattern, mb_qp_delta, residual: as in P macroblocks ---- */
-    unsigned c = br_ue(b);
-    if (c >= 48) { ERR(p, "invalid cbp"); return -1; }
-    m->cbp = cbp_inter_of_code[c];
+    const int c = rd_cbp(p, b, 0);
+    if (c < 0) { ERR(p, "invalid cbp"); return -1; }
+    m->cbp = (uint8_t)c;
     int qp = p->sh.qp, has_res = m->cbp != 0;
     if (has_res) {
-        int dqp = br_se(b);
+        int dqp = rd_mb_qp_delta(p, b);
+        if (dqp < -52 || dqp > 52) { ERR(p, "mb_qp_delta out of range"); return -1; }
         if (p->opts & P264PARSE_OPT_STRICT) qp = (p->qp_pred + dqp + 52) % 52;
         else qp = p->sh.qp + dqp;
-        if (parse_residual(p, b, m, &cf) < 0) { ERR(p, "read residual data failed"); return -1; }
-    } else memset(p->nnz + (size_t)p->mbi * 24, 0, 24);
+        if (rd_residual(p, b, m, &cf) < 0) { ERR(p, "read residual data failed"); return -1; }
+    } else { memset(p->nnz + (size_t)p->mbi * 24, 0, 24); p->last_dqp = 0; }
     if (store_coefs(p, m, &cf) < 0) return -1;
     finish_mb_qp(p, m, has_res, qp);
     if (br_overrun(b)) { ERR(p, "macroblock overruns the slice data"); return -1; }
     return 0;
 }
 
+/* one non-skipped macroblock of the current slice, whatever its slice type and entropy coder */
 static int parse_mb(p264parse *p, bitrd_t *b)
 {
-    const unsigned t = br_ue(b);
+    const int ti = p->cabac_on ? cb_mb_type(p) : (int)br_ue(b);
+    if (ti < 0) return -1;
+    const unsigned t = (unsigned)ti;
+    if (p->sh.type == P264_SLICE_B) return parse_mb_b_t(p, b, t);
     int intra_t = -1;
     if (p->sh.type == P264_SLICE_I) intra_t = (int)t;
     else if (t >= 5) intra_t = (int)t - 5;
@@ -1213,6 +1247,29 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
     }
     p->qp_pred = sh.qp;
 
+    p->cabac_on = pps->cabac;
+    p->last_dqp = 0;
+    if (p->cabac_on) {
+        /* slice_data( ) with CABAC (7.3.4): alignment bits, the engine started on the next byte, contexts from the slice QP;
+         * per macroblock mb_skip_flag (P / B), the macroblock, end_of_slice_flag */
+        if (!p->cinfo) { ERR(p, "CABAC slice without its context storage (Baseline parameter set)"); return -1; }
+        const size_t at = (size_t)((b.consumed + 7) >> 3);
+        if (at >= (size_t)size) { ERR(p, "CABAC slice without data"); return -1; }
+        p264cabac_init_contexts(&p->cb, sh.type == P264_SLICE_I, sh.cabac_init_idc, sh.qp);
+        p264cabac_start(&p->cb, payload + at, (size_t)size - at);
+        for (;;) {
+            if (p->next_mb >= p->n_mb) { ERR(p, "slice data runs past the picture"); p->pic_open = 0; return -1; }
+            p->mbi = p->next_mb; p->mbx = p->mbi % p->mb_w; p->mby = p->mbi / p->mb_w;
+            /* (the neighbour flags of the macroblock are needed before its first bin: begin_mb computes them again, identically) */
+            { p264hip_mb_t tmp; begin_mb(p, &tmp); }
+            if (sh.type != P264_SLICE_I && cb_mb_skip_flag(p)) { if (sh.type == P264_SLICE_B) decode_bskip(p); else decode_pskip(p); }
+            else if (parse_mb(p, &b) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
+            if (p->cb.bits_left < -64) { ERR(p, "CABAC data overrun"); p->pic_open = 0; return -1; }
+            p->slice_of[p->mbi] = (uint16_t)p->slice_no;
+            p->next_mb++;
+            if (p264cabac_terminate(&p->cb)) break;              /* end_of_slice_flag */
+        }
+    } else {
     long stop = rbsp_stop_bit(payload, size);
     p->skip_run = -1;
     while (p->next_mb < p->n_mb) {
@@ -1227,11 +1284,12 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
             p->skip_run--;
         } else {
             if ((long)b.consumed >= stop) break;
-            if ((sh.type == P264_SLICE_B ? parse_mb_b(p, &b) : parse_mb(p, &b)) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
+            if (parse_mb(p, &b) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
             p->skip_run = -1;
         }
         p->slice_of[p->mbi] = (uint16_t)p->slice_no;
         p->next_mb++;
+    }
     }
     if (p->next_mb < p->n_mb) return 0;                       /* wait for the next slice of this picture */
 

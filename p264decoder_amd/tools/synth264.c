@@ -33,6 +33,9 @@
  *                            [--temporal]; [--d8inf] direct_8x8_inference; [--implicit] weighted_bipred_idc 2.  The reference
  *                            decodes none of this (decoder/macroblock.c:168-171): see synth264_b.h.  --dump-mv then records per
  *                            picture both lists' vectors and indices, both lists as picture numbers and the implicit weights
+ *            [--cabac]       Main profile with entropy_coding_mode_flag 1: the same syntax through the CABAC binarisations and the
+ *                            arithmetic encoder (synth264_cabac.h) instead of the CAVLC codes; the random choices do not depend on
+ *                            the entropy coder, so `args` and `args --cabac` describe the same pictures
  *            [--pps-alt]     two identical PPS (ids 0 and 1), pictures alternate between them: every picture re-activates a
  *                            parameter set (context re-initialisation in the decoder, decoder/decoder.c:304-343)
  */
@@ -202,6 +205,10 @@ static int predict_nc(int mbx, int mby, int blk)
     return na >= 0 ? na : nb >= 0 ? nb : 0;
 }
 
+/* te(v): one inverted bit when the range is 0..1, ue(v) beyond */
+static void put_te(bw_t *b, int max, int v) { if (max == 1) bw_put(b, 1, (uint32_t)!v); else if (max > 1) bw_ue(b, (uint32_t)v); }
+#include "synth264_cabac.h"
+
 /* ---------------------------------------------------------------- CAVLC residual writer - */
 static int rand_level(void)
 {
@@ -306,18 +313,23 @@ static int rand_residual(resid_t *r, int is_i16, int *i16_ac)
 static void put_residual(bw_t *b, int mbx, int mby, const resid_t *r, int is_i16, int cbp)
 {
     uint8_t *nz = nnz + (size_t)cur * 24;
-    if (is_i16) put_block(b, r->dc_luma, 16, predict_nc(mbx, mby, 0));
+    if (is_i16) { if (opt_cabac) ce_block(b, 0, 0, r->dc_luma, 16); else put_block(b, r->dc_luma, 16, predict_nc(mbx, mby, 0)); }
     for (int i = 0; i < 16; i++) {
         nz[i] = 0;
         if (!(cbp & (1 << (i >> 2)))) continue;
-        put_block(b, r->blk[i], is_i16 ? 15 : 16, predict_nc(mbx, mby, i));
+        if (opt_cabac) ce_block(b, is_i16 ? 1 : 2, i, r->blk[i], is_i16 ? 15 : 16);
+        else put_block(b, r->blk[i], is_i16 ? 15 : 16, predict_nc(mbx, mby, i));
         int tc = 0; for (int k = 0; k < 16; k++) tc += r->blk[i][k] != 0;
         nz[i] = (uint8_t)tc;
     }
-    if (cbp >> 4) { put_block(b, r->dc_c[0], 4, -1); put_block(b, r->dc_c[1], 4, -1); }
+    if (cbp >> 4) {
+        if (opt_cabac) { ce_block(b, 3, 0, r->dc_c[0], 4); ce_block(b, 3, 1, r->dc_c[1], 4); }
+        else { put_block(b, r->dc_c[0], 4, -1); put_block(b, r->dc_c[1], 4, -1); }
+    }
     for (int i = 16; i < 24; i++) {
         nz[i] = 0;
         if (!((cbp >> 4) & 2)) continue;
+        if (opt_cabac) ce_block(b, 4, i, r->blk[i], 15); else
         put_block(b, r->blk[i], 15, predict_nc(mbx, mby, i));
         int tc = 0; for (int k = 0; k < 16; k++) tc += r->blk[i][k] != 0;
         nz[i] = (uint8_t)tc;
@@ -355,10 +367,11 @@ static void put_intra(bw_t *b, int mbx, int mby, int type_offset)
         int mode = legal[rnd(nl)];
         mb_type[cur] = T_I16;
         memset(i4m + cur * 16, 2, 16);
-        bw_ue(b, (uint32_t)(type_offset + 1 + mode + 4 * (cbp >> 4) + (i16_ac ? 12 : 0)));
+        sx_mb_type(b, type_offset + 1 + mode + 4 * (cbp >> 4) + (i16_ac ? 12 : 0));
+        w_cbp[cur] = (uint8_t)cbp;
     } else {
         mb_type[cur] = T_I4;
-        bw_ue(b, (uint32_t)type_offset);
+        sx_mb_type(b, type_offset);
         for (int i = 0; i < 16; i++) {
             int bx = blk_x[i], by = blk_y[i];
             int l = bx > 0 || L, t = by > 0 || T;
@@ -372,8 +385,7 @@ static void put_intra(bw_t *b, int mbx, int mby, int type_offset)
             if (l) legal[nl++] = 8;
             int mode = legal[rnd(nl)], pred = pred_i4mode(mbx, mby, i);
             i4m[cur * 16 + i] = (int8_t)mode;
-            if (mode == pred) bw_put(b, 1, 1);
-            else { bw_put(b, 1, 0); bw_put(b, 3, (uint32_t)(mode < pred ? mode : mode - 1)); }
+            sx_i4mode(b, mode, pred);
         }
     }
     {   /* intra_chroma_pred_mode */
@@ -382,19 +394,13 @@ static void put_intra(bw_t *b, int mbx, int mby, int type_offset)
         if (L) legal[nl++] = 1;
         if (T) legal[nl++] = 2;
         if (L && T && TL) legal[nl++] = 3;
-        bw_ue(b, (uint32_t)legal[rnd(nl)]);
+        sx_chroma_mode(b, legal[rnd(nl)]);
     }
-    if (!is16) {
-        int code = -1;
-        for (int k = 0; k < 48; k++) if (cbp_intra_of_code[k] == cbp) code = k;
-        bw_ue(b, (uint32_t)code);
-    }
-    if (cbp || is16) { bw_se(b, rand_qp_delta()); put_residual(b, mbx, mby, &r, is16, cbp); }
-    else memset(nnz + (size_t)cur * 24, 0, 24);
+    if (!is16) sx_cbp(b, cbp, 1);
+    if (cbp || is16) { sx_dqp(b, rand_qp_delta()); put_residual(b, mbx, mby, &r, is16, cbp); }
+    else { memset(nnz + (size_t)cur * 24, 0, 24); w_last_dqp = 0; }
 }
 
-/* te(v): one inverted bit when the range is 0..1, ue(v) beyond */
-static void put_te(bw_t *b, int max, int v) { if (max == 1) bw_put(b, 1, (uint32_t)!v); else if (max > 1) bw_ue(b, (uint32_t)v); }
 /* try to write a non-skipped inter MB; returns 0 if no legal vectors were found */
 static void put_inter(bw_t *b, int mbx, int mby)
 {
@@ -403,24 +409,30 @@ static void put_inter(bw_t *b, int mbx, int mby)
     static const int8_t geo[3][2][4] = { { {0,0,4,4}, {0,0,0,0} }, { {0,0,4,2}, {0,2,4,2} }, { {0,0,2,4}, {2,0,2,4} } };
     mb_type[cur] = t == 3 ? T_P8 : T_P;
     memset(i4m + cur * 16, 2, 16);
-    bw_ue(b, (uint32_t)t);
+    sx_mb_type(b, t);
     /* te(v) with two active references: one bit, inverted */
     int pref[4] = { 0, 0, 0, 0 };
     if (t < 3) {
         int np = t == 0 ? 1 : 2;
-        for (int k = 0; k < np; k++) if (n_active > 1) { pref[k] = pct(55) ? 0 : rnd(n_active); put_te(b, n_active - 1, pref[k]); }
+        for (int k = 0; k < np; k++) {
+            if (n_active > 1) pref[k] = pct(55) ? 0 : rnd(n_active);
+            sx_ref_idx(b, 0, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], n_active, pref[k]);
+        }
         for (int k = 0; k < np; k++) {
             int mx, my, px, py, dir = t == 0 ? 0 : t == 1 ? 1 + k : 3 + k;
             predict_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], dir, pref[k], &px, &py);
             if (pct(25) && mv_ok(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], px, py)) { mx = px; my = py; }
             else random_mv(mbx, mby, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], &mx, &my);
-            bw_se(b, mx - px); bw_se(b, my - py);
+            sx_mvd(b, 0, geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], mx - px, my - py);
             set_mv(geo[t][k][0], geo[t][k][1], geo[t][k][2], geo[t][k][3], mx, my, pref[k]);
         }
     } else {
         int sub[4];
-        for (int k = 0; k < 4; k++) { sub[k] = opt_sub8x8 ? rnd(4) : 0; bw_ue(b, (uint32_t)sub[k]); }   /* sub_mb_type: 8x8 only inside the reference's safe subset (A-Q4) */
-        for (int k = 0; k < 4; k++) if (n_active > 1) { pref[k] = pct(55) ? 0 : rnd(n_active); put_te(b, n_active - 1, pref[k]); }
+        for (int k = 0; k < 4; k++) { sub[k] = opt_sub8x8 ? rnd(4) : 0; sx_sub_mb_type(b, k, sub[k]); }   /* sub_mb_type: 8x8 only inside the reference's safe subset (A-Q4) */
+        for (int k = 0; k < 4; k++) {
+            if (n_active > 1) pref[k] = pct(55) ? 0 : rnd(n_active);
+            sx_ref_idx(b, 0, (k & 1) * 2, (k >> 1) * 2, 2, 2, n_active, pref[k]);
+        }
         for (int k = 0; k < 4; k++) {
             int ox = (k & 1) * 2, oy = (k >> 1) * 2;
             int sw = (sub[k] == 0 || sub[k] == 1) ? 2 : 1, sh = (sub[k] == 0 || sub[k] == 2) ? 2 : 1;   /* 8x8, 8x4, 4x8, 4x4 */
@@ -430,17 +442,16 @@ static void put_inter(bw_t *b, int mbx, int mby)
                     predict_mv(mbx, mby, ox + sx, oy + sy, sw, 0, pref[k], &px, &py);
                     if (sub[k] && pct(30) && mv_ok(mbx, mby, ox + sx, oy + sy, sw, sh, px, py)) { mx = px; my = py; }
                     else random_mv(mbx, mby, ox + sx, oy + sy, sw, sh, &mx, &my);
-                    bw_se(b, mx - px); bw_se(b, my - py);
+                    sx_mvd(b, 0, ox + sx, oy + sy, sw, sh, mx - px, my - py);
                     set_mv(ox + sx, oy + sy, sw, sh, mx, my, pref[k]);
                 }
         }
     }
     resid_t r; int dummy;
-    int cbp = rand_residual(&r, 0, &dummy), code = -1;
-    for (int k = 0; k < 48; k++) if (cbp_inter_of_code[k] == cbp) code = k;
-    bw_ue(b, (uint32_t)code);
-    if (cbp) { bw_se(b, rand_qp_delta()); put_residual(b, mbx, mby, &r, 0, cbp); }
-    else memset(nnz + (size_t)cur * 24, 0, 24);
+    int cbp = rand_residual(&r, 0, &dummy);
+    sx_cbp(b, cbp, 0);
+    if (cbp) { sx_dqp(b, rand_qp_delta()); put_residual(b, mbx, mby, &r, 0, cbp); }
+    else { memset(nnz + (size_t)cur * 24, 0, 24); w_last_dqp = 0; }
 }
 
 /* P_SKIP motion (8.4.1.1); returns 0 when the inferred vector would leave the safe zone */
@@ -589,29 +600,42 @@ static void put_slice(FILE *f, int idr, int is_p, int is_b, int frame_num, int i
             }
             bw_ue(&b, 0);
         } else bw_put(&b, 1, 0);                            /* sliding-window marking */
+        if (opt_cabac && (is_p || is_b)) bw_ue(&b, (uint32_t)(pic_no % 3));   /* cabac_init_idc */
         bw_se(&b, 0);                               /* slice_qp_delta */
         bw_ue(&b, (uint32_t)(opt_deblock ? opt_idc : 1)); /* disable_deblocking_filter_idc: 0 also across slice boundaries, 2 not */
         if (opt_deblock) { bw_se(&b, opt_alpha); bw_se(&b, opt_beta); }
         int skip_run = 0;
+        slice_kind = is_b ? 2 : is_p ? 1 : 0;
+        w_last_dqp = 0;
+        if (opt_cabac) {                            /* cabac_alignment_one_bit, then the arithmetic code words */
+            while (b.nacc) bw_put(&b, 1, 1);
+            ce_init(!is_p && !is_b, pic_no % 3, opt_qp);
+        }
         for (cur = first; cur < end; cur++) {
             int mbx = cur % W, mby = cur / W;
             mv_done = 0; mv_done1 = 0;
+            w_begin_mb();
             if (opt_bframes) { memset(refs1 + cur * 16, -1, 16); memset(mvs1 + cur * 32, 0, 64); }
-            if (is_b) {
-                int k = rnd(100);
-                if (k < 18) { b_skip(mbx, mby); skip_run++; continue; }
-                bw_ue(&b, (uint32_t)skip_run); skip_run = 0;
-                if (k >= 95) put_intra(&b, mbx, mby, 23); else put_b_mb(&b, mbx, mby);
-                continue;
+            int skipped = 0, k = 0;
+            if (is_b) { k = rnd(100); if (k < 18) { b_skip(mbx, mby); skipped = 1; } }
+            else if (is_p) { k = rnd(100); if (k < 20 && try_skip(mbx, mby)) skipped = 1; }
+            if (is_b || is_p) {
+                if (opt_cabac) sx_mb_skip(&b, skipped);
+                else if (skipped) skip_run++;
+                else { bw_ue(&b, (uint32_t)skip_run); skip_run = 0; }
             }
-            if (!is_p) { put_intra(&b, mbx, mby, 0); continue; }
-            int k = rnd(100);
-            if (k < 20 && try_skip(mbx, mby)) { skip_run++; continue; }
-            bw_ue(&b, (uint32_t)skip_run); skip_run = 0;
-            if (k >= 96) put_intra(&b, mbx, mby, 5); else put_inter(&b, mbx, mby);
+            if (!skipped) {
+                if (is_b) { if (k >= 95) put_intra(&b, mbx, mby, 23); else put_b_mb(&b, mbx, mby); }
+                else if (is_p) { if (k >= 96) put_intra(&b, mbx, mby, 5); else put_inter(&b, mbx, mby); }
+                else put_intra(&b, mbx, mby, 0);
+            }
+            if (opt_cabac) ce_terminate(&b, cur == end - 1);      /* end_of_slice_flag */
         }
-        if (skip_run) bw_ue(&b, (uint32_t)skip_run);
-        bw_trailing(&b);
+        if (opt_cabac) { while (b.nacc) bw_put(&b, 1, 0); }       /* (the stop bit came with the last terminate bin) */
+        else {
+            if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+            bw_trailing(&b);
+        }
         write_nal(f, is_b ? 0 : 3, idr ? 5 : 1, &b);
         free(b.buf);
     }
@@ -667,6 +691,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--reorder")) opt_reorder = 1;
         else if (!strcmp(a, "--pps-alt")) opt_pps_alt = 1;
         else if (!strcmp(a, "--bframes")) { opt_bframes = v; i++; }
+        else if (!strcmp(a, "--cabac")) opt_cabac = 1;
         else if (!strcmp(a, "--temporal")) opt_temporal = 1;
         else if (!strcmp(a, "--implicit")) opt_implicit = 1;
         else if (!strcmp(a, "--d8inf")) opt_d8inf = 1;
@@ -677,13 +702,14 @@ int main(int argc, char **argv)
     if (W < 1 || H < 1 || W > 512 || H > 512 || frames < 1 || opt_qp < 0 || opt_qp > 51 || opt_refs < 1 || opt_refs > ((opt_mmco || opt_bframes) ? 4 : 2) || (opt_bframes && (opt_refs < 2 || opt_bframes > 4)) || opt_alpha < -6 || opt_alpha > 6 || opt_beta < -6 || opt_beta > 6) { fprintf(stderr, "bad geometry\n"); return 2; }
     NMB = W * H;
     g_rng = seed * 0x9e3779b97f4a7c15ull + 264;
+    w_alloc();
     mb_type = calloc((size_t)NMB, 1); mvs = calloc((size_t)NMB * 32, 2); nnz = calloc((size_t)NMB, 24); i4m = calloc((size_t)NMB, 16); refs = calloc((size_t)NMB, 16);
     FILE *f = fopen(argv[1], "wb");
     if (!f) { perror(argv[1]); return 2; }
     const int log2_fn = 8;
     {   /* SPS: Baseline, POC type 2, one reference frame */
         bw_t b = { 0 };
-        if (opt_bframes) { bw_put(&b, 8, 77); bw_put(&b, 8, 0x40); bw_put(&b, 8, 40); }      /* Main profile */
+        if (opt_bframes || opt_cabac) { bw_put(&b, 8, 77); bw_put(&b, 8, 0x40); bw_put(&b, 8, 40); }      /* Main profile */
         else { bw_put(&b, 8, 66); bw_put(&b, 8, 0xc0); bw_put(&b, 8, 40); }
         bw_ue(&b, 0); bw_ue(&b, log2_fn - 4);
         if (opt_bframes) { bw_ue(&b, 0); bw_ue(&b, 8 - 4); }   /* pic_order_cnt_type 0, log2_max_pic_order_cnt_lsb 8 */
@@ -699,7 +725,7 @@ int main(int argc, char **argv)
     }
     for (int pps = 0; pps <= opt_pps_alt; pps++) {   /* PPS: CAVLC, deblocking control present */
         bw_t b = { 0 };
-        bw_ue(&b, (uint32_t)pps); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 1, 0); bw_ue(&b, 0);
+        bw_ue(&b, (uint32_t)pps); bw_ue(&b, 0); bw_put(&b, 1, (uint32_t)opt_cabac); bw_put(&b, 1, 0); bw_ue(&b, 0);   /* ids, entropy_coding_mode, pic_order_present, slice groups */
         bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 1, 0); bw_put(&b, 2, (uint32_t)(opt_implicit ? 2 : 0));   /* weighted_pred 0, weighted_bipred_idc */
         bw_se(&b, opt_qp - 26); bw_se(&b, 0); bw_se(&b, opt_cqo);
         bw_put(&b, 1, 1); bw_put(&b, 1, 0); bw_put(&b, 1, 0);

@@ -145,7 +145,7 @@ static void put_b_mb(bw_t *b, int mbx, int mby)
     const int pick = rnd(100);
     if (pick < 12) {                                                    /* B_Direct_16x16 */
         bdirect_t d;
-        bw_ue(b, 0);
+        sx_mb_type(b, 0);
         b_direct(mbx, mby, &d);
         b_apply_direct(&d, 0, 0, 4, 4, 0);
         b_apply_direct(&d, 0, 0, 4, 4, 1);
@@ -163,14 +163,14 @@ static void put_b_mb(bw_t *b, int mbx, int mby)
                 uses[k] = pairs[(t - 4) / 2][k];
             }
         }
-        bw_ue(b, (uint32_t)t);
+        sx_mb_type(b, t);
         int r[2][2];
         for (int l = 0; l < 2; l++)
             for (int k = 0; k < np; k++) {
                 r[l][k] = -1;
                 if (!(uses[k] & (1 << l))) continue;
                 r[l][k] = nact[l] > 1 ? (pct(55) ? 0 : rnd(nact[l])) : 0;
-                put_te(b, nact[l] - 1, r[l][k]);
+                sx_ref_idx(b, l, g[k][0], g[k][1], g[k][2], g[k][3], nact[l], r[l][k]);
             }
         for (int l = 0; l < 2; l++)
             for (int k = 0; k < np; k++) {
@@ -179,7 +179,7 @@ static void put_b_mb(bw_t *b, int mbx, int mby)
                 const int dir = np == 1 ? 0 : (t & 1) ? 3 + k : 1 + k;
                 predict_mv_l(mbx, mby, g[k][0], g[k][1], g[k][2], dir, r[l][k], &px, &py, l);
                 b_pick_mv(mbx, mby, g[k][0], g[k][1], g[k][2], g[k][3], px, py, &mx, &my);
-                bw_se(b, mx - px); bw_se(b, my - py);
+                sx_mvd(b, l, g[k][0], g[k][1], g[k][2], g[k][3], mx - px, my - py);
                 set_mv_l(g[k][0], g[k][1], g[k][2], g[k][3], mx, my, r[l][k], l);
             }
     } else {                                                            /* B_8x8 */
@@ -187,8 +187,8 @@ static void put_b_mb(bw_t *b, int mbx, int mby)
         static const int s_uses[13] = { 0, 1, 2, 3, 1, 1, 2, 2, 3, 3, 1, 2, 3 };
         static const int s_w[13] = { 2, 2, 2, 2, 2, 1, 2, 1, 2, 1, 1, 1, 1 }, s_h[13] = { 2, 2, 2, 2, 1, 2, 1, 2, 1, 2, 1, 1, 1 };
         int sub[4], any_direct = 0;
-        bw_ue(b, 22);
-        for (int k = 0; k < 4; k++) { sub[k] = pct(25) ? 0 : 1 + rnd(opt_sub8x8 ? 12 : 3); bw_ue(b, (uint32_t)sub[k]); any_direct |= !sub[k]; }
+        sx_mb_type(b, 22);
+        for (int k = 0; k < 4; k++) { sub[k] = pct(25) ? 0 : 1 + rnd(opt_sub8x8 ? 12 : 3); sx_sub_mb_type(b, k, sub[k]); any_direct |= !sub[k]; }
         bdirect_t d;
         if (any_direct) b_direct(mbx, mby, &d);
         int r[2][4];
@@ -197,7 +197,7 @@ static void put_b_mb(bw_t *b, int mbx, int mby)
                 r[l][k] = -1;
                 if (!(s_uses[sub[k]] & (1 << l))) continue;
                 r[l][k] = nact[l] > 1 ? (pct(55) ? 0 : rnd(nact[l])) : 0;
-                put_te(b, nact[l] - 1, r[l][k]);
+                sx_ref_idx(b, l, (k & 1) * 2, (k >> 1) * 2, 2, 2, nact[l], r[l][k]);
             }
         for (int l = 0; l < 2; l++)
             for (int k = 0; k < 4; k++) {
@@ -209,17 +209,16 @@ static void put_b_mb(bw_t *b, int mbx, int mby)
                         int px, py, mx, my;
                         predict_mv_l(mbx, mby, ox + sx, oy + sy, s_w[sub[k]], 0, r[l][k], &px, &py, l);
                         b_pick_mv(mbx, mby, ox + sx, oy + sy, s_w[sub[k]], s_h[sub[k]], px, py, &mx, &my);
-                        bw_se(b, mx - px); bw_se(b, my - py);
+                        sx_mvd(b, l, ox + sx, oy + sy, s_w[sub[k]], s_h[sub[k]], mx - px, my - py);
                         set_mv_l(ox + sx, oy + sy, s_w[sub[k]], s_h[sub[k]], mx, my, r[l][k], l);
                     }
             }
     }
     resid_t rs; int dummy;
-    int cbp = rand_residual(&rs, 0, &dummy), code = -1;
-    for (int k = 0; k < 48; k++) if (cbp_inter_of_code[k] == cbp) code = k;
-    bw_ue(b, (uint32_t)code);
-    if (cbp) { bw_se(b, rand_qp_delta()); put_residual(b, mbx, mby, &rs, 0, cbp); }
-    else memset(nnz + (size_t)cur * 24, 0, 24);
+    int cbp = rand_residual(&rs, 0, &dummy);
+    sx_cbp(b, cbp, 0);
+    if (cbp) { sx_dqp(b, rand_qp_delta()); put_residual(b, mbx, mby, &rs, 0, cbp); }
+    else { memset(nnz + (size_t)cur * 24, 0, 24); w_last_dqp = 0; }
 }
 
 /* the motion of a finished reference picture, kept with its frame-store entry (for the direct prediction of B pictures) */

@@ -65,6 +65,8 @@ ORACLE_CASES = {
     # what BASELINE config 4 is with the CAVLC entropy coder: 1920x1088 Main profile, I + P + B (two B pictures between
     # reference pictures), spatial direct prediction, implicit weights, deblocking
     "main_1080p_ipb": "--mbw 120 --mbh 68 --frames 13 --seed 91 --refs 2 --bframes 2 --implicit --d8inf --coded 12 --maxlevel 12 --crop-bottom 4",
+    # BASELINE config 4 itself: the same pictures with the CABAC entropy coder (1920x1080 Main profile, CABAC + B pictures + deblocking)
+    "main_1080p_cabac_ipb": "--mbw 120 --mbh 68 --frames 13 --seed 91 --refs 2 --bframes 2 --implicit --d8inf --coded 12 --maxlevel 12 --crop-bottom 4 --cabac",
 }
 
 

@@ -15,8 +15,9 @@ from tests.conftest import frame_sha256
 pytestmark = pytest.mark.gpu
 
 
-def test_main_1080p_ipb_matches_the_oracle_hashes(lib):
-    name = "main_1080p_ipb"
+@pytest.mark.parametrize("name", ["main_1080p_ipb", "main_1080p_cabac_ipb"])
+def test_main_1080p_ipb_matches_the_oracle_hashes(lib, name):
+    """CAVLC, and BASELINE config 4 itself: the same pictures behind the CABAC entropy coder"""
     digest, hashes = synth_cases.oracle_golden(name)
     data = open(synth_cases.generate(synth_cases.ORACLE_CASES[name]), "rb").read()
     assert hashlib.sha256(data).hexdigest() == digest

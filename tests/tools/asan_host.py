@@ -24,6 +24,8 @@ for trial in range(60):
 print("fuzz ok")
 # B streams (two lists, direct prediction from stored co-located motion, implicit weights), whole and damaged
 BARGS = ["--mbw 8 --mbh 6 --frames 16 --seed 82 --refs 3 --bframes 3 --sub8x8 --implicit --coded 10 --maxlevel 6",
+         "--mbw 8 --mbh 6 --frames 16 --seed 104 --refs 2 --bframes 2 --sub8x8 --implicit --coded 12 --maxlevel 8 --cabac",
+         "--mbw 9 --mbh 7 --frames 8 --gop 4 --seed 101 --coded 25 --maxlevel 40 --qp-delta 6 --cabac",
          "--mbw 7 --mbh 5 --frames 13 --seed 85 --refs 4 --bframes 3 --temporal --d8inf --implicit --slices 2 --coded 8 --maxlevel 6"]
 for a in BARGS:
     bs = open(synth_cases.generate(a), "rb").read()

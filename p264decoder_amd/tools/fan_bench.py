@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One rank of a fan-out run (include/p264fan.h) over RCCL or TCP: rank 0 owns `--streams` copies of the config-3 stream,
+"""One rank of a fan-out run (include/p264fan.h) over RCCL or TCP: rank 0 owns `--streams` copies of a 1080p stream (by default
+BASELINE config 5's kind: Main profile, CABAC, I+P+B),
 parses them, scatters the parsed pictures to the ranks owning the streams, gathers the I420 planes and checks every
 picture against the reference decoder's committed hash.  bench.py starts one of these per GPU (as child processes, so
 that a transport problem can never take the timed bench down); also usable by hand:
@@ -28,7 +29,9 @@ def main():
     ap.add_argument("--port", type=int, default=29555)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="default: one per rank")
-    ap.add_argument("--pictures", type=int, default=6)
+    ap.add_argument("--pictures", type=int, default=12)
+    ap.add_argument("--workload", default="main_1080p_cabac_ipb", help="main_1080p_cabac_ipb: BASELINE config 5's streams (1080p Main, CABAC, I+P+B; checked "
+                    "against the committed ORACLE hashes - the reference cannot decode them); cfg3_1080p_allp: Baseline all-P, checked against the reference's hashes")
     a = ap.parse_args()
     from p264decoder_amd import FanOut, _native
     from tests import synth_cases
@@ -48,8 +51,11 @@ def main():
         fan.close()
         return
     n = a.streams or a.world
-    data = synth_cases.stream_bytes("cfg3_1080p_allp")
-    hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    if a.workload in synth_cases.ORACLE_CASES:
+        data = open(synth_cases.generate(synth_cases.ORACLE_CASES[a.workload]), "rb").read()
+        hashes, pinned_by = synth_cases.oracle_golden(a.workload)[1], "oracle"
+    else:
+        data, hashes, pinned_by = synth_cases.stream_bytes(a.workload), synth_cases.golden(a.workload)[1], "reference"
     bad = []
 
     def on_frame(s, i, y, u, v):
@@ -70,7 +76,7 @@ def main():
            "parse_wait_seconds": round(st["parse_wait_seconds"], 3), "exchange_seconds": round(st["exchange_seconds"], 3),
            "root_reconstruct_seconds": round(st["reconstruct_seconds"], 3),
            "scattered_MB": round(st["bytes_scattered"] / 1e6, 2), "gathered_MB": round(st["bytes_gathered"] / 1e6, 2),
-           "all_pictures_match_reference": not bad,
+           "workload": a.workload, "all_pictures_match_%s" % pinned_by: not bad,
            "what": "rank 0 parses every stream (one host thread per stream, the next round while the current one is exchanged), "
                    "scatters parsed pictures, gathers I420; parse_wait_seconds is the part of the parse that was not hidden"}
     print("FANOUT " + json.dumps(out), flush=True)

@@ -70,6 +70,26 @@ def test_fanout_rounds_overlap_parse_and_exchange(lib):
     assert st["parse_seconds"] > 0 and st["parse_wait_seconds"] < 0.7 * st["parse_seconds"], st      # (the first round cannot be hidden: 1/8 at best)
 
 
+def test_fanout_main_profile_cabac_b_streams(lib, oracle):
+    """BASELINE config 5's kind of stream through the fan-out (Main profile, CABAC, I+P+B: list-1 arrays and weights travel in
+    the packed pictures): every gathered picture equals what the oracle gives for the stream decoded on its own."""
+    import subprocess, hashlib
+    from p264decoder_amd import Parser
+    from tests import oracle_bind
+    from tests.conftest import frame_sha256
+    args = "--mbw 8 --mbh 6 --frames 13 --seed 104 --refs 2 --bframes 2 --sub8x8 --implicit --coded 12 --maxlevel 8 --cabac"
+    data = open(synth_cases.generate(args), "rb").read()
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(data)
+    store = oracle_bind.FrameStore(pics[0].mb_w, pics[0].mb_h, parser.slots)
+    want = [frame_sha256(*oracle_bind.reconstruct(oracle, store, p)) for p in pics]
+    got, st = fan_helpers.run_job(3, [data] * 4, 0, True, 30900 + (os.getpid() % 300))
+    assert st["pictures"] == 4 * 13
+    for s in range(4):
+        for i in range(13):
+            assert got[(s, i)] == want[i], "stream %d picture %d" % (s, i)
+
+
 def test_fanout_symbols_and_errors(lib):
     from p264decoder_amd.fanout import FanOut
     for sym in ("p264fan_open", "p264fan_root_run", "p264fan_worker_run", "p264fan_close", "p264fan_tcp_transport",

@@ -38,11 +38,16 @@ for k, ctrs in agg.items():
     pmc[k]["launches_averaged"] = len(vals)
 note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
         "(1024 1080p pictures per launch), separate rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as reported")
+for k in ("k_mc", "k_mc_sort"):
+    if k in pmc:
+        pmc[k]["hbm_bytes_2xFETCH_plus_WRITE"] = int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
 json.dump({"note": note, **pmc}, open(os.path.join(here, tag + "_pmc.json"), "w"), indent=1)
 
 def hbm(k):
     return int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
-traffic = {"inter": sum(hbm(k) for k in pmc if k.startswith("k_mc_")), "intra": hbm("k_intra"), "deblock": hbm("k_deblock") + hbm("k_deblock_bs"),
+def hbm_any(prefix):
+    return sum(hbm(k) for k in pmc if k == prefix or k.startswith(prefix + "<") or k.startswith(prefix + "_"))
+traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra"), "deblock": hbm_any("k_deblock"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
 traffic["pictures_per_launch"] = 1024          # bench.py's default batch, which collect.sh profiles
 json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)

@@ -68,7 +68,7 @@ __host__ __device__ static inline int mc_list_keys(int l) { return l < ML_CM ? M
 #define MC_ENTRY_WORDS 4u
 struct McLayout {
     uint32_t band_log2, n_bands;
-    uint32_t max_chunks[ML_LISTS], off_cls[ML_LISTS], off_list[ML_LISTS], words;
+    uint32_t max_chunks[2 * ML_LISTS], off_cls[2 * ML_LISTS], off_list[2 * ML_LISTS], words;     // [pass * ML_LISTS + list]
 };
 static inline McLayout mc_layout(int mb_w, int mb_h, int band_log2)
 {
@@ -77,13 +77,14 @@ static inline McLayout mc_layout(int mb_w, int mb_h, int band_log2)
     L.n_bands = (uint32_t)((mb_h + (1 << band_log2) - 1) >> band_log2);
     const uint32_t n_mb = (uint32_t)(mb_w * mb_h);
     uint32_t at = 16;
-    for (int l = 0; l < ML_LISTS; l++) {
-        const uint32_t items = (l == ML_YM || l == ML_CM) ? n_mb : n_mb * 4u, per = (uint32_t)mc_chunk_items(l);
-        L.max_chunks[l] = (items + L.n_bands * (uint32_t)mc_list_keys(l) * (per - 1)) / per + 1;
+    for (int l = 0; l < 2 * ML_LISTS; l++) {
+        const int t = l % ML_LISTS;
+        const uint32_t items = (t == ML_YM || t == ML_CM) ? n_mb : n_mb * 4u, per = (uint32_t)mc_chunk_items(t);
+        L.max_chunks[l] = (items + L.n_bands * (uint32_t)mc_list_keys(t) * (per - 1)) / per + 1;
         L.off_cls[l] = at; at += (L.max_chunks[l] + 3) / 4;
     }
     at = (at + 15) & ~15u;
-    for (int l = 0; l < ML_LISTS; l++) { L.off_list[l] = at; at += L.max_chunks[l] * (uint32_t)mc_chunk_items(l) * MC_ENTRY_WORDS; }
+    for (int l = 0; l < 2 * ML_LISTS; l++) { L.off_list[l] = at; at += L.max_chunks[l] * (uint32_t)mc_chunk_items(l % ML_LISTS) * MC_ENTRY_WORDS; }
     L.words = (at + 63) & ~63u;
     return L;
 }
@@ -109,55 +110,115 @@ __device__ __forceinline__ void split_mb(int mbi, const Geom &g, uint32_t inv_mb
     mbx = mbi - mby * g.mb_w;
 }
 
-// What one inter macroblock contributes: either one macroblock item per plane kind (one vector, one reference) or its
-// four quadrants.  Packed so that a thread can keep the classification of several macroblocks in registers between
+// What one inter macroblock contributes to one pass: either one macroblock item per plane kind (one vector, one reference)
+// or its four quadrants.  Packed so that a thread can keep the classification of several macroblocks in registers between
 // the counting and the scattering pass: key[q] = luma key | chroma key << 16, vec[q] = the entry's vector,
-// info = inter | whole << 1 | reference indices (4 bits each) << 8.
+// info = inter | whole << 1 | reference indices (4 bits each) << 8 | list per quadrant << 24 | Z per quadrant << 28.
+//
+// B pictures take TWO passes (two list sets, two launches of the consumer): a block that predicts from both lists gets its
+// list-0 prediction in the first pass (entry with an empty coded-block mask: Z) and the list-1 prediction in the second,
+// which reads the first one back, combines the two (core/mc.c:76-155) and adds the residual.  Blocks with one list are
+// finished in the first pass, whichever list it is.  In the second pass Z on a quadrant means "not mine": no luma entry,
+// and a chroma entry that only carries the quadrant's samples through (the four chroma entries of a macroblock stay
+// together: their lanes store whole rows).  Macroblocks of a B picture whose vectors differ inside a quadrant go to the
+// generic two-list class, in the first pass, as a whole.
 struct McMb { uint32_t info, key[4], vec[4]; };
 #define MCMB_INTER 1u
 #define MCMB_WHOLE 2u
-__device__ __forceinline__ uint32_t mcmb_entry(const McMb &k, int mbx, int mby, int q) { return ((k.info >> (8 + 4 * q)) & 15u) << 28 | (uint32_t)mby << 13 | (uint32_t)mbx << 2 | (uint32_t)q; }
-__device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int mbi, uint32_t inv_mbw, int band_log2)
+#define MCE_LIST1  (1u << 23)       // entry flag: the reference index counts in list 1
+#define MCE_KEEP   (1u << 24)       // entry flag (second pass, chroma quadrant entries): pass the samples through
+#define MCE_W_SHIFT 23              // second pass: w = place in the coefficient stream | weight << 23
+__device__ __forceinline__ uint32_t mcmb_entry(const McMb &k, int mbx, int mby, int q, int pass)
+{
+    const uint32_t l1 = (k.info >> (24 + q)) & 1u, z = (k.info >> (28 + q)) & 1u;
+    return ((k.info >> (8 + 4 * q)) & 15u) << 28 | (l1 ? MCE_LIST1 : 0u) | ((pass && z) ? MCE_KEEP : 0u) | (uint32_t)mby << 13 | (uint32_t)mbx << 2 | (uint32_t)q;
+}
+__device__ __forceinline__ bool quad_uniform(const uint4 &m0, const uint4 &m1, const uint4 &m2, const uint4 &m3, int q, uint32_t &v)
+{
+    // vectors of the quadrant's four 4x4 blocks (raster inside the macroblock: b0, b0+1, b0+4, b0+5)
+    const uint4 top = q < 2 ? m0 : m2, bot = q < 2 ? m1 : m3;
+    const uint32_t va = (q & 1) ? top.z : top.x, vb = (q & 1) ? top.w : top.y, vc = (q & 1) ? bot.z : bot.x, vd = (q & 1) ? bot.w : bot.y;
+    v = va;
+    return va == vb && va == vc && va == vd;
+}
+template <bool BPIC>
+__device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int mbi, uint32_t inv_mbw, int band_log2, int pass)
 {
     McMb k;
     const uint4 rec = gload4(pd->mb + mbi);
     const int *mvp = pd->mv + mbi * 16;
-    const uint4 m0 = gload4(mvp), m1 = gload4(mvp + 4), m2 = gload4(mvp + 8), m3 = gload4(mvp + 12);
+    uint4 m0 = gload4(mvp), m1 = gload4(mvp + 4), m2 = gload4(mvp + 8), m3 = gload4(mvp + 12);
     const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
     k.info = P264_MB_IS_INTRA(rec.x & 255) ? 0u : MCMB_INTER;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { k.key[q] = 0; k.vec[q] = 0; }
     int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
     if (mbi - mby * g.mb_w >= g.mb_w) mby++;
     const int mbx = mbi - mby * g.mb_w, band = mby >> band_log2;
     const unsigned mask = rec.y, cc = mask & (0x00ff0000u | P264_COEF_CHROMA_DC);   // any chroma level present
     const int n_ref = pd->n_ref;
     int ri[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        ri[q] = (int)(int8_t)(refs >> (8 * q));
-        if (ri[q] < 0 || ri[q] >= n_ref) ri[q] = 0;        // negative or past the list: entry 0, as the reference's flat lists
-        k.info |= (uint32_t)ri[q] << (8 + 4 * q);
-    }
-    // B pictures: a macroblock that uses list 1 anywhere (or lacks list 0 somewhere) goes to the generic two-list class,
-    // all four quadrants of it; one that predicts from list 0 only is an ordinary P-type macroblock for this stage
+    bool zq[4] = { false, false, false, false };           // Z per quadrant
+    // B pictures: a macroblock that predicts from list 0 only is an ordinary P-type macroblock for this stage
     bool two_lists = false;
-    if (pd->slice_type == P264_SLICE_B && (k.info & MCMB_INTER)) {
-        const uint32_t refs1 = gload1(pd->ref_idx_l1 + mbi * 4);
+    uint32_t refs1 = 0xffffffffu;
+    if (BPIC && pd->slice_type == P264_SLICE_B && (k.info & MCMB_INTER)) {
+        refs1 = gload1(pd->ref_idx_l1 + mbi * 4);
         two_lists = ((~refs1 | refs) & 0x80808080u) != 0;                      // some list-1 index >= 0, or some list-0 index < 0
     }
-    if (two_lists) {
-        const int kc = band * MCC_KEYS + MCC_BI + (cc ? MCC_RESID : 0);
+    if (!BPIC || !two_lists) {
+        if (pass) { k.info = 0; return k; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int ky = band * MCY_KEYS + (PC_GEN | (((mask >> (4 * q)) & 15) ? MCY_RESID : 0));
-            k.key[q] = (uint32_t)ky | (uint32_t)kc << 16;
-            k.vec[q] = 0;
+            ri[q] = (int)(int8_t)(refs >> (8 * q));
+            if (ri[q] < 0 || ri[q] >= n_ref) ri[q] = 0;    // negative or past the list: entry 0, as the reference's flat lists
+            k.info |= (uint32_t)ri[q] << (8 + 4 * q);
         }
-        return k;
+    } else {
+        const int *mvp1 = pd->mv_l1 + mbi * 16;
+        const uint4 n0 = gload4(mvp1), n1 = gload4(mvp1 + 4), n2 = gload4(mvp1 + 8), n3 = gload4(mvp1 + 12);
+        bool ok = true, any = false;
+        uint32_t lq = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r0 = (int)(int8_t)(refs >> (8 * q)), r1 = (int)(int8_t)(refs1 >> (8 * q));
+            const bool u1 = r1 >= 0, u0 = r0 >= 0 || !u1;  // (no list at all: list 0, entry 0)
+            uint32_t v0, v1;
+            const bool un0 = quad_uniform(m0, m1, m2, m3, q, v0), un1 = quad_uniform(n0, n1, n2, n3, q, v1);
+            ok &= (!u0 || un0) && (!u1 || un1);
+            const bool bi = u0 && u1;
+            bool l1; int r;
+            if (!pass) { l1 = !u0; zq[q] = bi; r = l1 ? r1 : r0; any = true; }
+            else       { l1 = bi; zq[q] = !bi; r = bi ? r1 : 0; any |= bi; }
+            if (r < 0 || r >= (l1 ? pd->n_ref_l1 : n_ref)) r = 0;
+            // (list and index: what a whole macroblock has to agree on; second pass: the list-0 index too - the weight is per pair)
+            ri[q] = r | (l1 ? 16 : 0) | ((pass && bi) ? (r0 & 15) << 5 : 0);
+            k.info |= (uint32_t)r << (8 + 4 * q);
+            lq |= (l1 ? 1u : 0u) << q;
+            // this pass's vector of the quadrant takes the place of the list-0 vectors below
+            const uint32_t v = (pass && !bi) ? 0u : l1 ? v1 : v0;
+            if (q == 0) { m0.x = m0.y = m1.x = m1.y = v; } else if (q == 1) { m0.z = m0.w = m1.z = m1.w = v; }
+            else if (q == 2) { m2.x = m2.y = m3.x = m3.y = v; } else { m2.z = m2.w = m3.z = m3.w = v; }
+        }
+        if (!ok) {
+            // vectors differing inside a quadrant: the generic two-list class, all four quadrants, first pass
+            if (pass) { k.info = 0; return k; }
+            k.info = MCMB_INTER;
+            const int kc = band * MCC_KEYS + MCC_BI + (cc ? MCC_RESID : 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ky = band * MCY_KEYS + (PC_GEN | (((mask >> (4 * q)) & 15) ? MCY_RESID : 0));
+                k.key[q] = (uint32_t)ky | (uint32_t)kc << 16;
+            }
+            return k;
+        }
+        if (!any) { k.info = 0; return k; }
+        k.info |= lq << 24 | ((uint32_t)zq[0] | (uint32_t)zq[1] << 1 | (uint32_t)zq[2] << 2 | (uint32_t)zq[3] << 3) << 28;
     }
     const uint32_t v0 = m0.x;
     const uint32_t diff = (m0.y ^ v0) | (m0.z ^ v0) | (m0.w ^ v0) | (m1.x ^ v0) | (m1.y ^ v0) | (m1.z ^ v0) | (m1.w ^ v0) | (m2.x ^ v0) | (m2.y ^ v0)
                         | (m2.z ^ v0) | (m2.w ^ v0) | (m3.x ^ v0) | (m3.y ^ v0) | (m3.z ^ v0) | (m3.w ^ v0);
-    const bool whole = diff == 0 && ri[0] == ri[1] && ri[0] == ri[2] && ri[0] == ri[3];
+    const bool whole = diff == 0 && ri[0] == ri[1] && ri[0] == ri[2] && ri[0] == ri[3] && zq[0] == zq[1] && zq[0] == zq[2] && zq[0] == zq[3];
     if (whole) {
         k.info |= MCMB_WHOLE;
         const int mvx = mv_x((int)v0), mvy = mv_y((int)v0);
@@ -165,20 +226,17 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
         const bool in_y = wx >= 0 && wx + 21 <= g.w && wy >= 0 && wy + 21 <= g.h;
         const int cx = mbx * 8 + (mvx >> 3), cy = mby * 8 + (mvy >> 3);                 // 9 x 9 samples
         const bool in_c = cx >= 0 && cx + 9 <= g.cw && cy >= 0 && cy + 9 <= g.ch;
-        const int ky = band * MCY_KEYS + (phase_class(mvx & 3, mvy & 3) | (in_y ? 0 : MCY_CLAMP) | ((mask & 0xffffu) ? MCY_RESID : 0));
-        const int kc = band * MCC_KEYS + (in_c ? 0 : MCC_CLAMP) + (cc ? MCC_RESID : 0);
+        const int ky = band * MCY_KEYS + (phase_class(mvx & 3, mvy & 3) | (in_y ? 0 : MCY_CLAMP) | (((mask & 0xffffu) && !zq[0]) ? MCY_RESID : 0));
+        const int kc = band * MCC_KEYS + (in_c ? 0 : MCC_CLAMP) + ((cc && !zq[0]) ? MCC_RESID : 0);
         k.key[0] = (uint32_t)ky | (uint32_t)kc << 16;
         k.vec[0] = v0;
-        k.key[1] = k.key[2] = k.key[3] = 0; k.vec[1] = k.vec[2] = k.vec[3] = 0;
         return k;
     }
     bool c_inside = true;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        // vectors of the quadrant's four 4x4 blocks (raster inside the macroblock: b0, b0+1, b0+4, b0+5)
-        const uint4 top = q < 2 ? m0 : m2, bot = q < 2 ? m1 : m3;
-        const uint32_t va = (q & 1) ? top.z : top.x, vb = (q & 1) ? top.w : top.y, vc = (q & 1) ? bot.z : bot.x, vd = (q & 1) ? bot.w : bot.y;
-        const bool uniform = va == vb && va == vc && va == vd;
+        uint32_t va;
+        const bool uniform = quad_uniform(m0, m1, m2, m3, q, va);
         const int X0 = mbx * 16 + (q & 1) * 8, Y0 = mby * 16 + (q >> 1) * 8;
         const int mvx = mv_x((int)va), mvy = mv_y((int)va);
         const int wx = X0 + (mvx >> 2) - 2, wy = Y0 + (mvy >> 2) - 2;                   // 13 x 13 samples
@@ -187,7 +245,7 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
         const bool in_c = cx >= 0 && cx + 5 <= g.cw && cy >= 0 && cy + 5 <= g.ch;
         int pc = phase_class(mvx & 3, mvy & 3), fl = in_y ? 0 : MCY_CLAMP;
         if (!uniform) { pc = PC_GEN; fl = MCY_CLAMP; }
-        if ((mask >> (4 * q)) & 15) fl |= MCY_RESID;
+        if (((mask >> (4 * q)) & 15) && !zq[q]) fl |= MCY_RESID;
         const int ky = band * MCY_KEYS + (pc | fl);
         c_inside &= in_c && uniform;
         k.key[q] = (uint32_t)ky;
@@ -205,14 +263,15 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
 // stays in registers between the two passes: the macroblock arrays are read once.
 #define MC_KEY_SLOTS (2 * MC_MAX_BANDS * MCY_KEYS + 2 * MC_MAX_BANDS * MCC_KEYS)
 #define MC_SORT_KEEP 8
-struct McSortCtx { const PicDev *pd; uint32_t *cnt, *pos, *out; int b_ym, b_yq, b_cm, b_cq; uint32_t l_ym, l_yq, l_cm, l_cq; };
+struct McSortCtx { const PicDev *pd; uint32_t *cnt, *pos, *out; int b_ym, b_yq, b_cm, b_cq; uint32_t l_ym, l_yq, l_cm, l_cq; int pass; };
+__device__ __forceinline__ bool mcmb_luma_quad(const McMb &k, int q, int pass) { return !(pass && ((k.info >> (28 + q)) & 1u)); }
 __device__ __forceinline__ void mc_count(const McSortCtx &c, const McMb &k)
 {
     if (!(k.info & MCMB_INTER)) return;
     if (k.info & MCMB_WHOLE) { atomicAdd(&c.cnt[c.b_ym + (k.key[0] & 0xffffu)], 1u); atomicAdd(&c.cnt[c.b_cm + (k.key[0] >> 16)], 1u); }
     else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) atomicAdd(&c.cnt[c.b_yq + (k.key[q] & 0xffffu)], 1u);
+        for (int q = 0; q < 4; q++) if (mcmb_luma_quad(k, q, c.pass)) atomicAdd(&c.cnt[c.b_yq + (k.key[q] & 0xffffu)], 1u);
         atomicAdd(&c.cnt[c.b_cq + (k.key[0] >> 16)], 4u);
     }
 }
@@ -222,35 +281,44 @@ __device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, in
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
     const uint4 rec = gload4(c.pd->mb + mbi);              // (second look at the record: out of the cache)
-    const uint32_t ez = (rec.y & 0x03ffffffu) | ((rec.x >> 8) & 63u) << 26, ew = rec.z;
+    const uint32_t ez = (rec.y & 0x03ffffffu) | ((rec.x >> 8) & 63u) << 26;
+    uint32_t ew[4] = { rec.z, rec.z, rec.z, rec.z };
+    if (c.pass) {
+        // second pass: the weight of the pair of references (the table the parser derived, core/macroblock.c:525-583) rides
+        // in the entry; 32 = plain average
+        const uint32_t refs = gload1(c.pd->ref_idx + mbi * 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int w = 32;
+            if (c.pd->weighted) {
+                const int r0 = min(max((int)(int8_t)(refs >> (8 * q)), 0), c.pd->n_ref - 1), r1 = (int)((k.info >> (8 + 4 * q)) & 15u);
+                w = (int)glob(c.pd->bipred_w)[r0 * P264HIP_MAX_REFS + r1];
+            }
+            ew[q] = (rec.z & ((1u << MCE_W_SHIFT) - 1u)) | (uint32_t)w << MCE_W_SHIFT;
+        }
+    }
     if (k.info & MCMB_WHOLE) {
-        const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, 0), k.vec[0], ez, ew);
+        const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, 0, c.pass), k.vec[0], ((k.info >> 28) & 1u) ? (ez & 0xfc000000u) : ez, ew[0]);
         gstore4(c.out + c.l_ym + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
         gstore4(c.out + c.l_cm + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
     } else {
         const uint32_t cq = atomicAdd(&c.pos[c.b_cq + (k.key[0] >> 16)], 4u);     // (a multiple of 4: every segment starts on a chunk)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, q), k.vec[q], ez, ew);
-            gstore4(c.out + c.l_yq + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
+            const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, q, c.pass), k.vec[q], ((k.info >> (28 + q)) & 1u) ? (ez & 0xfc000000u) : ez, ew[q]);
+            if (mcmb_luma_quad(k, q, c.pass)) gstore4(c.out + c.l_yq + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
             gstore4(c.out + c.l_cq + MC_ENTRY_WORDS * (cq + (uint32_t)q), e);
         }
     }
 }
-__global__ __launch_bounds__(MC_SORT_THREADS)
-void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
+template <int PASS, bool BPIC>
+__device__ __forceinline__ void mc_sort_pass(const PicDev *pd, uint32_t *out, uint32_t *cnt, uint32_t *pos, const Geom &g, const McLayout &ml, uint32_t inv_mbw)
 {
-    __shared__ uint32_t cnt[MC_KEY_SLOTS], pos[MC_KEY_SLOTS];
-    const PicDev *pd = pics + blockIdx.x;
-    uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
+    constexpr int L0 = PASS * ML_LISTS;
     const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
     const int b_ym = 0, b_yq = nky, b_cm = 2 * nky, b_cq = 2 * nky + nkc, b_end = 2 * nky + 2 * nkc;     // key slots of the four lists
-    const McSortCtx ctx = { pd, cnt, pos, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[ML_YM], ml.off_list[ML_YQ], ml.off_list[ML_CM], ml.off_list[ML_CQ] };
     const int tid = threadIdx.x;
-    if (pd->slice_type == P264_SLICE_I) {                 // wave-uniform
-        if (tid < ML_LISTS) gstore1(out + tid, 0);
-        return;
-    }
+    const McSortCtx ctx = { pd, cnt, pos, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[L0 + ML_YM], ml.off_list[L0 + ML_YQ], ml.off_list[L0 + ML_CM], ml.off_list[L0 + ML_CQ], PASS };
     for (int k = tid; k < b_end; k += MC_SORT_THREADS) cnt[k] = 0;
     __syncthreads();
     const bool keep = g.n_mb <= MC_SORT_KEEP * MC_SORT_THREADS;
@@ -260,10 +328,10 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
         for (int j = 0; j < MC_SORT_KEEP; j++) {
             const int mbi = tid + j * MC_SORT_THREADS;
             kept[j].info = 0;
-            if (mbi < g.n_mb) { kept[j] = mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2); mc_count(ctx, kept[j]); }
+            if (mbi < g.n_mb) { kept[j] = mc_classify<BPIC>(pd, g, mbi, inv_mbw, (int)ml.band_log2, PASS); mc_count(ctx, kept[j]); }
         }
     } else {
-        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_count(ctx, mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2));
+        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_count(ctx, mc_classify<BPIC>(pd, g, mbi, inv_mbw, (int)ml.band_log2, PASS));
     }
     __syncthreads();
     // segment starts: every thread sums the padded counts in front of its key (a few hundred LDS reads at most), notes the
@@ -277,25 +345,50 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
         for (int j = 0; j < kk; j++) start += (cnt[first + j] + per - 1) / per;
         const uint32_t n = (cnt[k] + per - 1) / per;                            // chunks of this key, from chunk `start`
         pos[k] = start * per;
-        AS1 uint8_t *cls = glob((uint8_t *)(out + (l == ML_YM ? ml.off_cls[ML_YM] : l == ML_YQ ? ml.off_cls[ML_YQ] : l == ML_CM ? ml.off_cls[ML_CM] : ml.off_cls[ML_CQ])));
+        AS1 uint8_t *cls = glob((uint8_t *)(out + (l == ML_YM ? ml.off_cls[L0 + ML_YM] : l == ML_YQ ? ml.off_cls[L0 + ML_YQ] : l == ML_CM ? ml.off_cls[L0 + ML_CM] : ml.off_cls[L0 + ML_CQ])));
         const uint8_t v = (uint8_t)(kk % mc_list_keys(l));
         for (uint32_t c = 0; c < n; c++) cls[start + c] = v;
-        if (kk == nk - 1) gstore1(out + l, start + n);
+        if (kk == nk - 1) gstore1(out + L0 + l, start + n);
     }
     __syncthreads();
     if (keep) {
 #pragma unroll
         for (int j = 0; j < MC_SORT_KEEP; j++) mc_scatter(ctx, kept[j], tid + j * MC_SORT_THREADS, g, inv_mbw);
     } else {
-        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_scatter(ctx, mc_classify(pd, g, mbi, inv_mbw, (int)ml.band_log2), mbi, g, inv_mbw);
+        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_scatter(ctx, mc_classify<BPIC>(pd, g, mbi, inv_mbw, (int)ml.band_log2, PASS), mbi, g, inv_mbw);
     }
     __syncthreads();
     for (int k = tid; k < b_end; k += MC_SORT_THREADS) {                      // padding entries behind every segment
         const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
         const uint32_t per = (uint32_t)mc_chunk_items(l), end = pos[k];
-        const uint32_t lo = l == ML_YM ? ml.off_list[ML_YM] : l == ML_YQ ? ml.off_list[ML_YQ] : l == ML_CM ? ml.off_list[ML_CM] : ml.off_list[ML_CQ];
+        const uint32_t lo = l == ML_YM ? ml.off_list[L0 + ML_YM] : l == ML_YQ ? ml.off_list[L0 + ML_YQ] : l == ML_CM ? ml.off_list[L0 + ML_CM] : ml.off_list[L0 + ML_CQ];
         for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore4(out + lo + MC_ENTRY_WORDS * p, make_uint4(0xffffffffu, 0, 0, 0));
     }
+}
+template <bool BPIC>
+__device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml, uint32_t inv_mbw, uint32_t *cnt, uint32_t *pos)
+{
+    const PicDev *pd = pics + blockIdx.x;
+    uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
+    const int tid = threadIdx.x;
+    const int n_pass = pd->slice_type == P264_SLICE_I ? 0 : (BPIC && pd->slice_type == P264_SLICE_B) ? 2 : 1;       // wave-uniform
+    if (tid < ML_LISTS * 2 && tid >= ML_LISTS * n_pass) gstore1(out + tid, 0);                            // the passes not taken: empty lists
+    if (n_pass > 0) mc_sort_pass<0, BPIC>(pd, out, cnt, pos, g, ml, inv_mbw);
+    if (BPIC && n_pass > 1) { __syncthreads(); mc_sort_pass<1, BPIC>(pd, out, cnt, pos, g, ml, inv_mbw); }
+}
+// batches without B pictures (the two-list classification costs registers the sort of a P picture does not have to pay for)
+__global__ __launch_bounds__(MC_SORT_THREADS)
+void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
+{
+    __shared__ uint32_t cnt[MC_KEY_SLOTS], pos[MC_KEY_SLOTS];
+    mc_sort_picture<false>(pics, mc_all, g, ml, inv_mbw, cnt, pos);
+}
+// batches with B pictures
+__global__ __launch_bounds__(MC_SORT_THREADS)
+void k_mc_sort_b(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
+{
+    __shared__ uint32_t cnt[MC_KEY_SLOTS], pos[MC_KEY_SLOTS];
+    mc_sort_picture<true>(pics, mc_all, g, ml, inv_mbw, cnt, pos);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -323,6 +416,7 @@ __device__ __forceinline__ u32x4 bload4(rsrc_t r, uint32_t off) { return __built
 // reconstructed samples are written once and not read again by this stage: non-temporal stores keep them from pushing
 // reference lines out of L2 (measured: -3 % on the stage)
 #define MC_ST_AUX 2
+__device__ __forceinline__ u32x2 bload2(rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); }
 __device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b) { const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, MC_ST_AUX); }
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
@@ -690,12 +784,12 @@ __device__ __forceinline__ int xcd_logical_block()
 // k_mc_luma<MB>: one wavefront = one chunk of one key: 4 macroblock items of 16 lanes, or 16 quadrant items of 4 lanes;
 // the lane is one 4x4 block
 // ------------------------------------------------------------------------------------------
-template <bool MB>
+template <bool MB, bool PB>
 __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
                                              const McLayout &ml, int sub, int role_wgs)
 {
     typedef YItem<MB> I;
-    constexpr int LIST = MB ? ML_YM : ML_YQ;
+    constexpr int LIST = (MB ? ML_YM : ML_YQ) + (PB ? ML_LISTS : 0);
     const int wave = rfl((int)(threadIdx.x >> 6));
     // A wavefront walks the list's chunks with a stride of all the wavefronts that work on this list of this picture; the key
     // and the list entries of its NEXT chunk are requested before it starts on the current one, so that only the window
@@ -707,6 +801,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     const int n_ref = pd->n_ref;
+    const bool list_tables = n_ref > 1 || pd->slice_type == P264_SLICE_B;       // (scalar) else: the one reference of list 0
     uint32_t key_w = cls_w[chunk >> 2];
     uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
   for (;;) {
@@ -718,7 +813,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     const int pc = key & 7;
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
-    const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x & MC_ITEM_MASK) >> 13) : 0;
+    const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x >> 13) & 1023u) : 0;
     // block position inside the macroblock
     const int q = MB ? 0 : (valid ? (int)(e.x & 3) : 0);
     const int bx = MB ? (li & 3) : (q & 1) * 2 + (li & 1), by = MB ? (li >> 2) : (q >> 1) * 2 + (li >> 1);
@@ -726,7 +821,8 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     int mvp = (int)e.y;
     if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + (mby * g.mb_w + mbx) * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
     uint32_t roff = pd->ref_off[0];
-    if (n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];                             // (wave-uniform branch)
+    if (list_tables) roff = glob((e.x & MCE_LIST1) ? pd->ref_off_l1 : pd->ref_off)[e.x >> 28];       // (wave-uniform branch)
+    const uint32_t cidx = PB ? (e.w & ((1u << MCE_W_SHIFT) - 1u)) : e.w;            // place in the coefficient stream
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
     const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
     const unsigned mask = e.z & 0x03ffffffu;
@@ -734,6 +830,14 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     const bool coded = valid && ((mask >> blk) & 1);
     // coded levels (requested right behind the windows: they fly while the prediction is computed)
     uint4 la = make_uint4(0, 0, 0, 0), lb = la;
+    // second pass: the list-0 prediction the first pass left in the destination, as the lane will store it (requested in
+    // front of the windows: it has arrived when they have)
+    const uint32_t dsto = pd->dst_off + mb_luma_off(g, mbx, mby) + (MB ? (uint32_t)((by * 4 + bx) * 16) : (uint32_t)((by * 4 + ((bx & 1) ? 2 : 0)) * 16 + (bx >> 1) * 8));
+    u32x4 prev = { 0, 0, 0, 0 };
+    if (PB && valid) {
+        if (MB) prev = bload4(rs, dsto);
+        else { const u32x2 a = bload2(rs, dsto), b = bload2(rs, dsto + 16); prev = u32x4{ a.x, a.y, b.x, b.y }; }
+    }
     // ---- prediction ----
     uint32_t out[4];
     if (MB || pc != PC_GEN) {
@@ -750,7 +854,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         if (!(key & MCY_CLAMP)) { if (rows_mid) stage_luma<MB, 2, RM, false>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 0, I::ROWS, false>(img, rs, roff, g, xs, wy, li, third); }
         else                    { if (rows_mid) stage_luma<MB, 2, RM, true>(img, rs, roff, g, xs, wy, li, third);  else stage_luma<MB, 0, I::ROWS, true>(img, rs, roff, g, xs, wy, li, third); }
         if ((key & MCY_RESID) && coded) {
-            const int16_t *cf = pd->coefs + ((size_t)e.w + coef_slot(mask, blk)) * 16;
+            const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
         }
         wave_lds_fence();
@@ -760,7 +864,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
         // straight from memory, one pass per phase class present among the lanes.
         if ((key & MCY_RESID) && coded) {
-            const int16_t *cf = pd->coefs + ((size_t)e.w + coef_slot(mask, blk)) * 16;
+            const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
         }
         // one prediction per lane from reference frame `ro` with vector `mv` (lanes with use = false are left alone)
@@ -804,6 +908,20 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
             }
         }
     }
+    if (PB) {
+        // (core/macroblock.c:525-583, core/mc.c:76-132) the first pass's rows back into block order, then the mean or the weighted sum
+        uint32_t p0[4];
+        if (MB) { const uint32_t pr[4] = { prev.x, prev.y, prev.z, prev.w }; quad_transpose(p0, pr, lane); }
+        else {
+            // the lane loaded rows (2 * right, 2 * right + 1) of the pair of blocks: its own halves stay, the others swap
+            const bool right = bx & 1;
+            const uint32_t g0 = lane_xor1(right ? prev.x : prev.y), g1 = lane_xor1(right ? prev.z : prev.w);
+            p0[0] = right ? g0 : prev.x; p0[1] = right ? g1 : prev.z; p0[2] = right ? prev.y : g0; p0[3] = right ? prev.w : g1;
+        }
+        const int wgt = (int)e.w >> MCE_W_SHIFT;
+#pragma unroll
+        for (int y = 0; y < 4; y++) out[y] = pd->weighted ? bipred_weight4(p0[y], out[y], wgt) : bipred_avg4(p0[y], out[y]);
+    }
     // ---- residual (decoder/macroblock.c:839-847) ----
     if ((key & MCY_RESID) && __ballot(coded)) {
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
@@ -821,16 +939,15 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         // whole 16-byte row and the macroblock's sixteen lanes two whole cache lines
         uint32_t t[4];
         quad_transpose(t, out, lane);
-        if (valid) bstore4(rs, pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + bx) * 16), t[0], t[1], t[2], t[3]);
+        if (valid) bstore4(rs, dsto, t[0], t[1], t[2], t[3]);
     } else {
         const bool right = bx & 1;
         const uint32_t g0 = lane_xor1(right ? out[0] : out[2]), g1 = lane_xor1(right ? out[1] : out[3]);
         const uint32_t r0a = right ? g0 : out[0], r0b = right ? out[2] : g0;       // row 4*by + 2*right: samples 0-3, 4-7
         const uint32_t r1a = right ? g1 : out[1], r1b = right ? out[3] : g1;       // the row below
         if (valid) {
-            const uint32_t o = pd->dst_off + mb_luma_off(g, mbx, mby) + (uint32_t)((by * 4 + (right ? 2 : 0)) * 16 + (bx >> 1) * 8);
-            bstore2(rs, o, r0a, r0b);
-            bstore2(rs, o + 16, r1a, r1b);
+            bstore2(rs, dsto, r0a, r0b);
+            bstore2(rs, dsto + 16, r1a, r1b);
         }
     }
     if (!more) break;
@@ -902,12 +1019,12 @@ template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece(rsrc_t rs, u
 }
 __device__ __forceinline__ void lds_put16(uint8_t *p, u32x4 v) { *(uint2 *)p = make_uint2(v.x, v.y); *(uint2 *)(p + 8) = make_uint2(v.z, v.w); }
 
-template <bool MB>
+template <bool MB, bool PB>
 __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
                                                const McLayout &ml, int sub, int role_wgs)
 {
     typedef CItem<MB> I;
-    constexpr int LIST = MB ? ML_CM : ML_CQ;
+    constexpr int LIST = (MB ? ML_CM : ML_CQ) + (PB ? ML_LISTS : 0);
     const int wave = rfl((int)(threadIdx.x >> 6));
     // (chunk walk with the next chunk's key and entries requested ahead, as in mc_luma_body)
     const int stride = role_wgs * 4, n_chunks = (int)mc[LIST];
@@ -917,6 +1034,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     const int n_ref = pd->n_ref;
+    const bool list_tables = n_ref > 1 || pd->slice_type == P264_SLICE_B;
     uint32_t key_w = cls_w[chunk >> 2];
     uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
   for (;;) {
@@ -927,10 +1045,15 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
-    const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x & MC_ITEM_MASK) >> 13) : 0;
+    const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x >> 13) & 1023u) : 0;
     const int q = MB ? (li >> 1) : (valid ? (int)(e.x & 3) : 0);
     uint32_t roff = pd->ref_off[0];
-    if (n_ref > 1) roff = glob(pd->ref_off)[e.x >> 28];
+    if (list_tables) roff = glob((e.x & MCE_LIST1) ? pd->ref_off_l1 : pd->ref_off)[e.x >> 28];
+    const uint32_t cidx = PB ? (e.w & ((1u << MCE_W_SHIFT) - 1u)) : e.w;
+    // the 16-byte row this lane stores (see the end of the loop); second pass: what the first pass left there
+    const uint32_t dsto = pd->dst_off + mb_chroma_off(g, mbx, mby) + (uint32_t)((q >> 1) * 64 + (lane & 3) * 16);
+    u32x4 prev = { 0, 0, 0, 0 };
+    if (PB && valid) prev = bload4(rs, dsto);
     const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;      // the block's first sample
     const unsigned mask = e.z & 0x03ffffffu;
     const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
@@ -980,7 +1103,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
             img = pimg + (i >> 1) * I::BYTES;
         }
         if (key & MCC_RESID) {
-            const int16_t *cf = pd->coefs + (size_t)e.w * 16;
+            const int16_t *cf = pd->coefs + (size_t)cidx * 16;
             if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
@@ -998,7 +1121,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
         // follows its own vector): clamped windows straight from memory, one pass per piece, wave-uniformly skipped when
         // nobody needs it
         if (key & MCC_RESID) {
-            const int16_t *cf = pd->coefs + (size_t)e.w * 16;
+            const int16_t *cf = pd->coefs + (size_t)cidx * 16;
             if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
@@ -1025,7 +1148,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
                 }
             }
         };
-        if (!(key & MCC_BI)) predict(roff, pd->mv, valid, out);
+        if (!(key & MCC_BI)) predict(roff, (valid && (e.x & MCE_LIST1)) ? pd->mv_l1 : pd->mv, valid, out);      // (padding lanes: list 0, mv_l1 is null outside B pictures)
         else {
             // B picture, two lists: as in mc_luma_body
             const int r0 = (int)glob(pd->ref_idx)[mbi * 4 + q], r1 = (int)glob(pd->ref_idx_l1)[mbi * 4 + q];
@@ -1042,6 +1165,20 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
                 const uint32_t both = pd->weighted ? bipred_weight4(p0[y], p1[y], wgt) : bipred_avg4(p0[y], p1[y]);
                 out[y] = (u0 && u1) ? both : u0 ? p0[y] : p1[y];
             }
+        }
+    }
+    if (PB) {
+        // the first pass's rows (dwords U left, U right, V left, V right) back into block order; then the mean or the weighted
+        // sum, or - quadrants that were finished in the first pass - the samples as they are
+        const uint32_t pr[4] = { prev.x, prev.z, prev.y, prev.w };
+        uint32_t p0[4];
+        quad_transpose(p0, pr, lane);
+        const int wgt = (int)e.w >> MCE_W_SHIFT;
+        const bool keep = (e.x & MCE_KEEP) != 0;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint32_t both = pd->weighted ? bipred_weight4(p0[y], out[y], wgt) : bipred_avg4(p0[y], out[y]);
+            out[y] = keep ? p0[y] : both;
         }
     }
     // ---- residual (decoder/macroblock.c:851-890): chroma DC through the 2x2 transform, AC, inverse transform ----
@@ -1071,10 +1208,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
         // (four 4-byte stores per lane kept the address unit busier than anything else in this kernel).
         uint32_t t[4];
         quad_transpose(t, out, lane);
-        if (valid) {
-            const uint32_t o = pd->dst_off + mb_chroma_off(g, mbx, mby) + (uint32_t)((q >> 1) * 64 + (lane & 3) * 16);
-            bstore4(rs, o, t[0], t[2], t[1], t[3]);      // lane-in-quad = plane + 2 * (block column): dwords U0 U1 V0 V1
-        }
+        if (valid) bstore4(rs, dsto, t[0], t[2], t[1], t[3]);      // lane-in-quad = plane + 2 * (block column): dwords U0 U1 V0 V1
     }
     if (!more) break;
     chunk = next; key_w = key_w_next; e = e_next;
@@ -1093,11 +1227,11 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
 #define MC_COST_YQ 10u
 #define MC_COST_CM 5u
 #define MC_COST_CQ 9u
-__global__ __launch_bounds__(256, 4)
-void k_mc(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+template <bool PB>
+__device__ __forceinline__ void mc_roles(uint8_t *images, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml,
+                                         int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t images[YItem<false>::LEAD + 4 * 16 * YItem<false>::BYTES];        // the largest of the four roles' images
-    static_assert(sizeof(images) >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && sizeof(images) >= 4 * 8 * CItem<true>::BYTES && sizeof(images) >= 4 * 32 * CItem<false>::BYTES, "image space");
+    constexpr int L0 = PB ? ML_LISTS : 0;
     const int logical = xcd_logical_block();
     if (logical >= n_wgs) return;
     int pic = (int)__umulhi((unsigned)logical, inv_wgs);
@@ -1106,15 +1240,30 @@ void k_mc(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, 
     const PicDev *pd = pics + pic;
     const uint32_t *mc = mc_all + (size_t)pic * ml.words;  // (addresses from kernel arguments only: the first loads depend on nothing)
     // role split (scalar): every non-empty list gets one workgroup, the rest go by cost
-    const uint32_t n0 = mc[ML_YM], n1 = mc[ML_YQ], n2 = mc[ML_CM], n3 = mc[ML_CQ];
+    const uint32_t n0 = mc[L0 + ML_YM], n1 = mc[L0 + ML_YQ], n2 = mc[L0 + ML_CM], n3 = mc[L0 + ML_CQ];
     const uint32_t t0 = n0 * MC_COST_YM, t1 = n1 * MC_COST_YQ, t2 = n2 * MC_COST_CM, t3 = n3 * MC_COST_CQ, tt = t0 + t1 + t2 + t3;
     if (tt == 0) return;
     const uint32_t nz = (n0 != 0) + (n1 != 0) + (n2 != 0) + (n3 != 0), spare = (uint32_t)wgs_per_pic - nz;       // wgs_per_pic >= 4
     const float inv = (float)spare / (float)tt;
     const int w1 = (n1 != 0) + (int)((float)t1 * inv), w2 = (n2 != 0) + (int)((float)t2 * inv), w3 = (n3 != 0) + (int)((float)t3 * inv);
     const int w0 = wgs_per_pic - w1 - w2 - w3;             // (luma macroblock items take the rounding remainder)
-    if (s < w0) mc_luma_body<true>(images, pd, mc, g, ml, s, w0);
-    else if (s < w0 + w1) mc_luma_body<false>(images, pd, mc, g, ml, s - w0, w1);
-    else if (s < w0 + w1 + w2) mc_chroma_body<true>(images, pd, mc, g, ml, s - w0 - w1, w2);
-    else mc_chroma_body<false>(images, pd, mc, g, ml, s - w0 - w1 - w2, w3);
+    if (s < w0) mc_luma_body<true, PB>(images, pd, mc, g, ml, s, w0);
+    else if (s < w0 + w1) mc_luma_body<false, PB>(images, pd, mc, g, ml, s - w0, w1);
+    else if (s < w0 + w1 + w2) mc_chroma_body<true, PB>(images, pd, mc, g, ml, s - w0 - w1, w2);
+    else mc_chroma_body<false, PB>(images, pd, mc, g, ml, s - w0 - w1 - w2, w3);
+}
+#define MC_IMAGE_BYTES (YItem<false>::LEAD + 4 * 16 * YItem<false>::BYTES)        // the largest of the four roles' images
+static_assert(MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 8 * CItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 32 * CItem<false>::BYTES, "image space");
+__global__ __launch_bounds__(256, 4)
+void k_mc(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t images[MC_IMAGE_BYTES];
+    mc_roles<false>(images, pics, mc_all, g, ml, wgs_per_pic, n_wgs, inv_wgs);
+}
+// B pictures: the second pass (list-1 predictions of the blocks that use both lists), behind k_mc
+__global__ __launch_bounds__(256, 4)
+void k_mc_second(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t images[MC_IMAGE_BYTES];
+    mc_roles<true>(images, pics, mc_all, g, ml, wgs_per_pic, n_wgs, inv_wgs);
 }

@@ -413,7 +413,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // interpolation has to do, then the luma and chroma kernels over the sorted lists (kernel_mc.h), side by side
         ScopedStamp t(c, 0);
         const McLayout ml = c->ml;
-        hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
+        if (any_b) hipLaunchKernelGGL(k_mc_sort_b, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
+        else hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
         // one launch for luma / chroma, macroblock / quadrant items (k_mc): every picture gets the same number of workgroups,
         // which split into the four roles on the device.  Enough workgroups per picture to fill the chip a few times over,
         // no more than there can be chunks (four wavefronts per workgroup, one chunk per wavefront pass).
@@ -426,6 +427,10 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         if (wgs < 4) wgs = 4;
         hipLaunchKernelGGL(k_mc, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, c->stream, (const PicDev *)c->d_batch[r], (const uint32_t *)c->d_mc, g, ml,
                            wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
+        // B pictures: the blocks that predict from both lists get their second prediction (and their residual) in a second pass
+        if (any_b)
+            hipLaunchKernelGGL(k_mc_second, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, c->stream, (const PicDev *)c->d_batch[r], (const uint32_t *)c->d_mc, g, ml,
+                               wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
     }
     if (conc) { launch_bs(); HIPCHK(hipEventRecord(c->ev_join[3], c->side[3])); bs_forked = true; }
     {

@@ -14,6 +14,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n = r["Name"].split("(")[0]
+    n = n[5:] if n.startswith("void ") else n
     if n.startswith("k_"): print("%-16s calls %4s  avg %10.1f us  total %8.2f ms  %5s %%" % (n, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 PY
 tail -c 600 $out/trace.log | grep -o '"kernels".*' | head -c 400; echo

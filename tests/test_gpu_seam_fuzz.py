@@ -54,7 +54,7 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
         for dst, src in zip(store[s], f):
             dst[:] = src
         hip.write_frame(0, s, *f)
-    seen = dict(sub4x4=0, qp_edges=0, wrap=0, phases=set(), multi_ref=0, types=set(), avail=set(), intra4_modes=set(), weighted=set(), dirs=set())
+    seen = dict(sub4x4=0, qp_edges=0, wrap=0, phases=set(), multi_ref=0, types=set(), avail=set(), intra4_modes=set(), weighted=set(), dirs=set(), b_roads=set())
     oracle.oracle_stats_reset()
     for i in range(n_pics):
         pic = seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=(i != 2), dst_slot=i % slots, **kw)
@@ -72,6 +72,30 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
             seen["weighted"].add(int(pic.desc.weighted_bipred))
             r0, r1 = pic.ref_idx.reshape(n, 4)[inter], pic.ref_idx_l1.reshape(n, 4)[inter]
             seen["dirs"] |= set(((r0 >= 0).astype(int) + 2 * (r1 >= 0).astype(int)).reshape(-1).tolist())
+            # which road through the motion-compensation stage (kernel_mc.h, mc_classify): one list -> the P road; both lists
+            # with one vector per quadrant and list -> two passes (whole-macroblock items, quadrant items, quadrants that the
+            # second pass only carries through); vectors differing inside a quadrant -> the generic two-list class
+            mv1 = pic.mv_l1.reshape(n, 4, 4, 2)
+            for m, a0, a1 in zip(np.nonzero(inter)[0], r0, r1):
+                if not (a1 >= 0).any():
+                    seen["b_roads"].add("list0 only"); continue
+                uni = True
+                for q in range(4):
+                    qy, qx = (q >> 1) * 2, (q & 1) * 2
+                    for used, vv in ((a0[q] >= 0 or a1[q] < 0, mv[m]), (a1[q] >= 0, mv1[m])):
+                        if used and len({tuple(x) for x in vv[qy:qy + 2, qx:qx + 2].reshape(4, 2).tolist()}) > 1:
+                            uni = False
+                if not uni:
+                    seen["b_roads"].add("generic"); continue
+                bi = (a0 >= 0) & (a1 >= 0)
+                if not bi.any():
+                    seen["b_roads"].add("list1 only")
+                elif bi.all() and len({tuple(x) for x in mv1[m].reshape(16, 2).tolist()}) == 1 and len(set(a1.tolist())) == 1 and len(set(a0.tolist())) == 1:
+                    seen["b_roads"].add("second pass whole")
+                elif bi.all():
+                    seen["b_roads"].add("second pass quadrants")
+                else:
+                    seen["b_roads"].add("second pass with carried quadrants")
         seen["avail"] |= set(rec["avail"].tolist())
         for m in np.nonzero(inter)[0]:
             v = mv[m]
@@ -103,6 +127,7 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
         assert oracle.oracle_bipred_blocks() > 100, "hardly any bi-predicted block"
         assert seen["dirs"] == {1, 2, 3}, "not every prediction direction (list 0, list 1, both) occurred: %s" % seen["dirs"]
         assert seen["weighted"] == ({1} if kw.get("weighted") else {0, 1}), seen["weighted"]
+        assert seen["b_roads"] >= {"list0 only", "list1 only", "generic", "second pass whole", "second pass quadrants", "second pass with carried quadrants"}, seen["b_roads"]
         assert {N.MB_I4x4, N.MB_I16x16, N.MB_B} <= seen["types"]
     else:
         assert {N.MB_I4x4, N.MB_I16x16, N.MB_P_L0, N.MB_P_8x8, N.MB_P_SKIP} <= seen["types"]

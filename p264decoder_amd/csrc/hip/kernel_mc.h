@@ -141,14 +141,33 @@ __device__ __forceinline__ bool quad_uniform(const uint4 &m0, const uint4 &m1, c
     v = va;
     return va == vb && va == vc && va == vd;
 }
+// what the classification reads of a macroblock (once, whatever the number of passes)
+struct McIn { uint4 rec, m0, m1, m2, m3, n0, n1, n2, n3; uint32_t refs, refs1; bool two_lists; };
 template <bool BPIC>
-__device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int mbi, uint32_t inv_mbw, int band_log2, int pass)
+__device__ __forceinline__ McIn mc_load(const PicDev *pd, int mbi)
+{
+    McIn in;
+    in.rec = gload4(pd->mb + mbi);
+    const int *mvp = pd->mv + mbi * 16;
+    in.m0 = gload4(mvp); in.m1 = gload4(mvp + 4); in.m2 = gload4(mvp + 8); in.m3 = gload4(mvp + 12);
+    in.refs = gload1(pd->ref_idx + mbi * 4);
+    in.refs1 = 0xffffffffu; in.two_lists = false;
+    in.n0 = in.n1 = in.n2 = in.n3 = make_uint4(0, 0, 0, 0);
+    // B pictures: a macroblock that predicts from list 0 only is an ordinary P-type macroblock for this stage
+    if (BPIC && pd->slice_type == P264_SLICE_B && !P264_MB_IS_INTRA(in.rec.x & 255)) {
+        in.refs1 = gload1(pd->ref_idx_l1 + mbi * 4);
+        in.two_lists = ((~in.refs1 | in.refs) & 0x80808080u) != 0;             // some list-1 index >= 0, or some list-0 index < 0
+        if (in.two_lists) { const int *mvp1 = pd->mv_l1 + mbi * 16; in.n0 = gload4(mvp1); in.n1 = gload4(mvp1 + 4); in.n2 = gload4(mvp1 + 8); in.n3 = gload4(mvp1 + 12); }
+    }
+    return in;
+}
+template <bool BPIC>
+__device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, const McIn &in, int mbi, uint32_t inv_mbw, int band_log2, int pass)
 {
     McMb k;
-    const uint4 rec = gload4(pd->mb + mbi);
-    const int *mvp = pd->mv + mbi * 16;
-    uint4 m0 = gload4(mvp), m1 = gload4(mvp + 4), m2 = gload4(mvp + 8), m3 = gload4(mvp + 12);
-    const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
+    const uint4 rec = in.rec;
+    uint4 m0 = in.m0, m1 = in.m1, m2 = in.m2, m3 = in.m3;
+    const uint32_t refs = in.refs;
     k.info = P264_MB_IS_INTRA(rec.x & 255) ? 0u : MCMB_INTER;
 #pragma unroll
     for (int q = 0; q < 4; q++) { k.key[q] = 0; k.vec[q] = 0; }
@@ -159,13 +178,8 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
     const int n_ref = pd->n_ref;
     int ri[4];
     bool zq[4] = { false, false, false, false };           // Z per quadrant
-    // B pictures: a macroblock that predicts from list 0 only is an ordinary P-type macroblock for this stage
-    bool two_lists = false;
-    uint32_t refs1 = 0xffffffffu;
-    if (BPIC && pd->slice_type == P264_SLICE_B && (k.info & MCMB_INTER)) {
-        refs1 = gload1(pd->ref_idx_l1 + mbi * 4);
-        two_lists = ((~refs1 | refs) & 0x80808080u) != 0;                      // some list-1 index >= 0, or some list-0 index < 0
-    }
+    const bool two_lists = in.two_lists;
+    const uint32_t refs1 = in.refs1;
     if (!BPIC || !two_lists) {
         if (pass) { k.info = 0; return k; }
 #pragma unroll
@@ -175,8 +189,7 @@ __device__ __forceinline__ McMb mc_classify(const PicDev *pd, const Geom &g, int
             k.info |= (uint32_t)ri[q] << (8 + 4 * q);
         }
     } else {
-        const int *mvp1 = pd->mv_l1 + mbi * 16;
-        const uint4 n0 = gload4(mvp1), n1 = gload4(mvp1 + 4), n2 = gload4(mvp1 + 8), n3 = gload4(mvp1 + 12);
+        const uint4 n0 = in.n0, n1 = in.n1, n2 = in.n2, n3 = in.n3;
         bool ok = true, any = false;
         uint32_t lq = 0;
 #pragma unroll
@@ -311,70 +324,93 @@ __device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, in
         }
     }
 }
-template <int PASS, bool BPIC>
-__device__ __forceinline__ void mc_sort_pass(const PicDev *pd, uint32_t *out, uint32_t *cnt, uint32_t *pos, const Geom &g, const McLayout &ml, uint32_t inv_mbw)
-{
-    constexpr int L0 = PASS * ML_LISTS;
-    const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
-    const int b_ym = 0, b_yq = nky, b_cm = 2 * nky, b_cq = 2 * nky + nkc, b_end = 2 * nky + 2 * nkc;     // key slots of the four lists
-    const int tid = threadIdx.x;
-    const McSortCtx ctx = { pd, cnt, pos, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[L0 + ML_YM], ml.off_list[L0 + ML_YQ], ml.off_list[L0 + ML_CM], ml.off_list[L0 + ML_CQ], PASS };
-    for (int k = tid; k < b_end; k += MC_SORT_THREADS) cnt[k] = 0;
-    __syncthreads();
-    const bool keep = g.n_mb <= MC_SORT_KEEP * MC_SORT_THREADS;
-    McMb kept[MC_SORT_KEEP];
-    if (keep) {
-#pragma unroll
-        for (int j = 0; j < MC_SORT_KEEP; j++) {
-            const int mbi = tid + j * MC_SORT_THREADS;
-            kept[j].info = 0;
-            if (mbi < g.n_mb) { kept[j] = mc_classify<BPIC>(pd, g, mbi, inv_mbw, (int)ml.band_log2, PASS); mc_count(ctx, kept[j]); }
-        }
-    } else {
-        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_count(ctx, mc_classify<BPIC>(pd, g, mbi, inv_mbw, (int)ml.band_log2, PASS));
-    }
-    __syncthreads();
-    // segment starts: every thread sums the padded counts in front of its key (a few hundred LDS reads at most), notes the
-    // key's class bits for each of its chunks, and the thread of a list's last key writes the number of chunks in use
-    for (int k = tid; k < b_end; k += MC_SORT_THREADS) {
-        const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
-        const int first = l == ML_YM ? b_ym : l == ML_YQ ? b_yq : l == ML_CM ? b_cm : b_cq;
-        const int kk = k - first, nk = l < ML_CM ? nky : nkc;
-        const uint32_t per = (uint32_t)mc_chunk_items(l);
-        uint32_t start = 0;
-        for (int j = 0; j < kk; j++) start += (cnt[first + j] + per - 1) / per;
-        const uint32_t n = (cnt[k] + per - 1) / per;                            // chunks of this key, from chunk `start`
-        pos[k] = start * per;
-        AS1 uint8_t *cls = glob((uint8_t *)(out + (l == ML_YM ? ml.off_cls[L0 + ML_YM] : l == ML_YQ ? ml.off_cls[L0 + ML_YQ] : l == ML_CM ? ml.off_cls[L0 + ML_CM] : ml.off_cls[L0 + ML_CQ])));
-        const uint8_t v = (uint8_t)(kk % mc_list_keys(l));
-        for (uint32_t c = 0; c < n; c++) cls[start + c] = v;
-        if (kk == nk - 1) gstore1(out + L0 + l, start + n);
-    }
-    __syncthreads();
-    if (keep) {
-#pragma unroll
-        for (int j = 0; j < MC_SORT_KEEP; j++) mc_scatter(ctx, kept[j], tid + j * MC_SORT_THREADS, g, inv_mbw);
-    } else {
-        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) mc_scatter(ctx, mc_classify<BPIC>(pd, g, mbi, inv_mbw, (int)ml.band_log2, PASS), mbi, g, inv_mbw);
-    }
-    __syncthreads();
-    for (int k = tid; k < b_end; k += MC_SORT_THREADS) {                      // padding entries behind every segment
-        const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
-        const uint32_t per = (uint32_t)mc_chunk_items(l), end = pos[k];
-        const uint32_t lo = l == ML_YM ? ml.off_list[L0 + ML_YM] : l == ML_YQ ? ml.off_list[L0 + ML_YQ] : l == ML_CM ? ml.off_list[L0 + ML_CM] : ml.off_list[L0 + ML_CQ];
-        for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore4(out + lo + MC_ENTRY_WORDS * p, make_uint4(0xffffffffu, 0, 0, 0));
-    }
-}
+// One picture: P pictures one pass (the classification of up to MC_SORT_KEEP macroblocks per thread stays in registers between
+// counting and scattering: the macroblock arrays are read once); B pictures both passes in one sweep (the arrays are read
+// twice - keeping two classifications of eight macroblocks does not fit the register file).
 template <bool BPIC>
-__device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml, uint32_t inv_mbw, uint32_t *cnt, uint32_t *pos)
+__device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml, uint32_t inv_mbw,
+                                                uint32_t *cnt, uint32_t *pos)
 {
+    constexpr int NP = BPIC ? 2 : 1;
     const PicDev *pd = pics + blockIdx.x;
     uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
     const int tid = threadIdx.x;
     const int n_pass = pd->slice_type == P264_SLICE_I ? 0 : (BPIC && pd->slice_type == P264_SLICE_B) ? 2 : 1;       // wave-uniform
     if (tid < ML_LISTS * 2 && tid >= ML_LISTS * n_pass) gstore1(out + tid, 0);                            // the passes not taken: empty lists
-    if (n_pass > 0) mc_sort_pass<0, BPIC>(pd, out, cnt, pos, g, ml, inv_mbw);
-    if (BPIC && n_pass > 1) { __syncthreads(); mc_sort_pass<1, BPIC>(pd, out, cnt, pos, g, ml, inv_mbw); }
+    if (n_pass == 0) return;
+    const int nky = (int)ml.n_bands * MCY_KEYS, nkc = (int)ml.n_bands * MCC_KEYS;
+    const int b_ym = 0, b_yq = nky, b_cm = 2 * nky, b_cq = 2 * nky + nkc, b_end = 2 * nky + 2 * nkc;     // key slots of the four lists
+    McSortCtx ctx[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++)
+        ctx[ps] = McSortCtx{ pd, cnt + ps * MC_KEY_SLOTS, pos + ps * MC_KEY_SLOTS, out, b_ym, b_yq, b_cm, b_cq, ml.off_list[ps * ML_LISTS + ML_YM], ml.off_list[ps * ML_LISTS + ML_YQ],
+                             ml.off_list[ps * ML_LISTS + ML_CM], ml.off_list[ps * ML_LISTS + ML_CQ], ps };
+    for (int k = tid; k < NP * MC_KEY_SLOTS; k += MC_SORT_THREADS) cnt[k] = 0;
+    __syncthreads();
+    const bool keep = !BPIC && g.n_mb <= MC_SORT_KEEP * MC_SORT_THREADS;
+    McMb kept[BPIC ? 1 : MC_SORT_KEEP];
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < (BPIC ? 1 : MC_SORT_KEEP); j++) {
+            const int mbi = tid + j * MC_SORT_THREADS;
+            kept[j].info = 0;
+            if (mbi < g.n_mb) { kept[j] = mc_classify<BPIC>(pd, g, mc_load<BPIC>(pd, mbi), mbi, inv_mbw, (int)ml.band_log2, 0); mc_count(ctx[0], kept[j]); }
+        }
+    } else {
+        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) {
+            const McIn in = mc_load<BPIC>(pd, mbi);
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) if (ps < n_pass) mc_count(ctx[ps], mc_classify<BPIC>(pd, g, in, mbi, inv_mbw, (int)ml.band_log2, ps));
+        }
+    }
+    __syncthreads();
+    // segment starts: every thread sums the padded counts in front of its key (a few hundred LDS reads at most), notes the
+    // key's class bits for each of its chunks, and the thread of a list's last key writes the number of chunks in use
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        if (ps >= n_pass) break;
+        const uint32_t *cn = cnt + ps * MC_KEY_SLOTS;
+        uint32_t *po = pos + ps * MC_KEY_SLOTS;
+        const int L0 = ps * ML_LISTS;
+        for (int k = tid; k < b_end; k += MC_SORT_THREADS) {
+            const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
+            const int first = l == ML_YM ? b_ym : l == ML_YQ ? b_yq : l == ML_CM ? b_cm : b_cq;
+            const int kk = k - first, nk = l < ML_CM ? nky : nkc;
+            const uint32_t per = (uint32_t)mc_chunk_items(l);
+            uint32_t start = 0;
+            for (int j = 0; j < kk; j++) start += (cn[first + j] + per - 1) / per;
+            const uint32_t n = (cn[k] + per - 1) / per;                         // chunks of this key, from chunk `start`
+            po[k] = start * per;
+            AS1 uint8_t *cls = glob((uint8_t *)(out + (l == ML_YM ? ml.off_cls[L0 + ML_YM] : l == ML_YQ ? ml.off_cls[L0 + ML_YQ] : l == ML_CM ? ml.off_cls[L0 + ML_CM] : ml.off_cls[L0 + ML_CQ])));
+            const uint8_t v = (uint8_t)(kk % mc_list_keys(l));
+            for (uint32_t c = 0; c < n; c++) cls[start + c] = v;
+            if (kk == nk - 1) gstore1(out + L0 + l, start + n);
+        }
+    }
+    __syncthreads();
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < (BPIC ? 1 : MC_SORT_KEEP); j++) mc_scatter(ctx[0], kept[j], tid + j * MC_SORT_THREADS, g, inv_mbw);
+    } else {
+        for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) {
+            const McIn in = mc_load<BPIC>(pd, mbi);
+#pragma unroll
+            for (int ps = 0; ps < NP; ps++) if (ps < n_pass) mc_scatter(ctx[ps], mc_classify<BPIC>(pd, g, in, mbi, inv_mbw, (int)ml.band_log2, ps), mbi, g, inv_mbw);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        if (ps >= n_pass) break;
+        const uint32_t *po = pos + ps * MC_KEY_SLOTS;
+        const int L0 = ps * ML_LISTS;
+        for (int k = tid; k < b_end; k += MC_SORT_THREADS) {                  // padding entries behind every segment
+            const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
+            const uint32_t per = (uint32_t)mc_chunk_items(l), end = po[k];
+            const uint32_t lo = l == ML_YM ? ml.off_list[L0 + ML_YM] : l == ML_YQ ? ml.off_list[L0 + ML_YQ] : l == ML_CM ? ml.off_list[L0 + ML_CM] : ml.off_list[L0 + ML_CQ];
+            for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore4(out + lo + MC_ENTRY_WORDS * p, make_uint4(0xffffffffu, 0, 0, 0));
+        }
+    }
 }
 // batches without B pictures (the two-list classification costs registers the sort of a P picture does not have to pay for)
 __global__ __launch_bounds__(MC_SORT_THREADS)
@@ -387,7 +423,7 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
 __global__ __launch_bounds__(MC_SORT_THREADS)
 void k_mc_sort_b(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
 {
-    __shared__ uint32_t cnt[MC_KEY_SLOTS], pos[MC_KEY_SLOTS];
+    __shared__ uint32_t cnt[2 * MC_KEY_SLOTS], pos[2 * MC_KEY_SLOTS];
     mc_sort_picture<true>(pics, mc_all, g, ml, inv_mbw, cnt, pos);
 }
 

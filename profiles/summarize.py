@@ -26,6 +26,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
+        k = k[5:] if k.startswith("void ") else k              # (template instances: "void k_deblock_bs<false>")
         if k.startswith("k_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # steady state only: the first launch of k_intra / k_deblock* is the IDR picture (all intra), the k_mc_* kernels have none for it

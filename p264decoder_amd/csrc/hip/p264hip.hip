@@ -195,6 +195,7 @@ static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
     if (p->slice_type == P264_SLICE_B) {
         if (p->n_ref < 1 || p->n_ref_l1 < 1 || p->n_ref_l1 > P264HIP_MAX_REFS) return fail(P264HIP_EINVAL, "B picture: list lengths %d / %d", p->n_ref, p->n_ref_l1);
         if (!p->mv_l1 || !p->ref_idx_l1) return fail(P264HIP_EINVAL, "B picture without list-1 arrays");
+        if (p->n_coef_blocks >= (1u << MCE_W_SHIFT)) return fail(P264HIP_EINVAL, "B picture with %u coefficient blocks (limit %u: the second pass packs the weight beside the index)", p->n_coef_blocks, 1u << MCE_W_SHIFT);
         for (int i = 0; i < p->n_ref_l1; i++)
             if (p->ref_slot_l1[i] < 0 || p->ref_slot_l1[i] >= c->slots) return fail(P264HIP_EINVAL, "ref_slot_l1[%d]=%d out of range", i, p->ref_slot_l1[i]);
         if (p->weighted_bipred)

@@ -1,4 +1,4 @@
-// kernel_intra.h - K3: intra macroblock reconstruction (I pictures, and the intra MBs of P pictures).
+// kernel_intra.h - K3: intra macroblock reconstruction (I pictures, and the intra MBs of P / B pictures).
 //
 // Replaces the intra half of p264_macroblock_decode (decoder/macroblock.c:769-831,851-890), the
 // mode fix-ups valid_intra16x16_mode / valid_intra4x4_mode / valid_intra8x8c_mode
@@ -6,29 +6,38 @@
 // p264_mb_dequant_4x4_dc (core/dct.c:104-136, core/quant.c:161-191) and add16x16_idct.
 //
 // Intra prediction reads the UNFILTERED reconstruction of the left / top / top-left / top-right
-// neighbours, so macroblocks form a 2-MB-lag wavefront over the picture (wavefront_sync.h): per
-// picture one workgroup for luma and one for chroma (independent chains: the kernel is bound by the
-// latency of the macroblock-to-macroblock chain per wavefront, so two shorter chains side by side
-// and the registers of only one of them - 70 instead of 92, seven wavefronts per SIMD - beat one
-// long one), one wavefront per macroblock row.  In P pictures the inter MBs were
-// already written by k_mc_luma / k_mc_chroma, so only the sparse intra MBs are visited.  Missing neighbours are
-// substituted in registers (128 / replicated t3) instead of being written into the frame as the
-// reference does (decoder/macroblock.c:697-713, SURVEY A-Q7).
+// neighbours, so macroblocks form a 2-MB-lag wavefront over the picture (wavefront_sync.h).  Per
+// picture one workgroup for luma and one for chroma (independent chains).  A wavefront owns a BAND
+// of four macroblock rows and works on FOUR MACROBLOCKS AT A TIME, sixteen lanes each (group g of
+// the wavefront = row g of the band): the sixteen dependent 4x4 blocks of an Intra4x4 macroblock
+// never had work for more than sixteen lanes, and with one macroblock per wavefront (rounds 1-2)
+// the kernel was bound by the instructions and the memory round trip per macroblock, not by the
+// dependencies.  Every iteration each group takes the next intra macroblock of its row if that
+// macroblock's neighbours are final (the row above is this wavefront's own group g-1, or - for
+// group 0 - the last row of the band above, published through an LDS counter): in an I picture the
+// groups fall into the 2-MB staircase by themselves, in P pictures (sparse intra macroblocks, whose
+// inter neighbours were finished by the motion-compensation kernels) they mostly run independently.
+// A group never waits inside an iteration - the wavefront polls only when NO group can go - so a
+// wavefront cannot block itself.  Missing neighbours are substituted in registers (128 /
+// replicated t3) instead of being written into the frame as the reference does
+// (decoder/macroblock.c:697-713, SURVEY A-Q7).
 #pragma once
 #include <stddef.h>
 #include "device_common.h"
 #include "wavefront_sync.h"
 
 #define IT_STRIDE 24               // luma tile: row -1..15, byte 3 = left column, 4..19 = MB, 20..23 = top-right
-#define CT_STRIDE 12               // chroma tile: byte 3 = left column, 4..11 = MB
+#define CT_STRIDE 12               // chroma tile (one per plane): byte 3 = left column, 4..11 = MB
 
-struct IntraLds {                  // per wavefront
-    uint8_t  y[17 * IT_STRIDE];
-    uint8_t  c[2][9 * CT_STRIDE];
-    int16_t  coef[16 * 16];
+struct IntraGrp {                  // per group of sixteen lanes (= one macroblock in flight)
+    uint8_t  tile[17 * IT_STRIDE]; // luma: the tile above; chroma: two tiles of 9 x CT_STRIDE
+    int16_t  res[16 * 16];         // residual of every 4x4 block (luma: decode order; chroma: plane * 4 + block), raster inside
     int16_t  dc[16];
     uint8_t  edge[16];             // Intra4x4: l3 l3 l2 l1 l0 lt t0..t7 t7 of the current block
+    uint8_t  pad[8];
 };
+struct IntraLds { IntraGrp g[4]; };                        // per wavefront
+static_assert(sizeof(IntraGrp) % 16 == 0, "group areas stay 16-byte aligned");
 
 __device__ __forceinline__ int f3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
 __device__ __forceinline__ int f2(int a, int b) { return (a + b + 1) >> 1; }
@@ -36,14 +45,16 @@ __device__ __forceinline__ int f2(int a, int b) { return (a + b + 1) >> 1; }
 // Intra 4x4 prediction (core/predict.c:366-638) over an EDGE ARRAY: S[0..14] = l3 l3 l2 l1 l0 lt t0 .. t7 t7 (left
 // column bottom-up, corner, top and top-right row; the ends replicated).  Every directional mode is then one of
 //   copy S[c],  (S[c] + S[c+1] + 1) >> 1,  (S[c-1] + 2 S[c] + S[c+1] + 2) >> 2
-// with an index c that is linear in (x,y) per mode - the mode is wave-uniform, so this is a small scalar switch and
-// no per-mode sample code (checked against the per-mode formulas for all modes and positions).
-enum { P4_COPY = 0, P4_F2 = 1, P4_F3 = 2 };
+// with an index c that is linear in (x,y) per mode (checked against the per-mode formulas for all modes and positions).
+// The four macroblocks of a wavefront have four different modes: (c, kind) per (mode, sample) comes out of a 144-byte
+// table in LDS, filled from this function when the kernel starts.
+enum { P4_COPY = 0, P4_F2 = 1, P4_F3 = 2, P4_DC = 3 };
 __device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, int &kind)
 {
     switch (mode) {
     case 0: c = 6 + x; kind = P4_COPY; break;                                                   // vertical
     case 1: c = 4 - y; kind = P4_COPY; break;                                                   // horizontal
+    case 2: c = 1; kind = P4_DC; break;
     case 3: c = 7 + x + y; kind = P4_F3; break;                                                 // diagonal down-left
     case 4: c = 5 + x - y; kind = P4_F3; break;                                                 // diagonal down-right
     case 5: { int z = 2 * x - y;                                                                // vertical-right
@@ -55,332 +66,448 @@ __device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, in
               c = z >= 5 ? 1 : 3 - y - (x >> 1); kind = z > 5 ? P4_COPY : (z == 5 || (z & 1)) ? P4_F3 : P4_F2; break; }
     }
 }
+#define INTRA_LUT_BYTES (9 * 16)
 
-// Reconstruct one intra macroblock with one wavefront.  Every global load the macroblock needs (neighbour samples,
-// prediction modes, coefficients of all three planes) is issued at the top, before anything waits: one memory round
-// trip per macroblock, everything after that runs out of registers and LDS.
-// LUMA / CHROMA: which planes this wavefront reconstructs (k_intra runs the two as separate workgroups of a picture)
-template <bool LUMA, bool CHROMA>
-__device__ void intra_mb(const PicDev *pd, const Geom &g, IntraLds &L, int mbi, const p264hip_mb_t m, int lane, RowSync &sync, int row_publish_as)
+// sum over the sixteen lanes of a group / over aligned groups of 2^k lanes (xor butterflies stay inside the group)
+__device__ __forceinline__ int sum_lanes(int v, int n)
 {
-    // Everything below that depends on the lane number alone (roles, tile offsets, scan positions) would otherwise be
-    // hoisted out of the caller's macroblock loop and kept - or spilled - across it: recomputing it per macroblock is a few
-    // dozen instructions, holding it is ~50 registers.
-    asm volatile("" : "+v"(lane));
-    const int mbx = mbi % g.mb_w, mby = mbi / g.mb_w, X0 = mbx * 16, Y0 = mby * 16;
-    const bool aL = m.avail & P264_AVAIL_LEFT, aT = m.avail & P264_AVAIL_TOP;
-    const bool aTR = m.avail & P264_AVAIL_TOPRIGHT, aTL = m.avail & P264_AVAIL_TOPLEFT;
+    for (int m = 1; m < n; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int byte_sum(uint32_t v) { return (int)__builtin_amdgcn_sad_u8(v, 0u, 0u); }
+
+// add4x4_idct (core/dct.c:205-247) without the prediction: r[y][0] = (d[y][0], d[y][1]), r[y][1] = (d[y][2], d[y][3]) as the
+// reference's int16 d[][] = (sum + 32) >> 6; first pass in packed 16-bit (its int16 tmp), second pass in 32-bit
+__device__ __forceinline__ void idct_res(const uint32_t (&col)[4][2], uint32_t (&r)[4][2])
+{
+    s16x2 T[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const s16x2 c0 = as_s16x2(col[0][j]), c1 = as_s16x2(col[1][j]), c2 = as_s16x2(col[2][j]), c3 = as_s16x2(col[3][j]);
+        const s16x2 s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
+        T[0][j] = s02 + s13; T[1][j] = d02 + d13; T[2][j] = d02 - d13; T[3][j] = s02 - s13;
+    }
+    int res[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int a0 = T[x][0].x, a1 = T[x][0].y, a2 = T[x][1].x, a3 = T[x][1].y;
+        const int s02 = a0 + a2 + 32, d02 = a0 - a2 + 32, s13 = a1 + (a3 >> 1), d13 = (a1 >> 1) - a3;
+        res[0][x] = (s02 + s13) >> 6; res[1][x] = (d02 + d13) >> 6; res[2][x] = (d02 - d13) >> 6; res[3][x] = (s02 - s13) >> 6;
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        r[y][0] = ((uint32_t)res[y][0] & 0xffffu) | (uint32_t)res[y][1] << 16;
+        r[y][1] = ((uint32_t)res[y][2] & 0xffffu) | (uint32_t)res[y][3] << 16;
+    }
+}
+// four samples + four int16 residuals, clipped to bytes
+__device__ __forceinline__ uint32_t add_res4(uint32_t px, uint32_t r01, uint32_t r23)
+{
+    const s16x2 zero = { 0, 0 }, top = { 255, 255 };
+    // (saturating: a residual near the int16 limits must not wrap - the reference adds in int)
+    s16x2 lo = __builtin_elementwise_add_sat(as_s16x2(perm(0u, px, 0x0c010c00u)), as_s16x2(r01)), hi = __builtin_elementwise_add_sat(as_s16x2(perm(0u, px, 0x0c030c02u)), as_s16x2(r23));
+    lo = __builtin_elementwise_min(__builtin_elementwise_max(lo, zero), top);
+    hi = __builtin_elementwise_min(__builtin_elementwise_max(hi, zero), top);
+    return perm(as_u32(hi), as_u32(lo), 0x06040200u);
+}
+
+// ------------------------------------------------------------------------------------------
+// luma of one intra macroblock per group of sixteen lanes (l = lane inside the group).  Every global load the macroblock
+// needs is issued at the top, before anything waits: one memory round trip per iteration, everything after that runs out
+// of registers and LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, IntraGrp &L, const uint8_t *lut, int mbx, int mby, const uint4 rec, int l)
+{
+    // Everything below that depends on the lane number alone (roles, tile offsets, edge slots) would otherwise be hoisted
+    // out of the caller's loops and kept - or spilled - across them: recomputing it per macroblock is a few dozen
+    // instructions, holding it is dozens of registers.
+    asm volatile("" : "+v"(l));
+    const int mbi = mby * g.mb_w + mbx, X0 = mbx * 16, Y0 = mby * 16;
+    const int mb_type = (int)(rec.x & 255u), qp = (int)((rec.x >> 8) & 255u), modes = (int)(rec.x >> 24), avail = (int)(rec.w & 255u);
+    const bool aL = avail & P264_AVAIL_LEFT, aT = avail & P264_AVAIL_TOP, aTR = avail & P264_AVAIL_TOPRIGHT, aTL = avail & P264_AVAIL_TOPLEFT;
     uint8_t *F = pd->dst;                                  // strip frame layout (device_common.h)
     const AS1 uint8_t *Fg = glob(F);
-    const unsigned mask = m.coef_mask;
-    const AS1 int16_t *cf = glob(pd->coefs) + (size_t)m.coef_index * 16;
-    const bool is16 = m.mb_type == P264_MB_I16x16;
+    const unsigned mask = rec.y;
+    const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+    const bool is16 = mb_type == P264_MB_I16x16;
 
-    // ---- (a) neighbour samples; 128 where the neighbour does not exist.  Role A: lanes 0..20 top row (corner, 16 top,
-    //      4 top-right), 21..36 left column, 37..54 chroma top rows (corner + 8) of both planes; role B: lanes 0..15
-    //      chroma left columns ----
-    uint32_t offA = 0, offB = 0; bool okA = false, okB = false;
-    uint8_t *const lds8 = (uint8_t *)&L;                   // byte offsets, so that the stores stay LDS stores
-    const int c_base = (int)offsetof(IntraLds, c), c_size = (int)sizeof(L.c[0]);
-    int dstA = 0, dstB = 0;
-    if (!LUMA && lane < 37) {
-    } else if (lane < 21) {
-        int x = lane - 1;
-        okA = x < 0 ? aTL : x < 16 ? aT : aTR;
-        offA = luma_off(g, X0 + x, Y0 - 1); dstA = 3 + lane;
-    } else if (lane < 37) {
-        int r = lane - 21;
-        okA = aL; offA = luma_off(g, X0 - 1, Y0 + r); dstA = (r + 1) * IT_STRIDE + 3;
-    } else if (CHROMA && lane < 55) {
-        int p = (lane - 37) / 9, x = (lane - 37) % 9 - 1;
-        okA = x < 0 ? aTL : aT;
-        offA = chroma_off(g, p, X0 / 2 + x, Y0 / 2 - 1); dstA = c_base + p * c_size + 3 + x + 1;
-    }
-    if (CHROMA && lane < 16) {
-        int p = lane >> 3, r = lane & 7;
-        okB = aL; offB = chroma_off(g, p, X0 / 2 - 1, Y0 / 2 + r); dstB = c_base + p * c_size + (r + 1) * CT_STRIDE + 3;
-    }
-    int vA = 128, vB = 128;
-    if (okA) vA = Fg[offA];
-    if (okB) vB = Fg[offB];
-    // ---- (b) luma levels: lane = (block lane>>2 in decode order, levels 4*(lane&3) .. +3 of its 16 slots) ----
-    const int lb = lane >> 2;
-    uint2 lv = make_uint2(0, 0);
-    if (LUMA && ((mask >> lb) & 1)) lv = gload2(cf + coef_slot(mask, lb) * 16 + (lane & 3) * 4);
-    int ldc = 0;                                           // Intra16x16 DC levels, lanes 0..15
-    if (LUMA && is16 && (mask & P264_COEF_LUMA_DC) && lane < 16) ldc = cf[lane];
-    // ---- (c) Intra4x4 prediction modes, lanes 0..15 ----
+    // ---- (a) neighbour samples, 128 where the neighbour does not exist: lane l the left sample of row l; lanes 0..3 the
+    //      four dwords of the row above, lane 4 the top-right dword, lane 5 the corner ----
+    int vL = 128;
+    if (aL) vL = Fg[luma_off(g, X0 - 1, Y0 + l)];
+    uint32_t vT = 0x80808080u;
+    if (l < 4)       { if (aT)  vT = gload1(F + luma_off(g, X0 + 4 * l, Y0 - 1)); }
+    else if (l == 4) { if (aTR) vT = gload1(F + luma_off(g, X0 + 16, Y0 - 1)); }
+    else if (l == 5) { if (aTL) vT = Fg[luma_off(g, X0 - 1, Y0 - 1)]; }
+    // ---- (b) levels: lane l = block l (decode order), all 16 slots of it ----
+    const bool coded = (mask >> l) & 1;
+    uint4 la = make_uint4(0, 0, 0, 0), lb = la;
+    if (coded) { const int16_t *c = cf + coef_slot(mask, l) * 16; la = gload4(c); lb = gload4(c + 8); }
+    const bool dcflag = is16 && (mask & P264_COEF_LUMA_DC);
+    int ldc = 0;                                           // Intra16x16 DC level l (scan order)
+    if (dcflag) ldc = glob(cf)[l];
+    // ---- (c) Intra4x4 prediction mode of block l ----
     int modebyte = 0;
-    if (LUMA && !is16) modebyte = glob(pd->i4modes)[mbi * 16 + (lane & 15)];
-    // ---- (d) chroma: AC level k-1 of block j = lane>>4 of each plane (k = lane&15), DC levels in lanes 0..7 ----
-    const bool has_chroma = CHROMA && (m.cbp >> 4) != 0;
-    int cac[2] = { 0, 0 }, cdcv = 0;
-    if (has_chroma) {
-        const int j = lane >> 4, k = lane & 15;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int blk = 16 + 4 * p + j;
-            if (k > 0 && ((mask >> blk) & 1)) cac[p] = cf[coef_slot(mask, blk) * 16 + k - 1];
-        }
-        if ((mask & P264_COEF_CHROMA_DC) && lane < 8) cdcv = cf[((mask >> 24) & 1) * 16 + lane];
-    }
+    if (!is16) modebyte = glob(pd->i4modes)[mbi * 16 + l];
 
-    // Everything left of this macroblock is final once the stores of the previous one have landed: publishing here, where
-    // the wave has to wait for its loads anyway, keeps the store latency off the macroblock-to-macroblock path.
-    row_publish(sync, mby, row_publish_as);
     // ---- land the neighbours ----
-    if (LUMA ? lane < (CHROMA ? 55 : 37) : (lane >= 37 && lane < 55)) lds8[dstA] = (uint8_t)vA;
-    if (CHROMA && lane < 16) lds8[dstB] = (uint8_t)vB;
+    L.tile[(l + 1) * IT_STRIDE + 3] = (uint8_t)vL;
+    if (l < 5) *(uint32_t *)(L.tile + 4 + 4 * l) = vT;
+    else if (l == 5) L.tile[3] = (uint8_t)vT;
     wave_lds_fence();
-    if (LUMA && !aTR && lane < 4) L.y[20 + lane] = L.y[19];  // top-right of the MB missing: replicate t15 (:706-709)
+    if (!aTR && l == 4) *(uint32_t *)(L.tile + 20) = (uint32_t)L.tile[19] * 0x01010101u;   // top-right of the MB missing: replicate t15 (:706-709)
     wave_lds_fence();
 
-    if (!LUMA) {
-    } else if (is16) {
-        // ---- prediction: each lane 4 samples of one row ----
-        int mode = m.intra_modes & 3;
-        if (mode == 2) mode = aTL ? 2 : aL ? 4 : aT ? 5 : 6;                    // :635-667
-        const int row = lane >> 2, c0 = (lane & 3) * 4;
-        const uint8_t *top = L.y + 4, *tile = L.y + IT_STRIDE;
-        int pv[4];
-        if (mode == 0)      { for (int i = 0; i < 4; i++) pv[i] = top[c0 + i]; }
-        else if (mode == 1) { int v = tile[row * IT_STRIDE + 3]; for (int i = 0; i < 4; i++) pv[i] = v; }
-        else if (mode == 3) {                                                     // plane, core/predict.c:159-193
-            int H = 0, Vv = 0;
-            for (int i = 0; i <= 7; i++) {
-                H  += (i + 1) * (top[8 + i] - top[6 - i]);                       // top[-1] is the corner
-                Vv += (i + 1) * (tile[(8 + i) * IT_STRIDE + 3] - L.y[(7 - i) * IT_STRIDE + 3]);
-            }
-            int a = 16 * (tile[15 * IT_STRIDE + 3] + top[15]), b = (5 * H + 32) >> 6, c = (5 * Vv + 32) >> 6;
-            int i00 = a - 7 * b - 7 * c + 16 + c * row;
-            for (int i = 0; i < 4; i++) pv[i] = clip255((i00 + b * (c0 + i)) >> 5);
-        } else {
-            int s = 0;
-            if (mode == 2)      { for (int i = 0; i < 16; i++) s += top[i] + tile[i * IT_STRIDE + 3]; s = (s + 16) >> 5; }
-            else if (mode == 4) { for (int i = 0; i < 16; i++) s += tile[i * IT_STRIDE + 3]; s = (s + 8) >> 4; }
-            else if (mode == 5) { for (int i = 0; i < 16; i++) s += top[i]; s = (s + 8) >> 4; }
-            else s = 128;
-            for (int i = 0; i < 4; i++) pv[i] = s;
-        }
-        // ---- luma DC: unscan, idct4x4dc (core/dct.c:104-136), rounded dequant (core/quant.c:161-191) ----
-        if (lane < 16) L.dc[c_zigzag[lane]] = (int16_t)ldc;
-        wave_lds_fence();
+    // ---- residuals of all sixteen blocks into LDS (lane = block) ----
+    const bool grp_res = (mask & 0xffffu) != 0 || dcflag;  // (the same for the sixteen lanes)
+    if (__ballot(grp_res)) {
         int dcv = 0;
-        if (lane < 16) {
-            int i = lane >> 2, j = lane & 3, tcol[4];
-            for (int c = 0; c < 4; c++) {                                       // column pass for tmp[i][c]
-                int d0 = L.dc[c], d1 = L.dc[4 + c], d2 = L.dc[8 + c], d3 = L.dc[12 + c];
-                int s01 = d0 + d1, d01 = d0 - d1, s23 = d2 + d3, d23 = d2 - d3;
-                int v = pick_addsub(s01, d01, s23, d23, i >= 2, i == 1 || i == 2);   // {s01+s23, s01-s23, d01-d23, d01+d23}[i]
-                tcol[c] = (int)(int16_t)v;
-            }
-            int s01 = tcol[0] + tcol[1], d01 = tcol[0] - tcol[1], s23 = tcol[2] + tcol[3], d23 = tcol[2] - tcol[3];
-            int v = pick_addsub(s01, d01, s23, d23, j >= 2, j == 1 || j == 2);
-            v = (int)(int16_t)v;
-            int qbits = m.qp / 6 - 6, mf = dq_scale(0, m.qp % 6);
-            v = qbits >= 0 ? v * (int)((unsigned)mf << qbits) : (v * mf + (1 << (-qbits - 1))) >> (-qbits);
-            dcv = (int)(int16_t)v;
-        }
-        wave_lds_fence();
-        if (lane < 16) L.dc[lane] = (int16_t)dcv;                                // raster (y*4+x) of the 4x4 block grid
-        wave_lds_fence();
-        // ---- AC: scan position k of the block holds level k-1 (the slots hold 15 AC levels), DC goes to position 0
-        // (:787-794).  This lane fetched levels 4q..4q+3 (q = lane&3); level 4q-1 comes from the lane before. ----
-        {
-            const int e3 = (int)(int16_t)(lv.y >> 16);
-            const int prev = __shfl_up(e3, 1);
-            const int lev[4] = { prev, (int)(int16_t)(lv.x & 0xffff), (int)(int16_t)(lv.x >> 16), (int)(int16_t)(lv.y & 0xffff) };
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
-                int v = k == 0 ? L.dc[blk_y(lb) * 4 + blk_x(lb)] : dequant_coef(lev[kk], pos, m.qp);
-                L.coef[lb * 16 + pos] = (int16_t)v;
-            }
-        }
-        wave_lds_fence();
-        {
-            int b = blk_at(lane & 3, row >> 2), yy = row & 3;
-            idct4x4_rowpass(L.coef + b * 16, yy);                                // horizontal pass of this lane's row, in place
+        if (__ballot(dcflag)) {
+            // luma DC: unscan, idct4x4dc (core/dct.c:104-136), rounded dequant (core/quant.c:161-191)
+            if (dcflag) L.dc[zigzag_pos(l)] = (int16_t)ldc;
             wave_lds_fence();
-            for (int i = 0; i < 4; i++)
-                L.y[(row + 1) * IT_STRIDE + 4 + c0 + i] = (uint8_t)clip255(pv[i] + idct4x4_col_sample(L.coef + b * 16, i, yy));
-        }
-        wave_lds_fence();
-    } else {
-        // ---- I4x4: sixteen dependent blocks, 16 lanes each (decoder/macroblock.c:799-831); all coded blocks are
-        // unscanned + dequantised into LDS first ----
-        {
-            const int lev[4] = { (int)(int16_t)(lv.x & 0xffff), (int)(int16_t)(lv.x >> 16), (int)(int16_t)(lv.y & 0xffff), (int)(int16_t)(lv.y >> 16) };
+            int v = 0;
+            if (dcflag) {
+                const int i = l >> 2, j = l & 3;
+                int tcol[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                int k = (lane & 3) * 4 + kk, pos = c_zigzag[k];
-                L.coef[lb * 16 + pos] = (int16_t)dequant_coef(lev[kk], pos, m.qp);
-            }
-        }
-        wave_lds_fence();
-        idct4x4_rowpass(L.coef + lb * 16, lane & 3);                              // horizontal pass of all 16 blocks: lane = (block, row)
-        wave_lds_fence();
-        const int x = lane & 3, y = (lane >> 2) & 3;
-        // the lane's slot of the edge array: offset from the block origin inside the tile and the neighbour it belongs to
-        // (0 left, 1 top-left, 2 top, 3 top-right)
-        const int es = min(lane, 14);
-        const int eoff = es <= 4 ? (es == 0 ? 3 : 4 - es) * IT_STRIDE - 1 : es == 5 ? -IT_STRIDE - 1 : -IT_STRIDE + min(es - 6, 7);
-        const int eflag = es <= 4 ? 0 : es == 5 ? 1 : es <= 9 ? 2 : 3;
-        // which of the 16 blocks (decode order) have their left / top / top-left / top-right neighbour: one bit per block,
-        // from the macroblock's availability (inside the MB: fixed pattern, top-right per core/macroblock.c:1210-1231)
-        const unsigned left_m = 0xFAFAu | (aL ? 0x0505u : 0u), top_m = 0xFFCCu | (aT ? 0x0033u : 0u);
-        const unsigned tl_m = 0xFAC8u | (aT ? 0x0032u : 0u) | (aL ? 0x0504u : 0u) | (aTL ? 0x0001u : 0u);
-        const unsigned tr_m = 0x5744u | (aT ? 0x0013u : 0u) | (aTR ? 0x0020u : 0u);
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int bx = blk_x(i), by = blk_y(i);
-            const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1, topleft = (tl_m >> i) & 1, topright = (tr_m >> i) & 1;
-            int mode = __builtin_amdgcn_readlane(modebyte, i);
-            const uint8_t *o = L.y + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
-            // ---- edge array, missing neighbours substituted (decoder/macroblock.c:697-713): 128, or t3 for the top-right ----
-            {
-                const unsigned avail = (unsigned)left | (unsigned)topleft << 1 | (unsigned)top << 2 | (unsigned)topright << 3;
-                const int own = o[eoff], t3 = o[-IT_STRIDE + 3];
-                const int alt = (eflag == 3 && top) ? t3 : 128;
-                if (lane < 15) L.edge[lane] = (uint8_t)(((avail >> eflag) & 1) ? own : alt);
-            }
-            wave_lds_fence();
-            int v;
-            if (mode == 2) {                                                           // DC and its fall-backs, :677-695
-                const uint8_t *S = L.edge;
-                const int sl = S[1] + S[2] + S[3] + S[4], st = S[6] + S[7] + S[8] + S[9];
-                v = (left && top) ? (sl + st + 4) >> 3 : left ? (sl + 2) >> 2 : top ? (st + 2) >> 2 : 128;
-            } else {
-                int c, kind;
-                pred4x4_where(mode, x, y, c, kind);
-                const int a = L.edge[c - 1], b = L.edge[c], d = L.edge[c + 1];
-                v = kind == P4_COPY ? b : kind == P4_F2 ? (b + d + 1) >> 1 : (a + 2 * b + d + 2) >> 2;
-            }
-            if ((mask >> i) & 1) v = clip255(v + idct4x4_col_sample(L.coef + i * 16, x, y));
-            if (lane < 16) L.y[(by * 4 + y + 1) * IT_STRIDE + 4 + bx * 4 + x] = (uint8_t)v;
-            wave_lds_fence();
-        }
-    }
-
-    // ---- chroma prediction (core/predict.c:199-361), one sample per lane and plane ----
-    if (CHROMA) {
-        int mode = (m.intra_modes >> 4) & 3;
-        if (mode == 0) mode = aTL ? 0 : aL ? 4 : aT ? 5 : 6;                     // :721-753
-        const int px = lane & 7, py = lane >> 3;
-        const int qpc = chroma_qp(clip3i(m.qp + pd->chroma_qp_offset, 0, 51));
-        const int j = lane >> 4, k = lane & 15, pos = c_zigzag[k];
-        for (int p = 0; p < 2; p++) {
-            const uint8_t *top = L.c[p] + 4, *tile = L.c[p] + CT_STRIDE;
-            int v;
-            if (mode == 1) v = tile[py * CT_STRIDE + 3];
-            else if (mode == 2) v = top[px];
-            else if (mode == 3) {
-                int H = 0, Vv = 0;
-                for (int i = 0; i < 4; i++) {
-                    H  += (i + 1) * (top[4 + i] - top[2 - i]);
-                    Vv += (i + 1) * (tile[(4 + i) * CT_STRIDE + 3] - L.c[p][(3 - i) * CT_STRIDE + 3]);
+                for (int c = 0; c < 4; c++) {                                   // column pass for tmp[i][c]
+                    const int d0 = L.dc[c], d1 = L.dc[4 + c], d2 = L.dc[8 + c], d3 = L.dc[12 + c];
+                    const int s01 = d0 + d1, d01 = d0 - d1, s23 = d2 + d3, d23 = d2 - d3;
+                    tcol[c] = (int)(int16_t)pick_addsub(s01, d01, s23, d23, i >= 2, i == 1 || i == 2);   // {s01+s23, s01-s23, d01-d23, d01+d23}[i]
                 }
-                int a = 16 * (tile[7 * CT_STRIDE + 3] + top[7]), b = (17 * H + 16) >> 5, c = (17 * Vv + 16) >> 5;
-                v = clip255((a - 3 * b - 3 * c + 16 + c * py + b * px) >> 5);
-            } else {
-                int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                for (int i = 0; i < 4; i++) { s0 += top[i]; s1 += top[4 + i]; s2 += tile[i * CT_STRIDE + 3]; s3 += tile[(4 + i) * CT_STRIDE + 3]; }
-                int qd = ((py >> 2) << 1) | (px >> 2);
-                if (mode == 0)      v = qd == 0 ? (s0 + s2 + 4) >> 3 : qd == 1 ? (s1 + 2) >> 2 : qd == 2 ? (s3 + 2) >> 2 : (s1 + s3 + 4) >> 3;
-                else if (mode == 4) v = (qd < 2 ? s2 + 2 : s3 + 2) >> 2;
-                else if (mode == 5) v = ((qd & 1) ? s1 + 2 : s0 + 2) >> 2;
-                else v = 128;
-            }
-            if (has_chroma) {                                                     // residual, same arithmetic as kernel_mc.h
-                // the four DC levels of plane p sit in lanes 4p .. 4p+3 (all shuffles before any use)
-                const int d0 = __shfl(cdcv, p * 4), d1 = __shfl(cdcv, p * 4 + 1), d2 = __shfl(cdcv, p * 4 + 2), d3 = __shfl(cdcv, p * 4 + 3);
-                int cv;
-                if (k == 0) {
-                    int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
-                    int f = pick_addsub(t0, t1, t2, t3, j & 1, j & 2);            // {t0+t2, t1+t3, t0-t2, t1-t3}[j]
-                    f = (int)(int16_t)f;
-                    int qbits = qpc / 6 - 5, mf = dq_scale(0, qpc % 6);
-                    cv = qbits >= 0 ? f * (int)((unsigned)mf << qbits) : (f * mf) >> (-qbits);
-                    cv = (int)(int16_t)cv;
-                } else cv = dequant_coef(cac[p], pos, qpc);
-                L.coef[j * 16 + pos] = (int16_t)cv;
-                wave_lds_fence();
-                if (lane < 16) idct4x4_rowpass(L.coef + (lane >> 2) * 16, lane & 3);     // 4 blocks x 4 rows
-                wave_lds_fence();
-                int jj = ((py >> 2) << 1) | (px >> 2);
-                v = clip255(v + idct4x4_col_sample(L.coef + jj * 16, px & 3, py & 3));
+                const int s01 = tcol[0] + tcol[1], d01 = tcol[0] - tcol[1], s23 = tcol[2] + tcol[3], d23 = tcol[2] - tcol[3];
+                v = (int)(int16_t)pick_addsub(s01, d01, s23, d23, j >= 2, j == 1 || j == 2);
+                const int per = (qp * 43) >> 8, rem = qp - per * 6, qbits = per - 6, mf = dq_scale(0, rem);
+                v = qbits >= 0 ? v * (int)((unsigned)mf << qbits) : (v * mf + (1 << (-qbits - 1))) >> (-qbits);
+                v = (int)(int16_t)v;
             }
             wave_lds_fence();
-            L.c[p][(py + 1) * CT_STRIDE + 4 + px] = (uint8_t)v;
+            if (dcflag) L.dc[l] = (int16_t)v;                                   // raster (y*4+x) of the 4x4 block grid
             wave_lds_fence();
+            if (dcflag) dcv = L.dc[blk_y(l) * 4 + blk_x(l)];
         }
+        const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
+        uint32_t c4[4][2], c16[4][2], col[4][2], r[4][2];
+        unscan_cols<false>(lv, c4);                        // Intra4x4: 16 levels
+        unscan_cols<true>(lv, c16);                        // Intra16x16: 15 AC levels at scan positions 1..15 (:787-794)
+#pragma unroll
+        for (int x = 0; x < 4; x++) { col[x][0] = is16 ? c16[x][0] : c4[x][0]; col[x][1] = is16 ? c16[x][1] : c4[x][1]; }
+        dequant_cols(col, qp);
+        if (is16) col[0][0] = (col[0][0] & 0xffff0000u) | ((uint32_t)dcv & 0xffffu);
+        idct_res(col, r);
+        const bool mine = coded || dcflag;
+        uint4 *out = (uint4 *)(L.res + l * 16);
+        out[0] = mine ? make_uint4(r[0][0], r[0][1], r[1][0], r[1][1]) : make_uint4(0, 0, 0, 0);
+        out[1] = mine ? make_uint4(r[2][0], r[2][1], r[3][0], r[3][1]) : make_uint4(0, 0, 0, 0);
+        wave_lds_fence();
     }
 
-    // ---- write the macroblock out ----
-    {
-        int row = lane >> 2, d = lane & 3;
-        // lane (row, d) owns dword `lane` of the macroblock's 256 contiguous luma bytes, lane (p, r, dd) a dword of its
-        // 128 chroma bytes (rows of 8 bytes U + 8 bytes V)
-        if (LUMA) gstore1(F + mb_luma_off(g, mbx, mby) + lane * 4, *(const uint32_t *)(L.y + (row + 1) * IT_STRIDE + 4 + d * 4));
-        if (CHROMA && lane < 32) {
-            int p = lane >> 4, r = (lane >> 1) & 7, dd = lane & 1;
-            gstore1(F + mb_chroma_off(g, mbx, mby) + r * 16 + p * 8 + dd * 4, *(const uint32_t *)(L.c[p] + (r + 1) * CT_STRIDE + 4 + dd * 4));
+    if (__ballot(is16)) {
+        if (is16) {
+            // ---- Intra16x16 (core/predict.c:55-193): lane l = row l ----
+            int mode = modes & 3;
+            if (mode == 2) mode = aTL ? 2 : aL ? 4 : aT ? 5 : 6;                // :635-667
+            const uint32_t *trow = (const uint32_t *)(L.tile + 4);
+            const uint32_t t0 = trow[0], t1 = trow[1], t2 = trow[2], t3 = trow[3];
+            uint32_t pv[4];
+            const int sumT = byte_sum(t0) + byte_sum(t1) + byte_sum(t2) + byte_sum(t3), sumL = sum_lanes(vL, 16);
+            const int dc = mode == 2 ? (sumT + sumL + 16) >> 5 : mode == 4 ? (sumL + 8) >> 4 : mode == 5 ? (sumT + 8) >> 4 : 128;
+            const uint32_t flat = (uint32_t)(mode == 1 ? vL : dc) * 0x01010101u;
+            pv[0] = mode == 0 ? t0 : flat; pv[1] = mode == 0 ? t1 : flat; pv[2] = mode == 0 ? t2 : flat; pv[3] = mode == 0 ? t3 : flat;
+            if (__ballot(mode == 3)) {                                           // plane, core/predict.c:159-193
+                // H = sum (i+1) (top[8+i] - top[6-i]) = sum over x = -1..15 of (x - 7) top[x]; the same down the left column
+                const int corner = L.tile[3], topl = L.tile[4 + l];
+                const int H = sum_lanes((l - 7) * topl, 16) - 8 * corner, V = sum_lanes((l - 7) * vL, 16) - 8 * corner;
+                const int a = 16 * (__shfl(vL, (int)(threadIdx.x & 48) + 15) + (int)L.tile[19]), b = (5 * H + 32) >> 6, c = (5 * V + 32) >> 6;
+                const int i00 = a - 7 * b - 7 * c + 16 + c * l;
+                if (mode == 3) {
+                    // (round_pack4: written as clip255(v >> 5) | ... << 8 | ... the compiler picks v_ashr_pk_u8_i32 itself and ORs the
+                    // other bytes onto its result, whose upper half is not zero for negative inputs)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int t[4] = { i00 + b * (4 * k), i00 + b * (4 * k + 1), i00 + b * (4 * k + 2), i00 + b * (4 * k + 3) };
+                        pv[k] = round_pack4<5>(t);
+                    }
+                }
+            }
+            if (grp_res) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint2 rr = *(const uint2 *)(L.res + blk_at(k, l >> 2) * 16 + (l & 3) * 4);
+                    pv[k] = add_res4(pv[k], rr.x, rr.y);
+                }
+            }
+            gstore4(F + mb_luma_off(g, mbx, mby) + l * 16, make_uint4(pv[0], pv[1], pv[2], pv[3]));
         }
     }
+    if (__ballot(!is16)) {
+        if (!is16) {
+            // ---- Intra4x4: sixteen dependent blocks (decoder/macroblock.c:799-831), lane l = sample (x, y) of the current block ----
+            const int x = l & 3, y = l >> 2;
+            // the lane's slot of the edge array: offset from the block origin inside the tile and the neighbour it belongs to
+            // (0 left, 1 top-left, 2 top, 3 top-right)
+            const int es = min(l, 14);
+            const int eoff = es <= 4 ? (es == 0 ? 3 : 4 - es) * IT_STRIDE - 1 : es == 5 ? -IT_STRIDE - 1 : -IT_STRIDE + min(es - 6, 7);
+            const int eflag = es <= 4 ? 0 : es == 5 ? 1 : es <= 9 ? 2 : 3;
+            // which of the 16 blocks (decode order) have their left / top / top-left / top-right neighbour: one bit per block,
+            // from the macroblock's availability (inside the MB: fixed pattern, top-right per core/macroblock.c:1210-1231)
+            const unsigned left_m = 0xFAFAu | (aL ? 0x0505u : 0u), top_m = 0xFFCCu | (aT ? 0x0033u : 0u);
+            const unsigned tl_m = 0xFAC8u | (aT ? 0x0032u : 0u) | (aL ? 0x0504u : 0u) | (aTL ? 0x0001u : 0u);
+            const unsigned tr_m = 0x5744u | (aT ? 0x0013u : 0u) | (aTR ? 0x0020u : 0u);
+            const int grp_base = (int)(threadIdx.x & 48);
+#pragma unroll 1
+            for (int i = 0; i < 16; i++) {
+                const int bx = blk_x(i), by = blk_y(i);
+                const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1, topleft = (tl_m >> i) & 1, topright = (tr_m >> i) & 1;
+                const int mode = __shfl(modebyte, grp_base + i);
+                const uint8_t *o = L.tile + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;     // block origin inside the tile
+                // ---- edge array, missing neighbours substituted (decoder/macroblock.c:697-713): 128, or t3 for the top-right ----
+                {
+                    const unsigned av = (unsigned)left | (unsigned)topleft << 1 | (unsigned)top << 2 | (unsigned)topright << 3;
+                    const int own = o[eoff], t3 = o[-IT_STRIDE + 3];
+                    const int alt = (eflag == 3 && top) ? t3 : 128;
+                    if (l < 15) L.edge[l] = (uint8_t)(((av >> eflag) & 1) ? own : alt);
+                }
+                const int wk = lut[min(mode, 8) * 16 + l], c = wk & 15, kind = wk >> 4;
+                wave_lds_fence();
+                const int a = L.edge[c - 1], b = L.edge[c], d = L.edge[c + 1];
+                int v = kind == P4_COPY ? b : kind == P4_F2 ? (b + d + 1) >> 1 : (a + 2 * b + d + 2) >> 2;
+                if (__ballot(kind == P4_DC)) {                                          // DC and its fall-backs, :677-695
+                    const uint8_t *S = L.edge;
+                    const int sl = S[1] + S[2] + S[3] + S[4], st = S[6] + S[7] + S[8] + S[9];
+                    const int dcv = (left && top) ? (sl + st + 4) >> 3 : left ? (sl + 2) >> 2 : top ? (st + 2) >> 2 : 128;
+                    v = kind == P4_DC ? dcv : v;
+                }
+                if ((mask >> i) & 1) v = clip255(v + (int)L.res[i * 16 + l]);
+                L.tile[(by * 4 + y + 1) * IT_STRIDE + 4 + bx * 4 + x] = (uint8_t)v;
+                wave_lds_fence();
+            }
+            const uint32_t *row = (const uint32_t *)(L.tile + (l + 1) * IT_STRIDE + 4);
+            gstore4(F + mb_luma_off(g, mbx, mby) + l * 16, make_uint4(row[0], row[1], row[2], row[3]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// chroma of one intra macroblock per group of sixteen lanes: lane l = row r = l & 7 of plane p = l >> 3
+// (core/predict.c:199-361, decoder/macroblock.c:721-753,851-890)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void intra_chroma4(const PicDev *pd, const Geom &g, IntraGrp &L, int mbx, int mby, const uint4 rec, int l)
+{
+    asm volatile("" : "+v"(l));                            // (as in intra_luma4)
+    const int X0 = mbx * 8, Y0 = mby * 8;
+    const int qp = (int)((rec.x >> 8) & 255u), cbp = (int)((rec.x >> 16) & 255u), modes = (int)(rec.x >> 24), avail = (int)(rec.w & 255u);
+    const bool aL = avail & P264_AVAIL_LEFT, aT = avail & P264_AVAIL_TOP, aTL = avail & P264_AVAIL_TOPLEFT;
+    uint8_t *F = pd->dst;
+    const AS1 uint8_t *Fg = glob(F);
+    const unsigned mask = rec.y;
+    const int16_t *cf = pd->coefs + (size_t)rec.z * 16;
+    const int p = l >> 3, r = l & 7;
+    uint8_t *tile = L.tile + p * (9 * CT_STRIDE);
+
+    // ---- neighbours: lane (p, r) the left sample of its row; r = 0, 1 the two dwords of the row above, r = 2 the corner ----
+    int vL = 128;
+    if (aL) vL = Fg[chroma_off(g, p, X0 - 1, Y0 + r)];
+    uint32_t vT = 0x80808080u;
+    if (r < 2)       { if (aT)  vT = gload1(F + chroma_off(g, p, X0 + 4 * r, Y0 - 1)); }
+    else if (r == 2) { if (aTL) vT = Fg[chroma_off(g, p, X0 - 1, Y0 - 1)]; }
+    // ---- levels: lanes 0..7 = block (plane l >> 2, block l & 3): 15 AC levels; the plane's four DC levels ----
+    const bool has_chroma = (cbp >> 4) != 0;
+    const int blk = 16 + l;                                // (l < 8)
+    const bool coded = has_chroma && l < 8 && ((mask >> blk) & 1);
+    uint4 la = make_uint4(0, 0, 0, 0), lb = la; uint2 dcl = make_uint2(0, 0);
+    if (coded) { const int16_t *c = cf + coef_slot(mask, blk) * 16; la = gload4(c); lb = gload4(c + 8); }
+    if (has_chroma && l < 8 && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + (l >> 2) * 4);
+
+    tile[(r + 1) * CT_STRIDE + 3] = (uint8_t)vL;
+    if (r < 2) *(uint32_t *)(tile + 4 + 4 * r) = vT;
+    else if (r == 2) tile[3] = (uint8_t)vT;
+    wave_lds_fence();
+
+    // ---- residuals of the eight blocks (same arithmetic as kernel_mc.h) ----
+    if (__ballot(has_chroma)) {
+        if (l < 8) {
+            const int qpc = chroma_qp(clip3i(qp + pd->chroma_qp_offset, 0, 51));
+            const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
+            uint32_t col[4][2], rr[4][2];
+            unscan_cols<true>(lv, col);
+            dequant_cols(col, qpc);
+            // DC of block j: idct2x2dc (core/dct.c:55-68, int16 stores), then p264_mb_dequant_2x2_dc (core/quant.c:138-159)
+            const int j = l & 3;
+            const int d0 = (int)(int16_t)(dcl.x & 0xffff), d1 = (int)dcl.x >> 16, d2 = (int)(int16_t)(dcl.y & 0xffff), d3 = (int)dcl.y >> 16;
+            const int t0 = d0 + d1, t1 = d0 - d1, t2 = d2 + d3, t3 = d2 - d3;
+            int f = pick_addsub(t0, t1, t2, t3, j & 1, j & 2);                    // {t0+t2, t1+t3, t0-t2, t1-t3}[j]
+            f = (int)(int16_t)f;
+            const int per = (qpc * 43) >> 8, rem = qpc - per * 6;
+            const int dc = (f * (int)(dq_s(0, rem) << per)) >> 1;
+            col[0][0] = (col[0][0] & 0xffff0000u) | ((uint32_t)dc & 0xffffu);
+            idct_res(col, rr);
+            uint4 *out = (uint4 *)(L.res + l * 16);
+            out[0] = has_chroma ? make_uint4(rr[0][0], rr[0][1], rr[1][0], rr[1][1]) : make_uint4(0, 0, 0, 0);
+            out[1] = has_chroma ? make_uint4(rr[2][0], rr[2][1], rr[3][0], rr[3][1]) : make_uint4(0, 0, 0, 0);
+        }
+        wave_lds_fence();
+    }
+
+    // ---- prediction: 8 samples of row r ----
+    int mode = (modes >> 4) & 3;
+    if (mode == 0) mode = aTL ? 0 : aL ? 4 : aT ? 5 : 6;                         // :721-753
+    const uint32_t ta = *(const uint32_t *)(tile + 4), tb = *(const uint32_t *)(tile + 8);
+    const int s0 = byte_sum(ta), s1 = byte_sum(tb);
+    const int sq = sum_lanes(vL, 4);                                             // left sum of this lane's half (rows 0..3 or 4..7)
+    const int so = __shfl_xor(sq, 4);
+    const int s2 = r < 4 ? sq : so, s3 = r < 4 ? so : sq;
+    uint32_t pa, pb;                                                             // samples 0..3 and 4..7
+    {
+        const int up = r < 4;
+        int da, db;                                                              // DC of the left and right 4x4 of this row
+        if (mode == 0)      { da = up ? (s0 + s2 + 4) >> 3 : (s3 + 2) >> 2; db = up ? (s1 + 2) >> 2 : (s1 + s3 + 4) >> 3; }
+        else if (mode == 4) { da = db = ((up ? s2 : s3) + 2) >> 2; }
+        else if (mode == 5) { da = (s0 + 2) >> 2; db = (s1 + 2) >> 2; }
+        else                { da = db = 128; }
+        if (mode == 1) da = db = vL;
+        pa = (uint32_t)da * 0x01010101u; pb = (uint32_t)db * 0x01010101u;
+        if (mode == 2) { pa = ta; pb = tb; }
+    }
+    if (__ballot(mode == 3)) {
+        // H = sum (i+1) (top[4+i] - top[2-i]) = sum over x = -1..7 of (x - 3) top[x]; the same down the left column
+        const int corner = tile[3], topl = tile[4 + r];
+        const int H = sum_lanes((r - 3) * topl, 8) - 4 * corner, V = sum_lanes((r - 3) * vL, 8) - 4 * corner;
+        const int a = 16 * (__shfl(vL, (int)(threadIdx.x & 56) + 7) + (int)tile[11]), b = (17 * H + 16) >> 5, c = (17 * V + 16) >> 5;
+        const int i00 = a - 3 * b - 3 * c + 16 + c * r;
+        if (mode == 3) {
+            const int ta4[4] = { i00, i00 + b, i00 + 2 * b, i00 + 3 * b }, tb4[4] = { i00 + 4 * b, i00 + 5 * b, i00 + 6 * b, i00 + 7 * b };
+            pa = round_pack4<5>(ta4); pb = round_pack4<5>(tb4);
+        }
+    }
+    if (has_chroma) {
+        const int16_t *rs = L.res + (p * 4 + (r >> 2) * 2) * 16 + (r & 3) * 4;
+        const uint2 ra = *(const uint2 *)rs, rb = *(const uint2 *)(rs + 16);
+        pa = add_res4(pa, ra.x, ra.y); pb = add_res4(pb, rb.x, rb.y);
+    }
+    gstore2(F + mb_chroma_off(g, mbx, mby) + r * 16 + p * 8, make_uint2(pa, pb));
 }
 
 #ifndef INTRA_ROW_WAVES
 #define INTRA_ROW_WAVES 16          // most wavefronts per picture workgroup
 #endif
 #ifndef INTRA_WAVES_PER_EU
-#define INTRA_WAVES_PER_EU 4
+#define INTRA_WAVES_PER_EU 5
 #endif
+#define INTRA_BAND 4                // macroblock rows per wavefront = groups of sixteen lanes
 __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
 {
     __shared__ RowSync sync;
-    // one tile set per wavefront, sized by the launch (dynamic shared memory = wavefronts x sizeof(IntraLds)): with the space of
-    // sixteen wavefronts reserved for every workgroup only seven workgroups fitted a CU whatever their size - a batch of
-    // 1024 pictures (2048 workgroups of 4 wavefronts) then ran as two rounds of workgroups, i.e. took twice a workgroup's time
+    __shared__ uint8_t lut[INTRA_LUT_BYTES];
+    // one tile set per wavefront, sized by the launch (dynamic shared memory = wavefronts x sizeof(IntraLds))
     extern __shared__ __attribute__((aligned(16))) uint8_t intra_dyn_lds[];
     IntraLds *lds = (IntraLds *)intra_dyn_lds;
     const PicDev *pd = pics + blockIdx.x;
     const bool chroma_role = blockIdx.y != 0;               // grid.y = 2: luma and chroma of a picture in separate workgroups
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    rows_init(sync, g.mb_h);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
+    for (int i = threadIdx.x; i < INTRA_LUT_BYTES; i += blockDim.x) {
+        int c, kind;
+        pred4x4_where(i >> 4, i & 3, (i >> 2) & 3, c, kind);
+        lut[i] = (uint8_t)(c | kind << 4);
+    }
+    rows_init(sync, g.mb_h);                                // (ends with a barrier)
+    IntraGrp &L = lds[wave].g[grp];
     bool ok = true;
-    const int n_waves = blockDim.x >> 6;                       // 16 per picture, or 8 when two pictures share a CU (host's choice)
-    for (int row = wave; row < g.mb_h; row += n_waves) {
-        for (int base = 0; base < g.mb_w; base += 64) {
-            // which of the next 64 macroblocks of this row are intra, and which of them touch an intra macroblock of
-            // the row above?  Only those can still be in flight there (inter MBs were finished by the motion-compensation kernels), so the
-            // wavefront dependency only bites where intra macroblocks touch.  One batch of loads per 64 macroblocks.
-            const int x = base + lane;
-            const AS1 p264hip_mb_t *recs = glob(pd->mb) + row * g.mb_w;
-            bool intra = false, dep = false;
-            uint4 rec = make_uint4(0, 0, 0, 0);                                   // this lane's macroblock record
-            if (x < g.mb_w) {
-                rec = gload4(pd->mb + row * g.mb_w + x);
-                intra = P264_MB_IS_INTRA(rec.x & 255);
-                if (row > 0) {
-                    const AS1 p264hip_mb_t *up = recs - g.mb_w;
-                    dep = (int)P264_MB_IS_INTRA(up[x].mb_type) | (int)P264_MB_IS_INTRA(up[max(x - 1, 0)].mb_type) |
-                          (int)P264_MB_IS_INTRA(up[min(x + 1, g.mb_w - 1)].mb_type);
+    const int n_waves = blockDim.x >> 6;                       // 16 per picture, or fewer when pictures share a CU (host's choice)
+    const int n_bands = (g.mb_h + INTRA_BAND - 1) / INTRA_BAND;
+    for (int band = wave; band < n_bands; band += n_waves) {
+        const int R0 = band * INTRA_BAND;
+        const bool feeds = R0 + INTRA_BAND < g.mb_h;          // a band below reads this band's last row
+        // Per row of the band: a window of 64 macroblocks (one record per lane), which of them are intra (todo) and which of
+        // those touch an intra macroblock of the row above (deps: only those can still be in flight there - inter MBs were
+        // finished by the motion-compensation kernels).  Every row moves through its windows on its own.
+        unsigned long long todo[INTRA_BAND], deps[INTRA_BAND];
+        int base[INTRA_BAND];
+        bool fin[INTRA_BAND];
+#pragma unroll
+        for (int r = 0; r < INTRA_BAND; r++) { base[r] = -64; todo[r] = deps[r] = 0; fin[r] = R0 + r >= g.mb_h; }
+        int spins = 0, published = -1;
+        for (;;) {
+            // ---- rows whose window is used up take the next one (all of them in one batch of loads) ----
+            for (;;) {
+                bool need[INTRA_BAND], any_need = false;
+#pragma unroll
+                for (int r = 0; r < INTRA_BAND; r++) {
+                    need[r] = !fin[r] && todo[r] == 0;
+                    if (need[r]) { base[r] += 64; if (base[r] >= g.mb_w) { fin[r] = true; need[r] = false; } }
+                    any_need |= need[r];
+                }
+                if (!any_need) break;
+                bool intra[INTRA_BAND], dep[INTRA_BAND];
+#pragma unroll
+                for (int r = 0; r < INTRA_BAND; r++) {
+                    const int row = R0 + r, x = base[r] + lane;
+                    intra[r] = dep[r] = false;
+                    if (need[r] && x < g.mb_w) {
+                        const AS1 p264hip_mb_t *cur = glob(pd->mb) + row * g.mb_w;
+                        intra[r] = P264_MB_IS_INTRA(cur[x].mb_type);
+                        if (row > 0) {
+                            const AS1 p264hip_mb_t *up = cur - g.mb_w;
+                            dep[r] = (int)P264_MB_IS_INTRA(up[x].mb_type) | (int)P264_MB_IS_INTRA(up[max(x - 1, 0)].mb_type) |
+                                     (int)P264_MB_IS_INTRA(up[min(x + 1, g.mb_w - 1)].mb_type);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < INTRA_BAND; r++) if (need[r]) { todo[r] = __ballot(intra[r]); deps[r] = __ballot(dep[r]); }
+            }
+            // next macroblock of every row (the row's end when it has none left): everything in front of it is final
+            int col[INTRA_BAND];
+#pragma unroll
+            for (int r = 0; r < INTRA_BAND; r++) col[r] = fin[r] ? g.mb_w : base[r] + __ffsll((long long)todo[r]) - 1;
+            // their records: wave-uniform addresses, read-only data - scalar loads, no vector registers
+            uint4 srec[INTRA_BAND];
+#pragma unroll
+            for (int r = 0; r < INTRA_BAND; r++) {
+                const int idx = (R0 + r) * g.mb_w + col[r];
+                srec[r] = make_uint4(0, 0, 0, 0);
+                if (!fin[r]) {
+                    const __attribute__((address_space(4))) uint32_t *w = (const __attribute__((address_space(4))) uint32_t *)(pd->mb + rfl(idx));
+                    srec[r] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
-            unsigned long long todo = __ballot(intra);
-            const unsigned long long deps = __ballot(dep);
-            while (todo) {
-                int bit = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                int mbx = base + bit, mbi = row * g.mb_w + mbx;
-                if (((deps >> bit) & 1) && ok) ok = row_wait(sync, row - 1, min(mbx + 2, g.mb_w), status);
-                const uint4 mr = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)rec.x, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.y, bit),
-                                            (uint32_t)__builtin_amdgcn_readlane((int)rec.z, bit), (uint32_t)__builtin_amdgcn_readlane((int)rec.w, bit));
-                if (chroma_role)       intra_mb<false, true>(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane, sync, mbx);
-                else                   intra_mb<true, false>(pd, g, lds[wave], mbi, __builtin_bit_cast(p264hip_mb_t, mr), lane, sync, mbx);
+            // the band's last row feeds the band below (release: this wavefront's stores have landed)
+            if (feeds && col[INTRA_BAND - 1] != published) { published = col[INTRA_BAND - 1]; row_publish(sync, R0 + INTRA_BAND - 1, published); }
+            if (fin[0] && fin[1] && fin[2] && fin[3]) break;
+            // whose neighbours are final?  The row above is this wavefront's own previous row, or the band above (acquire)
+            bool go[INTRA_BAND], any = false;
+            int above = R0 > 0 ? __hip_atomic_load(&sync.progress[R0 - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : g.mb_w;
+            above = rfl(above);
+#pragma unroll
+            for (int r = 0; r < INTRA_BAND; r++) {
+                const bool dep = !fin[r] && ((deps[r] >> (col[r] - base[r])) & 1);
+                go[r] = !fin[r] && (!dep || !ok || min(col[r] + 2, g.mb_w) <= above);
+                any |= go[r];
+                above = col[r];
             }
+            if (!any) {                                        // (only ever waits for another wavefront: the band above)
+                __builtin_amdgcn_s_sleep(WAIT_SLEEP);
+                if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(status, 1); ok = false; }
+                continue;
+            }
+            // this group's macroblock
+            // (selected with lane masks: written as grp == 0 ? a : grp == 1 ? b : ... the compiler builds a table in scratch memory)
+            uint32_t m1 = 0u - (uint32_t)(grp == 1), m2 = 0u - (uint32_t)(grp == 2), m3 = 0u - (uint32_t)(grp == 3);
+            asm volatile("" : "+v"(m1), "+v"(m2), "+v"(m3));
+            const uint32_t m0 = ~(m1 | m2 | m3);
+            auto pick = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return (a & m0) | (b & m1) | (c & m2) | (d & m3); };
+            const bool active = pick(go[0], go[1], go[2], go[3]) != 0;
+            const int mbx = (int)pick((uint32_t)col[0], (uint32_t)col[1], (uint32_t)col[2], (uint32_t)col[3]);
+            const uint4 rec = make_uint4(pick(srec[0].x, srec[1].x, srec[2].x, srec[3].x), pick(srec[0].y, srec[1].y, srec[2].y, srec[3].y),
+                                         pick(srec[0].z, srec[1].z, srec[2].z, srec[3].z), pick(srec[0].w, srec[1].w, srec[2].w, srec[3].w));
+            if (active) {
+                if (chroma_role) intra_chroma4(pd, g, L, mbx, R0 + grp, rec, l);
+                else             intra_luma4(pd, g, L, lut, mbx, R0 + grp, rec, l);
+            }
+#pragma unroll
+            for (int r = 0; r < INTRA_BAND; r++) if (go[r]) todo[r] &= todo[r] - 1;
         }
-        row_publish(sync, row, g.mb_w);
     }
 }

@@ -256,7 +256,10 @@ __device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, Int
             const unsigned tl_m = 0xFAC8u | (aT ? 0x0032u : 0u) | (aL ? 0x0504u : 0u) | (aTL ? 0x0001u : 0u);
             const unsigned tr_m = 0x5744u | (aT ? 0x0013u : 0u) | (aTR ? 0x0020u : 0u);
             const int grp_base = (int)(threadIdx.x & 48);
-#pragma unroll 1
+#ifndef INTRA_I4_UNROLL
+#define INTRA_I4_UNROLL 16
+#endif
+#pragma unroll INTRA_I4_UNROLL
             for (int i = 0; i < 16; i++) {
                 const int bx = blk_x(i), by = blk_y(i);
                 const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1, topleft = (tl_m >> i) & 1, topright = (tr_m >> i) & 1;

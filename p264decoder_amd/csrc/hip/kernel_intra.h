@@ -399,27 +399,121 @@ __device__ __forceinline__ void intra_chroma4(const PicDev *pd, const Geom &g, I
 #define INTRA_WAVES_PER_EU 5
 #endif
 #define INTRA_BAND 4                // macroblock rows per wavefront = groups of sixteen lanes
+// P / B pictures: intra macroblocks without an intra neighbour to the left or above depend on nothing this kernel writes.
+// They are collected first (two lists, by macroblock type, so that the four macroblocks of an iteration run the same code)
+// and reconstructed four at a time in any order; only the rest goes through the ordered band walk below.
+#define INTRA_FREE_CAP   256        // entries per list (uint16 macroblock index); macroblocks beyond it stay in the band walk
+#define INTRA_MASKS      160        // pictures of up to this many row windows (rows x windows of 64 macroblocks): 1080p has 136
+struct IntraSync { int progress[MAX_MB_ROWS / INTRA_BAND + 1]; };            // per band: columns of its last row that are final
 __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
 {
-    __shared__ RowSync sync;
+    __shared__ IntraSync sync;
     __shared__ uint8_t lut[INTRA_LUT_BYTES];
+    __shared__ uint16_t free_list[2][INTRA_FREE_CAP];
+    __shared__ unsigned long long m_intra[INTRA_MASKS], m_walk[INTRA_MASKS];   // per row window: intra macroblocks / those left to the band walk
+    __shared__ int free_n[2];
     // one tile set per wavefront, sized by the launch (dynamic shared memory = wavefronts x sizeof(IntraLds))
     extern __shared__ __attribute__((aligned(16))) uint8_t intra_dyn_lds[];
     IntraLds *lds = (IntraLds *)intra_dyn_lds;
     const PicDev *pd = pics + blockIdx.x;
     const bool chroma_role = blockIdx.y != 0;               // grid.y = 2: luma and chroma of a picture in separate workgroups
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
+    const int n_waves = blockDim.x >> 6;                       // 16 per picture, or fewer when pictures share a CU (host's choice)
+    const int n_bands = (g.mb_h + INTRA_BAND - 1) / INTRA_BAND;
     for (int i = threadIdx.x; i < INTRA_LUT_BYTES; i += blockDim.x) {
         int c, kind;
         pred4x4_where(i >> 4, i & 3, (i >> 2) & 3, c, kind);
         lut[i] = (uint8_t)(c | kind << 4);
     }
-    rows_init(sync, g.mb_h);                                // (ends with a barrier)
+    for (int i = threadIdx.x; i <= n_bands; i += blockDim.x) sync.progress[i] = 0;
+    const int wins = (g.mb_w + 63) / 64, n_win = g.mb_h * wins;
+    const bool use_free = pd->slice_type != P264_SLICE_I && n_win <= INTRA_MASKS && g.n_mb < 65536;     // (scalar)
+    if (threadIdx.x < 2) free_n[threadIdx.x] = 0;
+    __syncthreads();
     IntraGrp &L = lds[wave].g[grp];
     bool ok = true;
-    const int n_waves = blockDim.x >> 6;                       // 16 per picture, or fewer when pictures share a CU (host's choice)
-    const int n_bands = (g.mb_h + INTRA_BAND - 1) / INTRA_BAND;
+    if (use_free) {
+        // ---- collect, pass 1: which macroblocks are intra (one byte per lane, four row windows per pass: the loads fly together) ----
+        for (int w0 = wave * 4; w0 < n_win; w0 += n_waves * 4) {
+            bool in[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int w = w0 + j, row = w / wins, x = (w - row * wins) * 64 + lane;
+                in[j] = w < n_win && x < g.mb_w && P264_MB_IS_INTRA(glob(pd->mb)[row * g.mb_w + x].mb_type);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const unsigned long long m = __ballot(in[j]); if (w0 + j < n_win && lane == 0) m_intra[w0 + j] = m; }
+        }
+        __syncthreads();
+        // ---- pass 2: free = no intra macroblock to the left, above-left, above, above-right (mask arithmetic); the free ones go
+        //      to the list of their type, the rest (and what the lists cannot take) is left to the band walk ----
+        for (int w = wave; w < n_win; w += n_waves) {
+            const int row = w / wins, win = w - row * wins;
+            const unsigned long long m = m_intra[w];
+            if (m == 0) { if (lane == 0) m_walk[w] = 0; continue; }
+            unsigned long long blocked = m << 1;
+            if (win > 0) blocked |= m_intra[w - 1] >> 63;
+            if (row > 0) {
+                const unsigned long long u = m_intra[w - wins];
+                blocked |= u | u << 1 | u >> 1;
+                if (win > 0) blocked |= m_intra[w - wins - 1] >> 63;
+                if (win + 1 < wins) blocked |= m_intra[w - wins + 1] << 63;
+            }
+            const unsigned long long fr = m & ~blocked;
+            unsigned long long taken = 0;
+            if (fr) {
+                const int mbi = row * g.mb_w + win * 64 + lane;
+                const bool mine = (fr >> lane) & 1;
+                int type = 0;
+                if (mine) type = glob(pd->mb)[mbi].mb_type;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const bool me = mine && (type == P264_MB_I16x16) == (t == 1);
+                    const unsigned long long mt = __ballot(me);
+                    if (mt == 0) continue;
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(&free_n[t], __popcll(mt));
+                    at = rfl(at) + __popcll(mt & ((1ull << lane) - 1ull));
+                    const bool put = me && at < INTRA_FREE_CAP;
+                    if (put) free_list[t][at] = (uint16_t)mbi;
+                    taken |= __ballot(put);
+                }
+            }
+            if (lane == 0) m_walk[w] = m & ~taken;
+        }
+        __syncthreads();
+        // ---- reconstruct the listed macroblocks, four per iteration; the records of the next four are requested a round ahead ----
+        const uint32_t inv_mbw = 0xffffffffu / (uint32_t)g.mb_w;
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            const int n = min(free_n[t], INTRA_FREE_CAP);
+            int k = wave * 4;
+            int mbi = k + grp < n ? (int)free_list[t][k + grp] : 0;
+            uint4 rec = gload4(pd->mb + mbi);
+#ifdef INTRA_EXP_SKIP_A
+            k = n;
+#endif
+            while (k < n) {
+                const bool active = k + grp < n;
+                const int kn = k + n_waves * 4;
+                const int mbi_n = kn + grp < n ? (int)free_list[t][kn + grp] : 0;
+                const uint4 rec_n = gload4(pd->mb + mbi_n);
+                int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+                if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+                const int mbx = mbi - mby * g.mb_w;
+                if (active) {
+                    if (chroma_role) intra_chroma4(pd, g, L, mbx, mby, rec, l);
+                    else             intra_luma4(pd, g, L, lut, mbx, mby, rec, l);
+                }
+                k = kn; mbi = mbi_n; rec = rec_n;
+            }
+        }
+        __syncthreads();                                       // (their samples are neighbours of the macroblocks below)
+    }
+#ifdef INTRA_EXP_SKIP_WALK
+    if (use_free) return;
+#endif
     for (int band = wave; band < n_bands; band += n_waves) {
         const int R0 = band * INTRA_BAND;
         const bool feeds = R0 + INTRA_BAND < g.mb_h;          // a band below reads this band's last row
@@ -443,6 +537,24 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                     any_need |= need[r];
                 }
                 if (!any_need) break;
+                if (use_free) {
+                    // (sparse pictures: the masks are in LDS; a macroblock waits only for macroblocks of the band walk above it)
+#pragma unroll
+                    for (int r = 0; r < INTRA_BAND; r++) {
+                        if (!need[r]) continue;
+                        const int row = R0 + r, win = base[r] >> 6, w = row * wins + win;
+                        todo[r] = m_walk[w];
+                        unsigned long long d = 0;
+                        if (row > 0) {
+                            const unsigned long long u = m_walk[w - wins];
+                            d = u | u << 1 | u >> 1;
+                            if (win > 0) d |= m_walk[w - wins - 1] >> 63;
+                            if (win + 1 < wins) d |= m_walk[w - wins + 1] << 63;
+                        }
+                        deps[r] = d;
+                    }
+                    continue;
+                }
                 bool intra[INTRA_BAND], dep[INTRA_BAND];
 #pragma unroll
                 for (int r = 0; r < INTRA_BAND; r++) {
@@ -477,11 +589,11 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
                 }
             }
             // the band's last row feeds the band below (release: this wavefront's stores have landed)
-            if (feeds && col[INTRA_BAND - 1] != published) { published = col[INTRA_BAND - 1]; row_publish(sync, R0 + INTRA_BAND - 1, published); }
+            if (feeds && col[INTRA_BAND - 1] != published) { published = col[INTRA_BAND - 1]; __hip_atomic_store(&sync.progress[band], published, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
             if (fin[0] && fin[1] && fin[2] && fin[3]) break;
             // whose neighbours are final?  The row above is this wavefront's own previous row, or the band above (acquire)
             bool go[INTRA_BAND], any = false;
-            int above = R0 > 0 ? __hip_atomic_load(&sync.progress[R0 - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : g.mb_w;
+            int above = band > 0 ? __hip_atomic_load(&sync.progress[band - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : g.mb_w;
             above = rfl(above);
 #pragma unroll
             for (int r = 0; r < INTRA_BAND; r++) {

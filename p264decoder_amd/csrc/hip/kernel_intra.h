@@ -33,7 +33,6 @@ struct IntraGrp {                  // per group of sixteen lanes (= one macroblo
     uint8_t  tile[17 * IT_STRIDE]; // luma: the tile above; chroma: two tiles of 9 x CT_STRIDE
     int16_t  res[16 * 16];         // residual of every 4x4 block (luma: decode order; chroma: plane * 4 + block), raster inside
     int16_t  dc[16];
-    uint8_t  edge[16];             // Intra4x4: l3 l3 l2 l1 l0 lt t0..t7 t7 of the current block
     uint8_t  pad[8];
 };
 struct IntraLds { IntraGrp g[4]; };                        // per wavefront
@@ -66,7 +65,8 @@ __device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, in
               c = z >= 5 ? 1 : 3 - y - (x >> 1); kind = z > 5 ? P4_COPY : (z == 5 || (z & 1)) ? P4_F3 : P4_F2; break; }
     }
 }
-#define INTRA_LUT_BYTES (9 * 16)
+#define INTRA_LUT_ENTRIES (9 * 16)         // int16: offset of S[c] from the block origin << 8 | kind << 4 | c
+__device__ __forceinline__ int edge_offset(int k) { return k <= 4 ? (4 - max(k, 1)) * IT_STRIDE - 1 : -IT_STRIDE + min(k, 13) - 6; }
 
 // sum over the sixteen lanes of a group / over aligned groups of 2^k lanes (xor butterflies stay inside the group)
 __device__ __forceinline__ int sum_lanes(int v, int n)
@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t add_res4(uint32_t px, uint32_t r01, uint32_t
 // needs is issued at the top, before anything waits: one memory round trip per iteration, everything after that runs out
 // of registers and LDS.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, IntraGrp &L, const uint8_t *lut, int mbx, int mby, const uint4 rec, int l)
+__device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, IntraGrp &L, const int16_t *lut, int mbx, int mby, const uint4 rec, int l)
 {
     // Everything below that depends on the lane number alone (roles, tile offsets, edge slots) would otherwise be hoisted
     // out of the caller's loops and kept - or spilled - across them: recomputing it per macroblock is a few dozen
@@ -243,47 +243,39 @@ __device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, Int
     }
     if (__ballot(!is16)) {
         if (!is16) {
-            // ---- Intra4x4: sixteen dependent blocks (decoder/macroblock.c:799-831), lane l = sample (x, y) of the current block ----
+            // ---- Intra4x4: sixteen dependent blocks (decoder/macroblock.c:799-831), lane l = sample (x, y) of the current block.
+            // The samples a prediction reads are the edge S = l3 l3 l2 l1 l0 lt t0..t7 t7 around the block (pred4x4_where); they
+            // are read straight out of the tile: cells of neighbours that do not exist already hold their substitute (128, put
+            // there with the macroblock's neighbours; decoder/macroblock.c:697-713), and where a block has a row above but no
+            // top-right neighbour (blocks 3, 7, 11, 13, 15 - and 5 without the macroblock's top-right, done above) the last
+            // sample of the block above is replicated into the four cells to its right by the step that produced it: those cells
+            // are padding, or belong to a block that is decoded later and overwrites them.  One LDS round trip per step. ----
             const int x = l & 3, y = l >> 2;
-            // the lane's slot of the edge array: offset from the block origin inside the tile and the neighbour it belongs to
-            // (0 left, 1 top-left, 2 top, 3 top-right)
-            const int es = min(l, 14);
-            const int eoff = es <= 4 ? (es == 0 ? 3 : 4 - es) * IT_STRIDE - 1 : es == 5 ? -IT_STRIDE - 1 : -IT_STRIDE + min(es - 6, 7);
-            const int eflag = es <= 4 ? 0 : es == 5 ? 1 : es <= 9 ? 2 : 3;
-            // which of the 16 blocks (decode order) have their left / top / top-left / top-right neighbour: one bit per block,
-            // from the macroblock's availability (inside the MB: fixed pattern, top-right per core/macroblock.c:1210-1231)
+            // which of the 16 blocks (decode order) have their left / top neighbour (for the DC fall-backs): one bit per block
             const unsigned left_m = 0xFAFAu | (aL ? 0x0505u : 0u), top_m = 0xFFCCu | (aT ? 0x0033u : 0u);
-            const unsigned tl_m = 0xFAC8u | (aT ? 0x0032u : 0u) | (aL ? 0x0504u : 0u) | (aTL ? 0x0001u : 0u);
-            const unsigned tr_m = 0x5744u | (aT ? 0x0013u : 0u) | (aTR ? 0x0020u : 0u);
             const int grp_base = (int)(threadIdx.x & 48);
-#ifndef INTRA_I4_UNROLL
-#define INTRA_I4_UNROLL 16
-#endif
-#pragma unroll INTRA_I4_UNROLL
+            const int16_t *lut16 = (const int16_t *)lut;
+#pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int bx = blk_x(i), by = blk_y(i);
-                const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1, topleft = (tl_m >> i) & 1, topright = (tr_m >> i) & 1;
+                const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1;
                 const int mode = __shfl(modebyte, grp_base + i);
-                const uint8_t *o = L.tile + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;     // block origin inside the tile
-                // ---- edge array, missing neighbours substituted (decoder/macroblock.c:697-713): 128, or t3 for the top-right ----
-                {
-                    const unsigned av = (unsigned)left | (unsigned)topleft << 1 | (unsigned)top << 2 | (unsigned)topright << 3;
-                    const int own = o[eoff], t3 = o[-IT_STRIDE + 3];
-                    const int alt = (eflag == 3 && top) ? t3 : 128;
-                    if (l < 15) L.edge[l] = (uint8_t)(((av >> eflag) & 1) ? own : alt);
-                }
-                const int wk = lut[min(mode, 8) * 16 + l], c = wk & 15, kind = wk >> 4;
-                wave_lds_fence();
-                const int a = L.edge[c - 1], b = L.edge[c], d = L.edge[c + 1];
+                uint8_t *o = L.tile + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
+                // where the lane's three edge samples sit: offset of S[c] from the origin, c and the filter kind out of the table;
+                // S[c-1] / S[c+1] one step back / on along the edge (down the left column, across the corner, along the top row)
+                const int wk = lut16[min(mode, 8) * 16 + l], ob = wk >> 8, c = wk & 15, kind = (wk >> 4) & 3;
+                const int oa = c == 1 ? ob : c <= 5 ? ob + IT_STRIDE : ob - 1, od = c >= 13 ? ob : c <= 4 ? ob - IT_STRIDE : ob + 1;
+                const int a = o[oa], b = o[ob], d = o[od];
                 int v = kind == P4_COPY ? b : kind == P4_F2 ? (b + d + 1) >> 1 : (a + 2 * b + d + 2) >> 2;
                 if (__ballot(kind == P4_DC)) {                                          // DC and its fall-backs, :677-695
-                    const uint8_t *S = L.edge;
-                    const int sl = S[1] + S[2] + S[3] + S[4], st = S[6] + S[7] + S[8] + S[9];
+                    const int sl = o[-1] + o[IT_STRIDE - 1] + o[2 * IT_STRIDE - 1] + o[3 * IT_STRIDE - 1], st = byte_sum(*(const uint32_t *)(o - IT_STRIDE));
                     const int dcv = (left && top) ? (sl + st + 4) >> 3 : left ? (sl + 2) >> 2 : top ? (st + 2) >> 2 : 128;
                     v = kind == P4_DC ? dcv : v;
                 }
                 if ((mask >> i) & 1) v = clip255(v + (int)L.res[i * 16 + l]);
-                L.tile[(by * 4 + y + 1) * IT_STRIDE + 4 + bx * 4 + x] = (uint8_t)v;
+                o[y * IT_STRIDE + x] = (uint8_t)v;
+                // the block below has no top-right neighbour: its t4..t7 = this block's last sample
+                if ((i == 1 || i == 5 || i == 7 || i == 9 || i == 13) && l == 15) *(uint32_t *)(o + 3 * IT_STRIDE + 4) = (uint32_t)v * 0x01010101u;
                 wave_lds_fence();
             }
             const uint32_t *row = (const uint32_t *)(L.tile + (l + 1) * IT_STRIDE + 4);
@@ -409,7 +401,7 @@ __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
 {
     __shared__ IntraSync sync;
-    __shared__ uint8_t lut[INTRA_LUT_BYTES];
+    __shared__ int16_t lut[INTRA_LUT_ENTRIES];
     __shared__ uint16_t free_list[2][INTRA_FREE_CAP];
     __shared__ unsigned long long m_intra[INTRA_MASKS], m_walk[INTRA_MASKS];   // per row window: intra macroblocks / those left to the band walk
     __shared__ int free_n[2];
@@ -421,10 +413,10 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
     const int n_waves = blockDim.x >> 6;                       // 16 per picture, or fewer when pictures share a CU (host's choice)
     const int n_bands = (g.mb_h + INTRA_BAND - 1) / INTRA_BAND;
-    for (int i = threadIdx.x; i < INTRA_LUT_BYTES; i += blockDim.x) {
+    for (int i = threadIdx.x; i < INTRA_LUT_ENTRIES; i += blockDim.x) {
         int c, kind;
         pred4x4_where(i >> 4, i & 3, (i >> 2) & 3, c, kind);
-        lut[i] = (uint8_t)(c | kind << 4);
+        lut[i] = (int16_t)(edge_offset(c) * 256 + (kind << 4 | c));
     }
     for (int i = threadIdx.x; i <= n_bands; i += blockDim.x) sync.progress[i] = 0;
     const int wins = (g.mb_w + 63) / 64, n_win = g.mb_h * wins;

@@ -453,7 +453,10 @@ __device__ __forceinline__ u32x4 bload4(rsrc_t r, uint32_t off) { return __built
 // reference lines out of L2 (measured: -3 % on the stage)
 #define MC_ST_AUX 2
 __device__ __forceinline__ u32x2 bload2(rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); }
-__device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b) { const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, MC_ST_AUX); }
+// (the 8-byte stores of quadrant items fill half a 16-byte row each: left to L2 to merge - non-temporal they cost 0.27 GB of
+// extra HBM writes per launch)
+#define MC_ST2_AUX 0
+__device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b) { const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, MC_ST2_AUX); }
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }

@@ -29,8 +29,12 @@
 //     otherwise (4 lanes, a 13-row window); quadrants whose 4x4 blocks differ (sub-8x8 partitions) fetch per lane with
 //     clamped coordinates.
 //
-// Chroma (4x4 per quadrant and plane, bilinear) has no phase classes; it has its own kernels and lists (macroblock items
+// Chroma (4x4 per quadrant and plane, bilinear) has no phase classes; it has its own roles and lists (macroblock items
 // of 8 lanes; quadrant items of 2 lanes, the four of a macroblock consecutive), keys {inside / clamped, residual or not}.
+//
+// One launch (k_mc) runs the four kinds of work - luma / chroma x macroblock / quadrant items - as roles of the workgroups a
+// picture gets (see k_mc below); B pictures take a second launch (k_mc_second) for the list-1 half of the blocks that
+// predict from both lists (mc_classify).
 //
 // Arithmetic to preserve: core/mc.c:172-266 (half-pel planes, quarter-pel averages), :303-334 (chroma),
 // core/quant.c:66-99,138-159, core/dct.c:55-68,205-247 with their int16 stores (A-Q8).
@@ -820,7 +824,7 @@ __device__ __forceinline__ int xcd_logical_block()
 }
 
 // ------------------------------------------------------------------------------------------
-// k_mc_luma<MB>: one wavefront = one chunk of one key: 4 macroblock items of 16 lanes, or 16 quadrant items of 4 lanes;
+// mc_luma_body<MB, PB> (a role of k_mc / k_mc_second): one wavefront = one chunk of one key: 4 macroblock items of 16 lanes, or 16 quadrant items of 4 lanes;
 // the lane is one 4x4 block
 // ------------------------------------------------------------------------------------------
 template <bool MB, bool PB>
@@ -994,7 +998,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
   }
 }
 // ------------------------------------------------------------------------------------------
-// k_mc_chroma<MB>: one wavefront = one chunk: 8 macroblock items of 8 lanes or 32 quadrant items of 2 lanes;
+// mc_chroma_body<MB, PB> (a role of k_mc / k_mc_second): one wavefront = one chunk: 8 macroblock items of 8 lanes or 32 quadrant items of 2 lanes;
 // the lane is one 4x4 chroma block (quadrant, plane)
 // ------------------------------------------------------------------------------------------
 // 1/8-pel bilinear (core/mc.c:303-334) of one 4x4 block from the two aligned dwords d0, d1 of five window rows; the

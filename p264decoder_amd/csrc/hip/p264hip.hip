@@ -78,7 +78,7 @@ struct p264hip_ctx {
     int batch_cap = 0, ring = 0;
     int *d_status = nullptr;
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
-    uint32_t *d_mc = nullptr;              // [batch_cap][ml.words], motion-compensation work lists (k_mc_sort -> k_mc_luma / k_mc_chroma)
+    uint32_t *d_mc = nullptr;              // [batch_cap][ml.words], motion-compensation work lists (k_mc_sort -> k_mc, k_mc_second)
     McLayout ml;
     std::vector<int> stream_seen;          // p264hip_reconstruct: batch index + 1 that last named a stream in the current call
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame

@@ -1,0 +1,483 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the MI355X macroblock-reconstruction hot path.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic
+1920x1080 (coded 1920x1088, 8160 MBs) Baseline CAVLC stream, 1 IDR + P pictures only
+(the "all-P-slice" stream of the north star), written by tools/synth264.  S independent
+streams are decoded side by side on one GPU - consecutive P pictures of one stream depend on
+each other, independent streams are the parallel axis.  A *step* = one pass of the hot path
+(inter prediction + residual, intra, deblocking) over one batch = the next picture of each of
+the S streams.  All parsed inputs (the host CAVLC parse is CPU work by design) are resident in
+HBM before the timed region; every stream has its own private copy of its inputs and its own
+frame store.  The IDR picture and W P pictures are the untimed warm-up, then exactly K P
+pictures per stream are timed.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S]
+  N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+       one rank per GPU, streams sharded across ranks, no data-path collective (weak scaling).
+
+Prints ONE JSON line (rank 0).  Besides the contract's fields: `roofline` (the dominant stage), `kernels` (every stage with
+its own fraction of the HBM roofline), `cpu_baseline` (the real reference decoder on one host core, N=1 only), a
+`golden_check` (the timed output of a golden-seeded stream hashed against the committed reference hash) and `extras`
+(never `value`: config 2, config 3 I+P, the parse- and PCIe-inclusive pipeline, the single-stream drop-in API; N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MB_W, MB_H = 120, 68
+N_MB = MB_W * MB_H
+DISTINCT = 4                   # distinct synthetic streams per rank; the S streams cycle through private copies of them
+STAGE_KERNELS = {"inter": "k_mc_sort + k_mc", "intra": "k_intra",
+                 "deblock": "k_deblock_bs + k_deblock"}
+
+
+def synth_args(frames, seed):
+    return "--mbw %d --mbh %d --frames %d --gop 0 --seed %d --coded 12 --maxlevel 12 --crop-bottom 4" % (MB_W, MB_H, frames, seed)
+
+
+def algorithmic_bytes(pics):
+    """Bytes that must cross HBM once per launch, per stage (DESIGN.md 'Roofline').  The MC figure is SURVEY 8d's
+    836 B per inter macroblock (384 B reference + 64 B motion + 4 B type read, 384 B written), its read part 452 B; the residual
+    input the MC kernels also consume (16 B record + 32 B per coded block, the seam's dense block format) is reported
+    separately as `inter_with_residual` and never enters `roofline.frac`."""
+    import numpy as np
+    inter = inter_read = inter_resid = intra = deblock = 0
+    for p in pics:
+        rec = p.mb_records()
+        is_intra = rec["mb_type"] <= 2
+        blocks = np.array([bin(int(m) & 0x3ffffff).count("1") for m in rec["coef_mask"]])
+        n_inter = int((~is_intra).sum())
+        n_intra = int(is_intra.sum())
+        inter += n_inter * 836
+        inter_read += n_inter * 452
+        inter_resid += n_inter * (836 + 16) + int(blocks[~is_intra].sum()) * 32
+        # intra: 384 B written + modes (16 B) + MB record (16 B) + coded blocks
+        intra += n_intra * (384 + 32) + int(blocks[is_intra].sum()) * 32
+        # deblock: 384 B read + 384 B written + side tables (16 B record, 64 B motion, 4 B refs)
+        deblock += len(rec) * (768 + 84)
+    return {"inter": inter, "intra": intra, "deblock": deblock, "inter_read": inter_read, "inter_with_residual": inter_resid}
+
+
+def cpu_quota():
+    """CPUs this process may use: the cgroup quota where there is one (cpu.max), else the visible CPUs."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 8
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def run_batched(lib, pics, S, mb_w, mb_h, slots):
+    """All pictures of one parsed stream on S streams side by side (private clones), inputs resident: pictures/s and the
+    hash of stream S-1's last picture."""
+    from p264decoder_amd import HipReconstructor
+    from tests.conftest import frame_sha256
+    T = len(pics)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=slots, max_pictures=S * T, lib=lib)
+    hip.upload(0, pics)
+    for s in range(1, S):
+        for t in range(T):
+            hip.clone_picture(s * T + t, t)
+    hip.sync()
+    streams = list(range(S))
+    hip.reconstruct([s * T for s in streams], streams)           # the first picture once, untimed: allocations, first launches
+    hip.sync()
+    t0 = time.perf_counter()
+    for t in range(T):
+        hip.reconstruct([s * T + t for s in streams], streams)
+    hip.sync()
+    dt = time.perf_counter() - t0
+    digest = frame_sha256(*hip.read_frame(S - 1, pics[-1].desc.dst_slot))
+    hip.close()
+    return S * T / dt, digest
+
+
+def extras(lib):
+    """Figures that are NOT the metric (never `value`): the other single-GPU configurations of BASELINE.json and the
+    end-to-end rates, each on a bounded run."""
+    from p264decoder_amd import Decoder, Parser
+    from tests import synth_cases
+    from tests.conftest import frame_sha256
+    out = {}
+    # config 2: 1280x720 Baseline CAVLC, I slices only (intra + IDCT path), 10 pictures x 1024 streams (as many streams as
+    # the metric's run: with 256 the two row-wavefront kernels leave most of the chip idle - 97 k against 144 k frames/s)
+    pics = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes("cfg2_720p_intra"))[:10]
+    fps, digest = run_batched(lib, pics, 1024, 80, 45, 2)
+    out["config2_720p_intra_only"] = {"value": round(fps, 1), "unit": "frames/s", "streams": 1024, "pictures_per_stream": len(pics),
+                                       "last_picture_matches_reference": digest == synth_cases.golden("cfg2_720p_intra")[1][len(pics) - 1]}
+    # config 3 as specified: I+P, GOP 30, 60 pictures x 1024 streams
+    pics = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes("cfg3_1080p_ip"))
+    fps, digest = run_batched(lib, pics, 1024, MB_W, MB_H, 2)
+    out["config3_1080p_i_plus_p_gop30"] = {"value": round(fps, 1), "unit": "frames/s", "streams": 1024, "pictures_per_stream": len(pics),
+                                            "last_picture_matches_reference": digest == synth_cases.golden("cfg3_1080p_ip")[1][-1]}
+    # BASELINE config 4 ("next"): 1920x1088 Main profile, CABAC, I + P + B pictures (two B pictures between
+    # reference pictures, implicit weights, direct prediction); 13 pictures x 1024 streams.
+    # The reference cannot decode B pictures: the check is against the committed ORACLE hash (parity with the reference unpinned)
+    try:
+        name = "main_1080p_cabac_ipb"
+        data = open(synth_cases.generate(synth_cases.ORACLE_CASES[name]), "rb").read()
+        t0 = time.perf_counter()
+        pics = Parser(quiet=True, lib=lib).parse_stream(data)
+        parse_fps = len(pics) / (time.perf_counter() - t0)
+        fps, digest = run_batched(lib, pics, 1024, MB_W, MB_H, 3)
+        out["config4_1080p_main_cabac_ipb"] = {"value": round(fps, 1), "unit": "frames/s", "streams": 1024, "pictures_per_stream": len(pics),
+                                                "b_pictures_per_stream": sum(1 for p in pics if p.desc.slice_type == 1),
+                                                "last_picture_matches_oracle": digest == synth_cases.oracle_golden(name)[1][-1],
+                                                "cabac_parse_fps_one_thread": round(parse_fps, 1),
+                                                "what": "BASELINE config 4: 1920x1080 Main profile, CABAC, I+P+B (two B pictures between reference pictures, implicit weights, "
+                                                        "direct prediction), deblocking; reconstruction of resident inputs as in `value`.  B macroblocks take the generic "
+                                                        "two-list class of the MC kernels.  Pinned to the CPU oracle only - the reference decodes neither CABAC nor B pictures"}
+    except Exception as e:
+        out["config4_1080p_main_cabac_ipb"] = {"error": str(e)}
+    # end to end: Annex-B bytes in host memory -> pictures in HBM, host CAVLC parse and PCIe uploads included.  The parse is
+    # CPU work: what this figure can reach is set by the host cores this process may use (the cgroup CPU quota where there
+    # is one - a one-GPU share of the box is 16 CPUs), so the quota, the parse-only ceiling (device = -1: the same threads
+    # without the GPU) and the rate per parser thread are reported next to it.
+    try:
+        from p264decoder_amd import Pipeline
+        quota = cpu_quota()
+        distinct = [open(synth_cases.generate(synth_args(24, 1000 + g)), "rb").read() for g in range(4)]
+        n_streams = 128
+
+        def run(threads, device):
+            pipe = Pipeline([distinct[i % 4] for i in range(n_streams)], threads=threads, device=device, lib=lib)
+            st = pipe.run()
+            pipe.close()
+            return st
+        run(min(2 * quota, 64), 0)                             # untimed: allocations, first launches
+        best, table = None, {}
+        for threads in sorted({quota, min(2 * quota, 128)}):
+            pst, est = run(threads, -1), run(threads, 0)
+            table[str(threads)] = {"parse_only_fps": round(pst["pictures"] / pst["seconds"], 1), "end_to_end_fps": round(est["pictures"] / est["seconds"], 1),
+                                   "fps_per_parser_thread": round(est["pictures"] / est["parse_seconds"], 1)}
+            if best is None or est["pictures"] / est["seconds"] > best[1]["pictures"] / best[1]["seconds"]:
+                best = (threads, est)
+        one = Pipeline([distinct[0]], threads=1, device=-1, lib=lib)
+        st1 = one.run()
+        one.close()
+        threads, st = best
+        fps = st["pictures"] / st["seconds"]
+        out["end_to_end_pipeline"] = {"value": round(fps, 1), "unit": "frames/s", "streams": n_streams, "host_threads": threads, "cpu_quota": quota, "cpus_visible": os.cpu_count(),
+                                      "by_threads": table, "single_thread_parse_fps": round(st1["pictures"] / st1["seconds"], 1),
+                                      "upload_GBps": round(st["bytes_uploaded"] / st["seconds"] / 1e9, 2) if "bytes_uploaded" in st else None,
+                                      "what": "Annex-B in host memory -> CAVLC parse on the host threads -> pinned uploads -> batched reconstruction; pictures stay in HBM; "
+                                              "bound by the host parse: compare parse_only_fps (same threads, no GPU)"}
+    except Exception as e:                                    # never let an extra take the metric down
+        out["end_to_end_pipeline"] = {"error": str(e)}
+    # the drop-in API, one stream, picture by picture with the I420 download (p264_decoder_decode)
+    try:
+        data = synth_cases.stream_bytes("cfg3_1080p_ip")
+        dec = Decoder(lib=lib)
+        t0 = time.perf_counter()
+        n = sum(1 for _ in dec.decode_annexb(data))
+        dt = time.perf_counter() - t0
+        dec.close()
+        out["single_stream_dropin_api"] = {"value": round(n / dt, 1), "unit": "frames/s", "pictures": n,
+                                           "what": "p264_nal_decode + p264_decoder_decode per NAL, host parse, upload, reconstruction and I420 download per picture"}
+    except Exception as e:
+        out["single_stream_dropin_api"] = {"error": str(e)}
+    return out
+
+
+def fanout_leg(rank, local_rank, world, lib):
+    """BASELINE config 5 (one rank owns inputs and outputs, RCCL send / recv over xGMI): every rank starts ONE child process
+    on its GPU (python -m p264decoder_amd.tools.fan_bench) with a communicator of its own and waits for it with a time
+    limit - whatever happens in there cannot disturb the timed result above.  Rank 0 returns the root child's report."""
+    import torch.distributed as dist
+    from p264decoder_amd import fanout
+    uid = [None]
+    if rank == 0:
+        try:
+            uid[0] = fanout.rccl_unique_id(lib).hex()
+        except Exception as e:
+            uid[0] = "error: %s" % e
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0].startswith("error"):
+        return {"error": uid[0]}
+    cmd = [sys.executable, "-m", "p264decoder_amd.tools.fan_bench", "--rank", str(rank), "--world", str(world), "--transport", "rccl",
+           "--uid", uid[0], "--device", str(local_rank), "--streams", str(max(world, 8)), "--pictures", "12"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    res = {"error": "no report"}
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+        try:
+            out, err = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+            res = {"error": "rank %d: fan-out child timed out" % rank}
+        for line in out.splitlines():
+            if line.startswith("FANOUT "):
+                res = json.loads(line[7:])                 # the report, or {"error": the transport's / RCCL's own message}
+        if res.get("error") == "no report" and p.returncode not in (0, None):
+            res = {"error": "rank %d: child exited with %s: %s" % (rank, p.returncode, err.strip().splitlines()[-1] if err.strip() else "")}
+    except Exception as e:                                    # noqa: BLE001
+        res = {"error": "rank %d: %r" % (rank, e)}
+    # the root's report plus whatever the other ranks have to say (a worker's RCCL error is the interesting one when the
+    # root only sees a time-out)
+    every = [None] * world
+    dist.all_gather_object(every, res)
+    if rank == 0:
+        worker_errors = [r["error"] for r in every[1:] if isinstance(r, dict) and r.get("error")]
+        if worker_errors:
+            res = dict(res, worker_errors=worker_errors)
+    return res
+
+
+def cpu_baseline(stream_path, n_pictures):
+    """The reference's own CPU path on the host cores of this box, 1 core (it is single-threaded),
+    on a bounded sample of the same workload.  kind = "reference" when oracle/_ref (the real
+    reference, built in the build container) travelled with the repo, else "port" (our oracle)."""
+    driver = os.path.join(ROOT, "oracle", "_ref", "p264ref_driver")
+    if os.path.exists(driver):
+        loops = 25                                          # ~12 s of single-core work at ~50 frames/s
+        try:
+            out = subprocess.run([driver, "time", stream_path, str(loops)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 text=True, timeout=600).stdout.split()
+            return {"value": round(float(out[out.index("fps") + 1]), 3), "unit": "frames/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model(),
+                    "includes_parse": True,
+                    "note": "the reference cannot reconstruct without parsing: this rate includes its CAVLC parse (12-14 % of its time, SURVEY 6), "
+                            "`value` (inputs resident in HBM) does not - compare with extras.end_to_end_pipeline for parse-inclusive rates",
+                    "sample": "%d-picture 1920x1088 all-P stream decoded %dx by the reference decoder (parse + reconstruction)" % (n_pictures, loops)}
+        except Exception:
+            pass
+    from p264decoder_amd import Parser
+    from tests import oracle_bind
+    ora = oracle_bind.load()
+    pics = Parser(quiet=True).parse_stream(open(stream_path, "rb").read())
+    store = oracle_bind.FrameStore(MB_W, MB_H, 2)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < 12.0:
+        for p in pics:
+            oracle_bind.reconstruct(ora, store, p)
+            n += 1
+    return {"value": round(n / (time.time() - t0), 3), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(), "includes_parse": False,
+            "sample": "%d 1920x1088 pictures through the scalar oracle (reconstruction only, parse excluded)" % n}
+
+
+def measured_copy_bandwidth(torch):
+    """Achievable HBM ceiling on this box next to the 8 TB/s vendor peak: device-to-device copy of 1 GiB,
+    bytes read + bytes written per second."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    a.fill_(1)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbps = 2.0 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    return round(gbps, 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=1024, help="independent 1080p streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
+    ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0)")
+    args = ap.parse_args()
+
+    import torch
+    from p264decoder_amd import shard
+    rank, local_rank, world = shard.env_rank()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the reconstruction path")
+    # (rehearsal knobs for a box with fewer GPUs than ranks: P264AMD_BENCH_DEVICE pins every rank to one GPU,
+    # P264AMD_BENCH_BACKEND=gloo replaces RCCL for the barrier and the clock; the driver's runs use neither)
+    if os.environ.get("P264AMD_BENCH_DEVICE"):
+        local_rank = int(os.environ["P264AMD_BENCH_DEVICE"])
+    backend = os.environ.get("P264AMD_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank)
+    shard.init(backend, torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm; barrier + clock only
+
+    from p264decoder_amd import HipReconstructor, Parser, _native
+    from tests import synth_cases
+    lib = _native.load()
+
+    S, K, Wm = args.streams, args.steps, args.warmup
+    T = 1 + Wm + K                                        # pictures per stream: IDR + warm-up + timed
+    # ---- set-up (untimed): write + parse DISTINCT streams, make every stream's inputs resident ----
+    # Stream 0 of every rank is the golden all-P stream (tests/golden/synth_cfg3_1080p_allp.sha256: per-picture hashes of
+    # the REAL reference decoder) as long as it is long enough: its timed output is checked against those hashes below.
+    golden_case = "cfg3_1080p_allp" if T <= 30 else "cfg3_1080p_allp_300"      # (the same stream, 30 / 300 pictures of it)
+    golden_hashes = synth_cases.golden(golden_case)[1]
+    use_golden = T <= len(golden_hashes)
+    synth_extra = os.environ.get("P264AMD_BENCH_SYNTH_EXTRA", "")     # experiments only (e.g. "--mvmax 0"): no golden stream then
+    if synth_extra:
+        use_golden = False
+    paths, parsed = [], []
+    for g in range(DISTINCT):
+        path = synth_cases.generate(golden_case) if (g == 0 and use_golden) else synth_cases.generate(synth_args(T, 1000 + 16 * rank + g) + (" " + synth_extra if synth_extra else ""))
+        paths.append(path)
+        pics = Parser(quiet=True, lib=lib).parse_stream(open(path, "rb").read(), limit=T)
+        assert len(pics) == T and all(p.desc.slice_type == 0 for p in pics[1:])
+        parsed.append(pics)
+    hip = HipReconstructor(MB_W, MB_H, n_streams=S, slots=2, max_pictures=S * T, device=local_rank, lib=lib)
+    for s in range(min(S, DISTINCT)):
+        hip.upload(s * T, parsed[s])
+    for s in range(DISTINCT, S):
+        for t in range(T):
+            hip.clone_picture(s * T + t, (s % DISTINCT) * T + t)
+    hip.sync()
+    streams = list(range(S))
+
+    def step(t):
+        hip.reconstruct([s * T + t for s in streams], streams)
+
+    for t in range(1 + Wm):                               # IDR + W P pictures
+        step(t)
+    hip.sync()
+    hip.timing_enable(os.environ.get('NOTIMING') is None)
+    hip.timing_reset()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(1 + Wm, T):
+        step(t)
+    hip.sync()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
+    timing = hip.timing_read()
+    hip.timing_enable(False)
+    if os.environ.get('NOTIMING'):
+        print('timing off: %.4f ms per step' % (elapsed / (T - 1 - Wm) * 1e3)); return
+
+    # ---- the timed output against the real reference decoder: the last picture of stream 0 and of its last clone must
+    #      hash to what the reference produced for that picture of the golden stream (committed fixture) ----
+    from tests.conftest import frame_sha256
+    last = parsed[0][-1].desc.dst_slot
+    golden_check = {"stream": golden_case, "picture": T - 1, "checked": False}
+    if use_golden:
+        clone = S - 1 - (S - 1) % DISTINCT                  # the last stream that decodes stream 0's pictures
+        for s in sorted({0, clone}):
+            got = frame_sha256(*hip.read_frame(s, last))
+            if got != golden_hashes[T - 1]:
+                raise SystemExit("bench.py: stream %d picture %d differs from the reference decoder (%s != %s)" % (s, T - 1, got[:16], golden_hashes[T - 1][:16]))
+        golden_check.update(checked=True, streams_checked=sorted({0, clone}), sha256=golden_hashes[T - 1][:16] + "...",
+                            source="tests/golden/synth_%s.sha256 (oracle/_ref, the real reference decoder)" % golden_case)
+
+    copy_gbps = measured_copy_bandwidth(torch) if rank == 0 else None
+    if rank == 0:
+        frames = S * K * world
+        fps = frames / elapsed
+        alg = algorithmic_bytes([parsed[s % DISTINCT][t] for s in streams for t in (T - 1,)])   # one representative step
+        kernels = {}
+        for name in ("inter", "intra", "deblock"):
+            ms, cnt = timing[name]
+            if cnt:
+                avg = ms / cnt
+                gbps = alg[name] / (avg * 1e-3) / 1e9
+                kernels[name] = {"kernels": STAGE_KERNELS[name], "avg_ms": round(avg, 4), "launches": int(cnt), "algorithmic_bytes": alg[name],
+                                 "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4)}
+                if name == "inter":                       # the read-only fraction (452 B/MB) and, separately, the figure with the residual input
+                    kernels[name]["bytes_per_inter_mb"] = 836
+                    kernels[name]["frac_read"] = round(alg["inter_read"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    kernels[name]["algorithmic_bytes_with_residual"] = alg["inter_with_residual"]
+                    kernels[name]["frac_with_residual"] = round(alg["inter_with_residual"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+
+        def traffic_of(stage):
+            """HBM traffic cannot be counted inside this run (PMC counters need rocprofv3 passes of their own): it is replayed
+            from the committed summary of the same command profiled on the same code (profiles/collect.sh), and says so."""
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if not os.path.exists(tpath):
+                return None, None
+            try:
+                tj = json.load(open(tpath))
+                if S == int(tj.get("pictures_per_launch", 1024)):              # (counted for the default batch: scaled to nothing else)
+                    return tj.get(stage), "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
+                return None, "none: profiles/%s was collected at %d pictures per launch, this run has %d" % (tj.get("source"), int(tj.get("pictures_per_launch", 1024)), S)
+            except Exception:
+                return None, None
+
+        def roofline_of(stage):
+            traffic, traffic_source = traffic_of(stage)
+            r = {"kernel": STAGE_KERNELS[stage], "stage": stage, "bound": "hbm", "achieved": kernels[stage]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(kernels[stage]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_source,
+                 "algorithmic_bytes_per_launch": kernels[stage]["algorithmic_bytes"], "avg_ms": kernels[stage]["avg_ms"], "measured_copy_GBps": copy_gbps}
+            if traffic:
+                r["traffic_over_algorithmic"] = round(traffic / kernels[stage]["algorithmic_bytes"], 3)
+            if stage == "inter":
+                r["bytes_per_inter_mb"] = 836
+                r["frac_read"] = kernels[stage]["frac_read"]
+                r["frac_with_residual"] = kernels[stage]["frac_with_residual"]
+                if traffic:
+                    r["traffic_over_algorithmic_with_residual"] = round(traffic / kernels[stage]["algorithmic_bytes_with_residual"], 3)
+            return r
+        out = {
+            "metric": "1080p decoded frames/sec", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 1920x1080 (coded 1920x1088) Baseline CAVLC all-P stream (1 IDR + P), "
+                                   "reconstruction hot path (MC + residual, intra, deblock), parsed inputs resident in HBM",
+                       "streams_per_gpu": S, "pictures_per_step": S * world, "mb_per_picture": N_MB, "parallelism": "stream-parallel x%d" % world},
+            "macroblocks_per_s": round(fps * N_MB, 0),
+            # `roofline` = the stage that takes longest (the contract's "dominant kernel"); `roofline_mc` = the motion-compensation
+            # stage, which the north star names, whichever is longer
+            "roofline": roofline_of(dom),
+            "roofline_mc": roofline_of("inter") if "inter" in kernels else None,
+            "kernels": kernels,
+            "reconstruct_call_ms": round(timing["reconstruct"][0] / max(timing["reconstruct"][1], 1), 4),
+            "golden_check": golden_check,
+        }
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: a reported baseline, not part of the scaling runs
+            out["cpu_baseline"] = cpu_baseline(paths[0], T)
+    hip.close()
+    fan = None
+    if world > 1 and not args.no_fanout and os.environ.get("P264AMD_BENCH_FANOUT", "1") != "0":
+        fan = fanout_leg(rank, local_rank, world, lib)       # after the timed region, in child processes, never `value`
+    if rank == 0:
+        if not args.no_extras and world == 1:
+            out["extras"] = extras(lib)
+        if fan is not None:
+            out.setdefault("extras", {})["fanout_config5"] = fan
+        print(json.dumps(out), flush=True)
+    shard.barrier()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,7 +68,7 @@ def test_mc_launch_knobs(lib, oracle, band_log2, wgs, concurrent, monkeypatch):
 def test_vectors_far_outside_the_picture(lib, oracle):
     """Windows that lie entirely outside the picture (vectors of +-100 pixels on a 160x128 picture): beyond the
     reference's 32-pixel pads its behaviour is undefined (SURVEY A-Q9), so this is HIP against the oracle's clamped
-    coordinates only - it exercises the replicated-border dwords of k_inter on all four sides."""
+    coordinates only - it exercises the replicated-border dwords of the motion-compensation kernel on all four sides."""
     parser = Parser(quiet=True, lib=lib)
     pics = parser.parse_stream(open(synth_cases.generate("--mbw 10 --mbh 8 --frames 6 --gop 6 --seed 29 --mvmax 400 --coded 5 --maxlevel 6"), "rb").read())
     mb_w, mb_h = pics[0].mb_w, pics[0].mb_h

@@ -49,3 +49,33 @@ def test_b_stream_through_the_dropin_api(lib):
     for i, (g, w) in enumerate(zip(got, want)):
         for plane, (a, b) in enumerate(zip(g, w)):
             assert np.array_equal(a[:b.shape[0], :b.shape[1]], b), "picture %d plane %d" % (i, plane)
+
+
+def test_mixed_slice_types_in_one_batch(lib, oracle):
+    """One reconstruct call with I, P and B pictures side by side (two streams of the same Main-profile sequence, the second one
+    picture behind): the B-capable sort, the second motion-compensation pass and the two-list bS derivation run for the
+    whole batch as soon as ONE picture is a B picture, and must leave the others as they are."""
+    from tests import oracle_bind
+    args = "--mbw 11 --mbh 9 --frames 13 --seed 57 --refs 2 --bframes 2 --implicit --d8inf --coded 14 --maxlevel 10"
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(open(synth_cases.generate(args), "rb").read())
+    types = [p.desc.slice_type for p in pics]
+    assert {0, 1, 2} <= set(types)
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+    want = [[a.copy() for a in oracle_bind.reconstruct(oracle, store, p)] for p in pics]
+    hip = HipReconstructor(mb_w, mb_h, n_streams=2, slots=parser.slots, max_pictures=len(pics), lib=lib)
+    hip.upload(0, pics)
+    mixed = 0
+    for i in range(len(pics) + 1):
+        ids, streams = [], []
+        if i < len(pics): ids.append(i); streams.append(0)
+        if i >= 1: ids.append(i - 1); streams.append(1)
+        mixed += len({types[k] for k in ids}) > 1
+        hip.reconstruct(ids, streams)
+        for k, s in zip(ids, streams):
+            got = hip.read_frame(s, pics[k].desc.dst_slot)
+            for plane, (a, b) in enumerate(zip(got, want[k])):
+                assert np.array_equal(a, b), "batch %d: picture %d (type %d) of stream %d, plane %d" % (i, k, types[k], s, plane)
+    assert mixed >= 6
+    hip.close()

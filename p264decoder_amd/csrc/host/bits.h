@@ -77,9 +77,12 @@ static inline uint32_t br_ue(bitrd_t *b)
      * buffer it is zero-padded, so a truncated code reads as "32 zeros" and is rejected by the callers' range checks) */
     const uint32_t w = br_peek(b, 32);
     const int zeros = w ? __builtin_clz(w) : 32;
+    if (zeros <= 15) {                   /* the whole code (2 * zeros + 1 bits) is inside the peeked word: one step */
+        br_skip(b, 2 * zeros + 1);
+        return (w >> (31 - 2 * zeros)) - 1u;
+    }
     br_skip(b, zeros);
     br_skip(b, 1);                       /* the terminating 1 */
-    if (zeros == 0) return 0;
     if (zeros >= 32) return 0xffffffffu;
     return ((1u << zeros) - 1u) + br_u(b, zeros);
 }

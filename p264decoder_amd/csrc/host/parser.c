@@ -597,12 +597,18 @@ typedef struct { int ref, mvx, mvy; } nbmv_t;      /* ref: -2 unavailable, -1 in
 static nbmv_t nb_motion_l(const p264parse *p, int x4, int y4, int list)
 {
     nbmv_t r = { -2, 0, 0 };
-    if (x4 < 0 || y4 < 0) return r;
-    int mx = x4 >> 2, my = y4 >> 2;
-    if (mx >= p->mb_w || my >= p->mb_h) return r;
-    int i = my * p->mb_w + mx, sub = (y4 & 3) * 4 + (x4 & 3);
-    if (i == p->mbi) { if (!(((list ? p->mv_done1 : p->mv_done) >> sub) & 1)) return r; }
-    else if (!(i < p->mbi && p->slice_of[i] == (uint16_t)p->slice_no)) return r;
+    /* where the block lies relative to the current macroblock decides everything: inside it - decoded so far or not; in the
+     * left / top / top-right / top-left neighbour - that macroblock's availability (begin_mb); anywhere else - not decoded yet */
+    const int dx = x4 - p->mbx * 4, dy = y4 - p->mby * 4, sub = (y4 & 3) * 4 + (x4 & 3);
+    int i;
+    if (dy >= 0) {
+        if (dx >= 0) { if (dx >= 4 || dy >= 4 || !(((list ? p->mv_done1 : p->mv_done) >> sub) & 1)) return r; i = p->mbi; }
+        else { if (dy >= 4 || !(p->cur_avail & P264_AVAIL_LEFT)) return r; i = p->mbi - 1; }
+    } else {
+        if (dx < 0)      { if (!(p->cur_avail & P264_AVAIL_TOPLEFT)) return r;  i = p->mbi - p->mb_w - 1; }
+        else if (dx < 4) { if (!(p->cur_avail & P264_AVAIL_TOP)) return r;      i = p->mbi - p->mb_w; }
+        else             { if (dx >= 8 || !(p->cur_avail & P264_AVAIL_TOPRIGHT)) return r; i = p->mbi - p->mb_w + 1; }
+    }
     const picbuf_t *q = &p->buf[p->cur];
     const int8_t *ref = list ? q->ref1 : q->ref; const int16_t *mv = list ? q->mv1 : q->mv;
     r.ref = ref[i * 4 + ((y4 & 2) | ((x4 >> 1) & 1))];     /* -1: intra, or (B pictures) this list is not used there */
@@ -636,6 +642,14 @@ static void set_motion_l(p264parse *p, int bx, int by, int bw, int bh, int mvx, 
 {
     picbuf_t *q = &p->buf[p->cur];
     int16_t *mv = list ? q->mv1 : q->mv;
+    if (bw == 4 && bh == 4) {                                   /* the whole macroblock: sixteen equal vectors, eight 8-byte stores */
+        const uint32_t one = (uint32_t)(uint16_t)mvx | (uint32_t)(uint16_t)mvy << 16;
+        const uint64_t two = (uint64_t)one | (uint64_t)one << 32;
+        int16_t *d = mv + (size_t)p->mbi * 32;
+        for (int k = 0; k < 8; k++) memcpy(d + 4 * k, &two, 8);
+        if (list) p->mv_done1 = 0xffffu; else p->mv_done = 0xffffu;
+        return;
+    }
     for (int y = by; y < by + bh; y++)
         for (int x = bx; x < bx + bw; x++) {
             mv[(p->mbi * 16 + y * 4 + x) * 2] = (int16_t)mvx;
@@ -707,7 +721,6 @@ static int parse_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *c
     uint8_t *nnz = p->nnz + (size_t)p->mbi * 24;
     int cbp_l = m->cbp & 15, cbp_c = m->cbp >> 4, tc;
     if (m->mb_type == P264_MB_I16x16) {
-        memset(cf->dc_luma, 0, sizeof cf->dc_luma);
         if ((tc = cavlc_read_block(b, predict_nc(p, 0), 16, cf->dc_luma)) < 0) return -1;
         if (tc) cf->mask |= P264_COEF_LUMA_DC;
     }
@@ -715,7 +728,6 @@ static int parse_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *c
     for (int i = 0; i < 16; i++) {
         nnz[i] = 0;
         if (!(cbp_l & (1 << (i >> 2)))) continue;
-        memset(cf->blk[i], 0, sizeof cf->blk[i]);
         if ((tc = cavlc_read_block(b, predict_nc(p, i), maxc, cf->blk[i])) < 0) return -1;
         nnz[i] = (uint8_t)tc;
         if (tc) cf->mask |= 1u << i;
@@ -730,7 +742,6 @@ static int parse_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *c
     for (int i = 16; i < 24; i++) {
         nnz[i] = 0;
         if (!(cbp_c & 2)) continue;
-        memset(cf->blk[i], 0, sizeof cf->blk[i]);
         if ((tc = cavlc_read_block(b, predict_nc(p, i), 15, cf->blk[i])) < 0) return -1;
         nnz[i] = (uint8_t)tc;
         if (tc) cf->mask |= 1u << i;

@@ -122,13 +122,16 @@ int cavlc_read_block(bitrd_t *b, int nC, int max_coeff, int16_t *out)
 
     int level[16];
     int suffix_len = (tc > 10 && t1 < 3) ? 1 : 0;
-    for (int i = 0; i < t1; i++) level[i] = br_u1(b) ? -1 : 1;
+    if (t1) {                                               /* the trailing ones' signs, all at once */
+        const uint32_t sg = br_u(b, t1);
+        for (int i = 0; i < t1; i++) level[i] = ((sg >> (t1 - 1 - i)) & 1) ? -1 : 1;
+    }
     for (int i = t1; i < tc; i++) {
         const uint32_t w = br_peek(b, 32);                  /* level_prefix: zeros up to the first 1, counted in one step */
         const int prefix = w ? __builtin_clz(w) : 32;
-        br_skip(b, prefix);
+        if (prefix >= 32) return -1;                        /* (no level prefix is that long: a truncated or broken stream) */
+        br_skip(b, prefix + 1);
         if (br_overrun(b)) return -1;
-        br_skip(b, 1);
         int sufbits = suffix_len;
         if (prefix == 14 && suffix_len == 0) sufbits = 4;
         else if (prefix >= 15) sufbits = prefix - 3;
@@ -148,9 +151,11 @@ int cavlc_read_block(bitrd_t *b, int nC, int max_coeff, int16_t *out)
         if (z < 0) return -1;
         zeros_left = z;
     }
-    /* levels were read from the highest frequency down: place them */
+    /* levels were read from the highest frequency down: place them (the block is cleared here, not by the caller: most
+     * calls find an empty block and never get this far) */
     int pos = zeros_left + tc - 1;
     if (pos >= max_coeff) return -1;
+    memset(out, 0, (size_t)(max_coeff == 4 ? 4 : 16) * sizeof *out);     /* (AC blocks: the unused sixteenth entry too - the block is stored whole) */
     for (int i = 0; i < tc; i++) {
         out[pos] = (int16_t)level[i];
         if (i == tc - 1) break;

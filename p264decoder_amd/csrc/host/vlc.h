@@ -35,8 +35,8 @@ static inline int vlc_get(bitrd_t *b, const vlc_t *v)
 int cavlc_global_init(void);
 
 /* Read one residual block.  nC: predicted number of coefficients, or -1 for chroma DC.
- * max_coeff: 16 (full 4x4 / luma DC), 15 (AC), 4 (chroma DC).  out[] must be zeroed by the
- * caller (max_coeff entries); levels are written at their scan positions.
+ * max_coeff: 16 (full 4x4 / luma DC), 15 (AC), 4 (chroma DC).  When the block has coefficients, out[0 .. 16) (chroma DC: out[0 .. 4)) is
+ * cleared and the levels are written at their scan positions; an empty block leaves out[] untouched.
  * Returns total_coeff (0..16) or -1 on a broken stream. */
 int cavlc_read_block(bitrd_t *b, int nC, int max_coeff, int16_t *out);
 

@@ -59,7 +59,7 @@ def build(force=False, verbose=False):
         src = os.path.join(HOST_DIR, s)
         obj = os.path.join(OBJ_DIR, s + ".o")
         if force or _newer(obj, [src] + hdrs):
-            out = _run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-I" + INC, "-I" + HOST_DIR, "-c", src, "-o", obj])
+            out = _run(["gcc", "-O3", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-I" + INC, "-I" + HOST_DIR, "-c", src, "-o", obj])
             if verbose and out:
                 print(out)
         objs.append(obj)

@@ -352,7 +352,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     const int r = c->ring; c->ring = (c->ring + 1) % BATCH_RING;
     HIPCHK(hipEventSynchronize(c->batch_free[r]));            // the copy that last used this staging buffer is done
     PicDev *hb = c->h_batch[r];
-    bool any_p = false, any_b = false;                      // any picture with inter macroblocks / any B picture
+    bool any_p = false, any_b = false, any_i = false;       // any picture with inter macroblocks / any B picture / any I picture
     for (int i = 0; i < n; i++) {                          // two pictures of one call must not share a stream: they would race on its frames
         const int st = streams[i];
         if (st < 0 || st >= c->n_streams) return fail(P264HIP_EINVAL, "stream %d out of range", st);
@@ -391,6 +391,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
             any_b = true;
         }
         any_p |= s.meta.slice_type != P264_SLICE_I;
+        any_i |= s.meta.slice_type == P264_SLICE_I;
     }
     ScopedStamp whole(c, 3);
     HIPCHK(hipMemcpyAsync(c->d_batch[r], hb, (size_t)n * sizeof(PicDev), hipMemcpyHostToDevice, c->stream));
@@ -442,7 +443,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         if (c->tune_intra_waves >= 1 && c->tune_intra_waves <= INTRA_ROW_WAVES) intra_waves = c->tune_intra_waves;
         // luma and chroma of a picture are independent chains: as two workgroups they run side by side (the kernel is bound by
         // the latency of the macroblock-to-macroblock chain, not by arithmetic)
-        hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status);
+        if (any_i) hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status);
+        else hipLaunchKernelGGL(k_intra_sparse, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status);
     }
     {
         ScopedStamp t(c, 2);

@@ -394,6 +394,10 @@ __device__ __forceinline__ void intra_chroma4(const PicDev *pd, const Geom &g, I
 // P / B pictures: intra macroblocks without an intra neighbour to the left or above depend on nothing this kernel writes.
 // They are collected first (two lists, by macroblock type, so that the four macroblocks of an iteration run the same code)
 // and reconstructed four at a time in any order; only the rest goes through the ordered band walk below.
+#ifndef INTRA_ROUNDS
+#define INTRA_ROUNDS     2          // rounds of ready macroblocks before the ordered band walk takes what is left (measured on the
+                                    // bench stream: 1 / 2 / 3 and more rounds 0.46 / 0.33 / 0.37 ms per launch)
+#endif
 #define INTRA_FREE_CAP   256        // entries per list (uint16 macroblock index); macroblocks beyond it stay in the band walk
 #define INTRA_MASKS      160        // pictures of up to this many row windows (rows x windows of 64 macroblocks): 1080p has 136
 struct IntraSync { int progress[MAX_MB_ROWS / INTRA_BAND + 1]; };            // per band: columns of its last row that are final
@@ -444,74 +448,82 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
             for (int j = 0; j < 4; j++) { const unsigned long long m = __ballot(in[j]); if (w0 + j < n_win && lane == 0) m_intra[w0 + j] = m; }
         }
         __syncthreads();
-        // ---- pass 2: free = no intra macroblock to the left, above-left, above, above-right (mask arithmetic); the free ones go
-        //      to the list of their type, the rest (and what the lists cannot take) is left to the band walk ----
-        for (int w = wave; w < n_win; w += n_waves) {
-            const int row = w / wins, win = w - row * wins;
-            const unsigned long long m = m_intra[w];
-            if (m == 0) { if (lane == 0) m_walk[w] = 0; continue; }
-            unsigned long long blocked = m << 1;
-            if (win > 0) blocked |= m_intra[w - 1] >> 63;
-            if (row > 0) {
-                const unsigned long long u = m_intra[w - wins];
-                blocked |= u | u << 1 | u >> 1;
-                if (win > 0) blocked |= m_intra[w - wins - 1] >> 63;
-                if (win + 1 < wins) blocked |= m_intra[w - wins + 1] << 63;
-            }
-            const unsigned long long fr = m & ~blocked;
-            unsigned long long taken = 0;
-            if (fr) {
-                const int mbi = row * g.mb_w + win * 64 + lane;
-                const bool mine = (fr >> lane) & 1;
-                int type = 0;
-                if (mine) type = glob(pd->mb)[mbi].mb_type;
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const bool me = mine && (type == P264_MB_I16x16) == (t == 1);
-                    const unsigned long long mt = __ballot(me);
-                    if (mt == 0) continue;
-                    int at = 0;
-                    if (lane == 0) at = atomicAdd(&free_n[t], __popcll(mt));
-                    at = rfl(at) + __popcll(mt & ((1ull << lane) - 1ull));
-                    const bool put = me && at < INTRA_FREE_CAP;
-                    if (put) free_list[t][at] = (uint16_t)mbi;
-                    taken |= __ballot(put);
-                }
-            }
-            if (lane == 0) m_walk[w] = m & ~taken;
-        }
-        __syncthreads();
-        // ---- reconstruct the listed macroblocks, four per iteration; the records of the next four are requested a round ahead ----
+        // ---- rounds: the macroblocks of m_intra are PENDING.  Ready = no pending macroblock to the left, above-left, above,
+        //      above-right (mask arithmetic); the ready ones go to the list of their type (what the lists cannot take stays
+        //      pending), are reconstructed four per iteration in any order, and leave the pending set.  Round 0 takes every
+        //      macroblock without an intra neighbour (85 % in the bench stream), the next rounds peel the small clusters layer by
+        //      layer; what is still pending after INTRA_ROUNDS rounds (large intra areas) is left to the ordered band walk. ----
         const uint32_t inv_mbw = 0xffffffffu / (uint32_t)g.mb_w;
 #pragma unroll 1
-        for (int t = 0; t < 2; t++) {
-            const int n = min(free_n[t], INTRA_FREE_CAP);
-            int k = wave * 4;
-            int mbi = k + grp < n ? (int)free_list[t][k + grp] : 0;
-            uint4 rec = gload4(pd->mb + mbi);
-#ifdef INTRA_EXP_SKIP_A
-            k = n;
-#endif
-            while (k < n) {
-                const bool active = k + grp < n;
-                const int kn = k + n_waves * 4;
-                const int mbi_n = kn + grp < n ? (int)free_list[t][kn + grp] : 0;
-                const uint4 rec_n = gload4(pd->mb + mbi_n);
-                int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
-                if (mbi - mby * g.mb_w >= g.mb_w) mby++;
-                const int mbx = mbi - mby * g.mb_w;
-                if (active) {
-                    if (chroma_role) intra_chroma4(pd, g, L, mbx, mby, rec, l);
-                    else             intra_luma4(pd, g, L, lut, mbx, mby, rec, l);
+        for (int round = 0; round < INTRA_ROUNDS; round++) {
+            for (int w = wave; w < n_win; w += n_waves) {
+                const int row = w / wins, win = w - row * wins;
+                const unsigned long long m = m_intra[w];
+                if (m == 0) { if (lane == 0) m_walk[w] = 0; continue; }
+                unsigned long long blocked = m << 1;
+                if (win > 0) blocked |= m_intra[w - 1] >> 63;
+                if (row > 0) {
+                    const unsigned long long u = m_intra[w - wins];
+                    blocked |= u | u << 1 | u >> 1;
+                    if (win > 0) blocked |= m_intra[w - wins - 1] >> 63;
+                    if (win + 1 < wins) blocked |= m_intra[w - wins + 1] << 63;
                 }
-                k = kn; mbi = mbi_n; rec = rec_n;
+                const unsigned long long fr = m & ~blocked;
+                unsigned long long taken = 0;
+                if (fr) {
+                    const int mbi = row * g.mb_w + win * 64 + lane;
+                    const bool mine = (fr >> lane) & 1;
+                    int type = 0;
+                    if (mine) type = glob(pd->mb)[mbi].mb_type;
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const bool me = mine && (type == P264_MB_I16x16) == (t == 1);
+                        const unsigned long long mt = __ballot(me);
+                        if (mt == 0) continue;
+                        int at = 0;
+                        if (lane == 0) at = atomicAdd(&free_n[t], __popcll(mt));
+                        at = rfl(at) + __popcll(mt & ((1ull << lane) - 1ull));
+                        const bool put = me && at < INTRA_FREE_CAP;
+                        if (put) free_list[t][at] = (uint16_t)mbi;
+                        taken |= __ballot(put);
+                    }
+                }
+                if (lane == 0) m_walk[w] = taken;              // (this round's share; the pending set changes behind the barrier)
             }
+            __syncthreads();
+            const int n0 = min(free_n[0], INTRA_FREE_CAP), n1 = min(free_n[1], INTRA_FREE_CAP);
+            if (n0 + n1 == 0) break;                           // (scalar: nothing was ready - nothing is pending)
+            // ---- reconstruct the listed macroblocks; the records of the next four are requested a round trip ahead ----
+#pragma unroll 1
+            for (int t = 0; t < 2; t++) {
+                const int n = t ? n1 : n0;
+                int k = wave * 4;
+                int mbi = k + grp < n ? (int)free_list[t][k + grp] : 0;
+                uint4 rec = gload4(pd->mb + mbi);
+                while (k < n) {
+                    const bool active = k + grp < n;
+                    const int kn = k + n_waves * 4;
+                    const int mbi_n = kn + grp < n ? (int)free_list[t][kn + grp] : 0;
+                    const uint4 rec_n = gload4(pd->mb + mbi_n);
+                    int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+                    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+                    const int mbx = mbi - mby * g.mb_w;
+                    if (active) {
+                        if (chroma_role) intra_chroma4(pd, g, L, mbx, mby, rec, l);
+                        else             intra_luma4(pd, g, L, lut, mbx, mby, rec, l);
+                    }
+                    k = kn; mbi = mbi_n; rec = rec_n;
+                }
+            }
+            // their samples are neighbours of what is still pending: stores drained, then the sets updated
+            __syncthreads();
+            for (int w = threadIdx.x; w < n_win; w += blockDim.x) m_intra[w] &= ~m_walk[w];
+            if (threadIdx.x < 2) free_n[threadIdx.x] = 0;
+            __syncthreads();
         }
-        __syncthreads();                                       // (their samples are neighbours of the macroblocks below)
+        for (int w = threadIdx.x; w < n_win; w += blockDim.x) m_walk[w] = m_intra[w];       // the band walk's share
+        __syncthreads();
     }
-#ifdef INTRA_EXP_SKIP_WALK
-    if (use_free) return;
-#endif
     for (int band = wave; band < n_bands; band += n_waves) {
         const int R0 = band * INTRA_BAND;
         const bool feeds = R0 + INTRA_BAND < g.mb_h;          // a band below reads this band's last row

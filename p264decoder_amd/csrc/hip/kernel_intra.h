@@ -646,7 +646,10 @@ void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
     __shared__ IntraShared sh;
     intra_picture(sh, pics, g, status);
 }
-__global__ __launch_bounds__(INTRA_ROW_WAVES * 64, 8)
+#ifndef INTRA_SPARSE_WAVES_PER_EU
+#define INTRA_SPARSE_WAVES_PER_EU 8
+#endif
+__global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_SPARSE_WAVES_PER_EU)
 void k_intra_sparse(const PicDev *__restrict__ pics, Geom g, int *status)
 {
     __shared__ IntraShared sh;

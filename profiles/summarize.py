@@ -34,7 +34,7 @@ pmc = {}
 for k, ctrs in agg.items():
     pmc[k] = {}
     for c, v in ctrs.items():
-        vals = v[1:] if not k.startswith("k_mc") and len(v) > 1 else v
+        vals = v[1:] if not k.startswith("k_mc") and k != "k_intra_sparse" and len(v) > 1 else v
         pmc[k][c] = round(sum(vals) / len(vals))
     pmc[k]["launches_averaged"] = len(vals)
 note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
@@ -48,7 +48,8 @@ def hbm(k):
     return int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
 def hbm_any(prefix):
     return sum(hbm(k) for k in pmc if k == prefix or k.startswith(prefix + "<") or k.startswith(prefix + "_"))
-traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra"), "deblock": hbm_any("k_deblock"),
+# (the bench's P launches run k_intra_sparse; k_intra itself only sees the all-intra IDR launch of the warm-up)
+traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra_sparse" if "k_intra_sparse" in pmc else "k_intra"), "deblock": hbm_any("k_deblock"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
 traffic["pictures_per_launch"] = 1024          # bench.py's default batch, which collect.sh profiles
 json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)

@@ -13,14 +13,21 @@ void p264cabac_init_contexts(p264cabac_t *c, int is_i_slice, int cabac_init_idc,
         pre = pre < 1 ? 1 : pre > 126 ? 126 : pre;
         c->state[i] = pre <= 63 ? (uint8_t)((63 - pre) << 1) : (uint8_t)((pre - 64) << 1 | 1);
     }
+    /* state transitions (9.3.3.2.1.1) on the packed state byte: MPS -> transIdxMPS = min(pStateIdx + 1, 62); LPS -> table 9-45,
+     * and at pStateIdx 0 the MPS flips */
+    for (int s = 0; s < 128; s++) {
+        const int idx = s >> 1, mps = s & 1;
+        c->next[s][0] = (uint8_t)((idx < 62 ? idx + 1 : 62) << 1 | mps);
+        c->next[s][1] = (uint8_t)(cabac_trans_lps[idx] << 1 | (idx == 0 ? mps ^ 1 : mps));
+    }
 }
 
 void p264cabac_start(p264cabac_t *c, const uint8_t *data, size_t bytes)
 {
-    c->p = data; c->end = data + bytes;
-    c->cache = 0; c->cache_bits = 0; c->bits_left = (int64_t)bytes * 8;
+    c->data = data; c->size = bytes; c->pos = 0;
+    c->low = 0; c->n = -9;                                 /* the first refill leaves codIOffset = the first 9 bits, 23 bits behind it */
     c->range = 510;
-    c->offset = p264cabac_bits(c, 9);
+    p264cabac_refill(c);
 }
 
 int p264cabac_decode_ops(const uint8_t *data, size_t bytes, int is_i_slice, int cabac_init_idc, int slice_qp,
@@ -35,5 +42,5 @@ int p264cabac_decode_ops(const uint8_t *data, size_t bytes, int is_i_slice, int 
         if (op >= P264_CABAC_CONTEXTS || op < -2) return -1;
         bins[i] = (uint8_t)(op >= 0 ? p264cabac_decision(&c, op) : op == -1 ? p264cabac_bypass(&c) : p264cabac_terminate(&c));
     }
-    return c.bits_left < 0 ? 1 : 0;
+    return p264cabac_bits_left(&c) < 0 ? 1 : 0;
 }

@@ -12,16 +12,21 @@
 #define P264_CABAC_H
 #include <stdint.h>
 #include <stddef.h>
+#include <string.h>
 #include "cabac_tables.h"
 
 #define P264_CABAC_CONTEXTS 460
 
 typedef struct p264cabac {
-    uint32_t range, offset;            /* codIRange (9 bits), codIOffset */
-    uint64_t cache;                    /* upcoming bits, MSB first */
-    int      cache_bits;
-    const uint8_t *p, *end;
-    int64_t  bits_left;                /* bits of the data not yet consumed; negative = the decoder read past the end */
+    /* The standard's codIOffset is kept SCALED: low = codIOffset << n | the next n bits of the data, so that a
+     * renormalisation by k bits is "n -= k" and the data is touched once per 32 bits.  Every operation leaves n >= 8 (no
+     * renormalisation shifts by more than 7: the smallest rangeTabLPS is 6). */
+    uint32_t range;                    /* codIRange (9 bits) */
+    int      n;
+    uint64_t low;
+    const uint8_t *data;
+    size_t   size, pos;                /* bytes of the data / bytes taken so far (counts on behind the end: zeros) */
+    uint8_t  next[128][2];             /* state byte behind a bin decoded as the MPS / as the LPS */
     uint8_t  state[P264_CABAC_CONTEXTS];   /* pStateIdx << 1 | valMPS */
 } p264cabac_t;
 
@@ -30,58 +35,52 @@ void p264cabac_init_contexts(p264cabac_t *c, int is_i_slice, int cabac_init_idc,
 /* 9.3.1.2: start at a byte-aligned position of the slice data */
 void p264cabac_start(p264cabac_t *c, const uint8_t *data, size_t bytes);
 
-static inline void p264cabac_refill(p264cabac_t *c)
+/* bits of the data not yet consumed; negative = the decoder used bits from behind the end */
+static inline int64_t p264cabac_bits_left(const p264cabac_t *c) { return (int64_t)c->size * 8 - ((int64_t)c->pos * 8 - c->n); }
+
+static inline void p264cabac_refill(p264cabac_t *c)       /* 32 more bits behind low (n < 8 before: low stays below 2^50) */
 {
-    while (c->cache_bits <= 56) {
-        uint64_t b = 0;
-        if (c->p < c->end) b = *c->p++;                   /* (zeros behind the end; bits_left tells whether any were USED) */
-        c->cache |= b << (56 - c->cache_bits);
-        c->cache_bits += 8;
-    }
-}
-static inline uint32_t p264cabac_bits(p264cabac_t *c, int n)       /* 1 <= n <= 16 */
-{
-    if (c->cache_bits < n) p264cabac_refill(c);
-    const uint32_t v = (uint32_t)(c->cache >> (64 - n));
-    c->cache <<= n; c->cache_bits -= n; c->bits_left -= n;
-    return v;
+    uint32_t v = 0;
+    if (c->pos + 4 <= c->size) { memcpy(&v, c->data + c->pos, 4); v = __builtin_bswap32(v); }
+    else for (int i = 0; i < 4; i++) v = v << 8 | (c->pos + (size_t)i < c->size ? c->data[c->pos + (size_t)i] : 0u);
+    c->pos += 4;
+    c->low = c->low << 32 | v;
+    c->n += 32;
 }
 
-/* 9.3.3.2.1: one context-coded bin */
+/* 9.3.3.2.1: one context-coded bin.  Branch-free up to the refill: the LPS / MPS decision is a mask. */
 static inline int p264cabac_decision(p264cabac_t *c, int ctx)
 {
-    uint32_t s = c->state[ctx];
+    const uint32_t s = c->state[ctx];
     const uint32_t lps = cabac_range_lps[s >> 1][(c->range >> 6) & 3];
-    int bin = (int)(s & 1);
-    c->range -= lps;
-    if (c->offset >= c->range) {                           /* least probable symbol */
-        c->offset -= c->range;
-        c->range = lps;
-        bin ^= 1;
-        if ((s >> 1) == 0) s ^= 1;                         /* pStateIdx 0: the MPS flips */
-        s = (uint32_t)cabac_trans_lps[s >> 1] << 1 | (s & 1);
-    } else if (s < 124) s += 2;                            /* transIdxMPS = min(pStateIdx + 1, 62) */
-    c->state[ctx] = (uint8_t)s;
-    if (c->range < 256) {                                  /* 9.3.3.2.2 renormalisation, all its shifts at once */
-        const int n = __builtin_clz(c->range) - 23;
-        c->range <<= n;
-        c->offset = c->offset << n | p264cabac_bits(c, n);
-    }
-    return bin;
+    uint32_t range = c->range - lps;
+    const uint64_t scaled = (uint64_t)range << c->n;
+    const uint64_t is_lps = (uint64_t)0 - (uint64_t)(c->low >= scaled);           /* all ones: least probable symbol */
+    c->low -= scaled & is_lps;
+    range = (range & ~(uint32_t)is_lps) | (lps & (uint32_t)is_lps);
+    c->state[ctx] = c->next[s][is_lps & 1];
+    const int k = __builtin_clz(range) - 23;                                        /* 9.3.3.2.2 renormalisation, all its shifts at once */
+    c->range = range << k;
+    c->n -= k;
+    if (c->n < 8) p264cabac_refill(c);
+    return (int)((s ^ (uint32_t)is_lps) & 1u);
 }
 /* 9.3.3.2.3: one equiprobable bin */
 static inline int p264cabac_bypass(p264cabac_t *c)
 {
-    c->offset = c->offset << 1 | p264cabac_bits(c, 1);
-    if (c->offset >= c->range) { c->offset -= c->range; return 1; }
-    return 0;
+    c->n -= 1;
+    const uint64_t scaled = (uint64_t)c->range << c->n;
+    const int bin = c->low >= scaled;
+    if (bin) c->low -= scaled;
+    if (c->n < 8) p264cabac_refill(c);
+    return bin;
 }
 /* 9.3.3.2.2.x: end_of_slice_flag / the bin in front of I_PCM samples */
 static inline int p264cabac_terminate(p264cabac_t *c)
 {
     c->range -= 2;
-    if (c->offset >= c->range) return 1;
-    if (c->range < 256) { c->range <<= 1; c->offset = c->offset << 1 | p264cabac_bits(c, 1); }
+    if (c->low >= (uint64_t)c->range << c->n) return 1;
+    if (c->range < 256) { c->range <<= 1; c->n -= 1; if (c->n < 8) p264cabac_refill(c); }
     return 0;
 }
 #endif

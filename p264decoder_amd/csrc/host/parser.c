@@ -1275,7 +1275,7 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
             { p264hip_mb_t tmp; begin_mb(p, &tmp); }
             if (sh.type != P264_SLICE_I && cb_mb_skip_flag(p)) { if (sh.type == P264_SLICE_B) decode_bskip(p); else decode_pskip(p); }
             else if (parse_mb(p, &b) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
-            if (p->cb.bits_left < -64) { ERR(p, "CABAC data overrun"); p->pic_open = 0; return -1; }
+            if (p264cabac_bits_left(&p->cb) < -64) { ERR(p, "CABAC data overrun"); p->pic_open = 0; return -1; }
             p->slice_of[p->mbi] = (uint16_t)p->slice_no;
             p->next_mb++;
             if (p264cabac_terminate(&p->cb)) break;              /* end_of_slice_flag */

@@ -2,7 +2,8 @@
  *
  * Replaces p264_cabac_context_init / p264_cabac_decode_init / _decision / _bypass / _terminal of the reference
  * (core/cabac.c:819-902).  Own formulation: the standard's (pStateIdx, valMPS) context state packed into one byte
- * (pStateIdx << 1 | valMPS), a 64-bit bit reservoir, renormalisation by a leading-zero count instead of a bit loop.
+ * (pStateIdx << 1 | valMPS), codIOffset kept scaled by the bits read ahead (32 at a time), renormalisation by a
+ * leading-zero count instead of a bit loop, the LPS / MPS decision as a mask instead of a branch.
  * This is the first piece of the Main-profile entropy layer: binarisation and context selection of the
  * macroblock layer sit on top of it (the reference's own CABAC macroblock parse is a stub, decoder/macroblock.c:594-597).
  * Pinned by a known-answer test: bins ENCODED by the reference's p264_cabac_encode_* (core/cabac.c:907-1018) must decode

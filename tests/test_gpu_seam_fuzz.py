@@ -168,3 +168,28 @@ def test_seam_fuzz_1080p_batch(lib, oracle):
             got = hip.read_frame(s, pics[s].desc.dst_slot)
             compare(got, want, "1080p picture %d stream %d" % (i, s), pics[s])
     hip.close()
+
+
+@pytest.mark.parametrize("share,b_picture", [(0.02, False), (0.3, False), (0.9, False), (0.45, True)])
+def test_seam_fuzz_1080p_intra_shares(lib, oracle, share, b_picture):
+    """P / B pictures of 1080p with few to nearly only intra macroblocks: k_intra's lists of ready macroblocks overflow (256 per
+    type and round), the second round and the ordered band walk behind it get real work (in the bench stream they see 15 % of
+    the 4 % intra macroblocks)."""
+    rng = np.random.default_rng(777 + int(share * 100) + 1000 * b_picture)
+    mb_w, mb_h, slots = 120, 68, 3
+    store = oracle_bind.FrameStore(mb_w, mb_h, slots)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=1, slots=slots, max_pictures=1, lib=lib)
+    for s in range(slots):
+        f = seam_fuzz.random_frame(rng, mb_w, mb_h, "noise")
+        for dst, src in zip(store[s], f):
+            dst[:] = src
+        hip.write_frame(0, s, *f)
+    for i in range(2):
+        pic = seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=True, dst_slot=i % slots, level_style="small", qp_mode="random", n_ref=2, slots=slots,
+                                     intra_share=share, b_picture=b_picture, n_ref_l1=2)
+        n_intra = int((pic.rec["mb_type"] <= N.MB_IPCM).sum())
+        assert abs(n_intra - share * mb_w * mb_h) < 0.25 * share * mb_w * mb_h + 40
+        want = oracle_bind.reconstruct(oracle, store, pic)
+        hip.submit(0, pic)
+        compare(hip.read_frame(0, pic.desc.dst_slot), want, "intra share %.2f picture %d" % (share, i), pic)
+    hip.close()

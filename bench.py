@@ -341,7 +341,7 @@ def main():
     golden_hashes = synth_cases.golden(golden_case)[1]
     use_golden = T <= len(golden_hashes)
     synth_extra = os.environ.get("P264AMD_BENCH_SYNTH_EXTRA", "")     # experiments only (e.g. "--mvmax 0"): no golden stream then
-    if synth_extra:
+    if synth_extra or os.environ.get("P264AMD_BENCH_NO_GOLDEN"):     # timing experiments with deliberately wrong kernels (scratch/)
         use_golden = False
     paths, parsed = [], []
     for g in range(DISTINCT):

@@ -26,6 +26,32 @@
 #define DEBLOCK_WAIT_SLEEP 16
 #endif
 
+// timing experiments (scratch/variant.sh): results are wrong unless all defaults hold
+#ifndef EXPD_LUMA_EDGES
+#define EXPD_LUMA_EDGES 4
+#endif
+#ifndef EXPD_CHROMA_EDGES
+#define EXPD_CHROMA_EDGES 4
+#endif
+#ifndef EXPD_STRONG
+#define EXPD_STRONG 1
+#endif
+#ifndef EXPD_HPASS
+#define EXPD_HPASS 1
+#endif
+#ifndef EXPD_BANDSYNC
+#define EXPD_BANDSYNC 1
+#endif
+#ifndef EXPD_VMCNT
+#define EXPD_VMCNT 1
+#endif
+#ifdef EXPD_STAMPS
+// in-kernel clock stamps of one wavefront (diagnostic build only: scratch/r4_stamps.sh)
+__device__ unsigned long long g_db_stamps[256 * 8];
+#define DB_STAMP(k) do { if (stamp_me && t < 256) g_db_stamps[t * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DB_STAMP(k) do { } while (0)
+#endif
 #define DY_DW 5                    // luma tile row: 5 dwords = cols -4..15
 #define DC_DW 3                    // chroma tile row: 3 dwords = cols -4..7
 #define DY_STRIDE (DY_DW * 4)
@@ -33,12 +59,17 @@
 
 enum { EC_LEFT = 0, EC_TOP = 1, EC_INNER = 2 };     // edge classes
 
-struct EdgeClass { uint8_t alpha, beta, any, pad, zero, tc[3]; };   // tc = tc0 for bS 1..3 (chroma: already +1); second dword: byte bS = tc0[bS]
-struct EdgeInfo {                  // 64 bytes per macroblock, written by k_deblock_bs
-    uint32_t  bs[4];               // 8 edges x 4 segments x 4 bits: word = dir*2 + (edge>>1), nibble = (edge&1)*4 + seg
-    EdgeClass cls[6];              // [class + 3*chroma]; cls[0].any = some bS != 0
-};
-#define EDGE_DW 16
+// What k_deblock_bs hands to k_deblock: 16 bytes per macroblock (64 in rounds 1-3: the class parameters travelled expanded).
+//   bs[dir]  two bits per (edge, segment), bit 2 * (4 * edge + segment): the boundary strength, except that on a macroblock
+//            edge (edge 0) code 3 stands for strength 4 - strength 3 only exists on inner edges, strength 4 only on
+//            macroblock edges (core/frame.c:535-538)
+//   qp       own luma QP (= the averaged QP of the inner edges)
+//   avg      the averaged QPs of the other five edge classes, six bits each: luma left, luma top, chroma left, chroma
+//            top, chroma inner (core/frame.c:593-601)
+// alpha / beta / tc0 come out of tables in the consumer (edge_expand below).
+struct EdgeInfo { uint32_t bs[2], qp, avg; };
+#define EDGE_DW 16                 // per macroblock in LDS: the four words above, then per class [class + 3 * chroma] two words
+                                   // {alpha | beta << 8, tc0 of code 1..3 in bytes 1..3 (chroma: already + 1)}
 
 // ------------------------------------------------------------------------------------------
 // K4a
@@ -47,7 +78,7 @@ struct EdgeInfo {                  // 64 bytes per macroblock, written by k_debl
 // segment is a handful of compares, so shuffling records around and packing nibbles across lanes dominated, ~57 vector
 // instructions per macroblock.  With the whole macroblock in one lane's registers - its 16 vectors, the left column and
 // the bottom row of the neighbours - everything unrolls at compile time to ~8 per macroblock, and the loads and the
-// 64-byte store of neighbouring lanes still cover whole cache lines.)
+// 16-byte store of neighbouring lanes still cover whole cache lines.)
 __device__ __forceinline__ int bs_motion(int vp, int vq, int rp, int rq)
 {   // core/frame.c:565-577: different reference or a vector component differing by >= 4 quarter-pels
     const int dx = (int)(int16_t)vp - (int)(int16_t)vq, dy = (vp >> 16) - (vq >> 16);
@@ -60,15 +91,6 @@ template <bool TWO_LISTS>
 __global__ __launch_bounds__(256)
 void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info, uint32_t inv_mbw)
 {
-    // alpha / tc0 (one dword per index) and beta tables in LDS: lane-varying indices, no constant-memory gathers
-    __shared__ uint32_t t_alpha_tc[52];
-    __shared__ uint8_t  t_beta[52];
-    if (threadIdx.x < 52) {
-        const int i = threadIdx.x;
-        t_alpha_tc[i] = (uint32_t)c_alpha[i] | ((uint32_t)c_tc0[i][0] << 8) | ((uint32_t)c_tc0[i][1] << 16) | ((uint32_t)c_tc0[i][2] << 24);
-        t_beta[i] = c_beta[i];
-    }
-    __syncthreads();
     const PicDev *pd = pics + blockIdx.y;
     if (!pd->deblock) return;
     const int mbi = blockIdx.x * 256 + threadIdx.x;
@@ -113,8 +135,8 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
     const bool fL = m_edges & P264_EDGE_LEFT, fT = m_edges & P264_EDGE_TOP;
     auto ref_of = [](uint32_t r4, int x, int y) { return (int)((r4 >> (8 * ((y >> 1) * 2 + (x >> 1)))) & 255); };
 
-    // ---- boundary strengths, core/frame.c:535-581: word = dir*2 + (edge>>1), nibble = (edge&1)*4 + segment ----
-    uint32_t word[4] = { 0, 0, 0, 0 };
+    // ---- boundary strengths, core/frame.c:535-581 ----
+    uint32_t word[2] = { 0, 0 };
 #pragma unroll
     for (int dir = 0; dir < 2; dir++)
 #pragma unroll
@@ -135,57 +157,66 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
                     bS |= bs_motion(wp, wq, ref_of(!outer ? refs1 : dir == 0 ? refs1L : refs1T, xn, yn), ref_of(refs1, x, y));
                 }
                 if (((mmask >> blk_at(x, y)) | (n_mask >> blk_at(xn, yn))) & 1) bS = 2;
-                if (m_intra | n_intra) bS = outer ? 4 : 3;
+                if (m_intra | n_intra) bS = 3;                    // on a macroblock edge: the code of strength 4
                 if (!enabled) bS = 0;
-                word[dir * 2 + (e >> 1)] |= (uint32_t)bS << (4 * ((e & 1) * 4 + i));
+                word[dir] |= (uint32_t)bS << (2 * (4 * e + i));
             }
-    const bool any = (word[0] | word[1] | word[2] | word[3]) != 0;
 
-    // ---- per edge class: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted: A-Q3) ----
-    const int cqo = pd->chroma_qp_offset, alpha_off = pd->alpha_off, beta_off = pd->beta_off;
-    const int qps[3] = { (int)((recL.x >> 8) & 255), (int)((recT.x >> 8) & 255), m_qp };          // EC_LEFT, EC_TOP, EC_INNER neighbours
+    // ---- averaged QPs per edge class (deblock_edge, core/frame.c:472-488,593-601) ----
+    const int cqo = pd->chroma_qp_offset;
+    const int qpL = (int)((recL.x >> 8) & 255), qpT = (int)((recT.x >> 8) & 255);
     const int cq_own = chroma_qp(clip3i(m_qp + cqo, 0, 51));
-    uint32_t cls[12];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int c = k % 3, chroma = k / 3;
-        const int q = !chroma ? (m_qp + qps[c] + 1) >> 1                                           // :593-595
-                              : (cq_own + chroma_qp(clip3i(qps[c] + cqo, 0, 51)) + 1) >> 1;       // :600-601
-        const uint32_t at = t_alpha_tc[clip3i(q + alpha_off, 0, 51)];
-        const uint32_t be = t_beta[clip3i(q + beta_off, 0, 51)];
-        const uint32_t add = chroma ? 0x01010100u : 0u;                                            // chroma: tc0 + 1
-        const uint32_t v = at + add;                                                               // alpha | tc0[0..2] (+1), no carries: tc0 <= 25
-        cls[2 * k] = (v & 0xffu) | (be << 8) | ((uint32_t)(any ? 1 : 0) << 16);
-        cls[2 * k + 1] = v & 0xffffff00u;                                                         // byte bS (1..3) = its tc0, byte 0 = 0
-    }
-    EdgeInfo *out = info + (size_t)blockIdx.y * g.n_mb + mbi;
-    uint32_t *o = (uint32_t *)out;
-    gstore4(o, make_uint4(word[0], word[1], word[2], word[3]));
-    gstore4(o + 4, make_uint4(cls[0], cls[1], cls[2], cls[3]));
-    gstore4(o + 8, make_uint4(cls[4], cls[5], cls[6], cls[7]));
-    gstore4(o + 12, make_uint4(cls[8], cls[9], cls[10], cls[11]));
+    const uint32_t avg = (uint32_t)((m_qp + qpL + 1) >> 1) | (uint32_t)((m_qp + qpT + 1) >> 1) << 6
+                       | (uint32_t)((cq_own + chroma_qp(clip3i(qpL + cqo, 0, 51)) + 1) >> 1) << 12
+                       | (uint32_t)((cq_own + chroma_qp(clip3i(qpT + cqo, 0, 51)) + 1) >> 1) << 18 | (uint32_t)cq_own << 24;
+    gstore4(info + (size_t)blockIdx.y * g.n_mb + mbi, make_uint4(word[0], word[1], (uint32_t)m_qp, avg));
 }
 
-// A macroblock's EdgeInfo as its eight lanes see it: the four boundary-strength words in registers, the class
+// alpha | tc0 of strengths 1..3 (one dword per index A) and beta (per index B): core/frame.c:262-291
+struct EdgeTables { uint32_t alpha_tc[52]; uint8_t beta[52]; };
+__device__ __forceinline__ void edge_tables_init(EdgeTables &T)
+{
+    if (threadIdx.x < 52) {
+        const int i = threadIdx.x;
+        T.alpha_tc[i] = (uint32_t)c_alpha[i] | ((uint32_t)c_tc0[i][0] << 8) | ((uint32_t)c_tc0[i][1] << 16) | ((uint32_t)c_tc0[i][2] << 24);
+        T.beta[i] = c_beta[i];
+    }
+}
+// Class k = class + 3 * chroma of a macroblock: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted:
+// A-Q3).  k may vary per lane.  On the macroblock-edge classes code 3 means strength 4, which has no tc0: byte 3 = 0.
+__device__ __forceinline__ uint2 edge_expand(const EdgeTables &T, uint32_t qp, uint32_t avg, int k, int alpha_off, int beta_off)
+{
+    const int sh = k < 2 ? 6 * k : 6 * (k - 1);                        // k: 0 1 [2] 3 4 5 -> field 0 1 [qp] 2 3 4 of avg
+    const int q = k == 2 ? (int)(qp & 63u) : (int)((avg >> sh) & 63u);
+    const uint32_t at = T.alpha_tc[clip3i(q + alpha_off, 0, 51)];
+    const uint32_t be = T.beta[clip3i(q + beta_off, 0, 51)];
+    uint32_t v = at + (k >= 3 ? 0x01010100u : 0u);                     // chroma: tc0 + 1 (no carries: tc0 <= 25)
+    if (k != 2 && k != 5) v &= 0x00ffffffu;
+    return make_uint2((v & 0xffu) | (be << 8), v & 0xffffff00u);
+}
+
+// A macroblock's EdgeInfo as its eight lanes see it: the two boundary-strength words in registers, the class
 // parameters fetched from the octet's LDS copy where an edge needs them.
 struct EdgeRegs {
-    uint32_t e[4];
-    const uint32_t *lds;            // the octet's copy of the 16 dwords
-    __device__ __forceinline__ uint32_t nib(int dir, int ed) const { return (e[dir * 2 + (ed >> 1)] >> ((ed & 1) * 16)) & 0xffffu; }
+    uint32_t e[2];
+    const uint32_t *lds;            // the octet's copy: 4 raw words, then 6 classes x 2 words
+    // code of (edge ed, the lane's segment): seg2 = 2 * segment
+    __device__ __forceinline__ int code(int dir, int ed, int seg2) const { return (int)__builtin_amdgcn_ubfe(e[dir], (unsigned)(8 * ed + seg2), 2u); }
 };
-// class k occupies dwords 4+2k (alpha, beta, any) and 5+2k (0, tc0[1..3]); k is a compile-time constant.  Everything comes out
+// class k occupies dwords 4+2k (alpha, beta) and 5+2k (0, tc0 of code 1..3); k is a compile-time constant.  Everything comes out
 // as a 16-bit pair with the same value in both halves, one v_perm each: the filter arithmetic is packed.
 struct EdgeParams {
     uint32_t lo, hi;
     __device__ __forceinline__ EdgeParams(const EdgeRegs &E, int k) { uint2 v = *(const uint2 *)(E.lds + 4 + 2 * k); lo = v.x; hi = v.y; }
     __device__ __forceinline__ uint32_t alpha2() const { return perm(lo, lo, 0x0c000c00u); }
     __device__ __forceinline__ uint32_t beta2() const { return perm(lo, lo, 0x0c010c01u); }
-    // tc0 of boundary strength b (per lane; 0 for b = 0 and for b = 4, which does not use it): byte b of {0, hi}
-    __device__ __forceinline__ uint32_t tc2(int b) const { return perm(0u, hi, 0x0c000c00u + (uint32_t)b * 0x00010001u); }
+    // tc0 of code c (per lane; 0 for code 0 and for strength 4, which does not use it): byte c of {0, hi}
+    __device__ __forceinline__ uint32_t tc2(int c) const { return perm(0u, hi, 0x0c000c00u + (uint32_t)c * 0x00010001u); }
 };
-// all ones where the boundary strength is 1..3 / is 4 (one sign-extending bit-field extract instead of compare + select)
-__device__ __forceinline__ uint32_t mask_bs123(int b) { return (uint32_t)__builtin_amdgcn_sbfe(0x0e, (unsigned)b, 1u); }
-__device__ __forceinline__ uint32_t mask_bs4(int b) { return (uint32_t)__builtin_amdgcn_sbfe(0x10, (unsigned)b, 1u); }
+// all ones where the boundary strength is 1..3 / is 4, from the code (one sign-extending bit-field extract instead of compare +
+// select): macroblock edges (ed == 0) hold strengths {0, 1, 2, 4 as code 3}, inner edges {0, 1, 2, 3}
+__device__ __forceinline__ uint32_t mask_bs123(int c, int ed) { return (uint32_t)__builtin_amdgcn_sbfe(ed == 0 ? 0x06 : 0x0e, (unsigned)c, 1u); }
+__device__ __forceinline__ uint32_t mask_bs4(int c) { return (uint32_t)__builtin_amdgcn_sbfe(0x08, (unsigned)c, 1u); }     // ed == 0 only
 __device__ __forceinline__ int edge_class(int dir, int ed) { return ed == 0 ? (dir == 0 ? EC_LEFT : EC_TOP) : EC_INNER; }
 
 // ------------------------------------------------------------------------------------------
@@ -295,33 +326,41 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
 {
     __shared__ int progress[MAX_PICS_PER_WG][MAX_BANDS];     // fully stored macroblocks of a band's last row
     __shared__ OctLds lds[ROW_WAVES][8];
+    __shared__ EdgeTables tables;
+    edge_tables_init(tables);
     const Geom g = g_;
-    const int RB = 1 << rb_log2;                               // pics_per_wg <= 8 >> rb_log2; octets beyond that idle
+    const int RB = 1 << rb_log2, PW = 8 >> rb_log2;             // rows of a band, pictures per wavefront
     const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     const int o = lane >> 3, j = lane & 7;
-    const int gr = o & (RB - 1), pi = o >> rb_log2;           // row inside the band, picture inside the workgroup
+    const int gr = o & (RB - 1), pi = o >> rb_log2;           // row inside the band, picture inside the wavefront
     const int n_bands = (g.mb_h + RB - 1) >> rb_log2;
+    const int n_groups = (pics_per_wg + PW - 1) / PW;         // the workgroup's pictures in groups of PW: a work unit = (band, group)
     for (int k = threadIdx.x; k < MAX_PICS_PER_WG * MAX_BANDS; k += blockDim.x) (&progress[0][0])[k] = 0;
     __syncthreads();
-    const int pic = blockIdx.x * pics_per_wg + pi;
-    const PicDev *pd = pics + min(pic, n_pics - 1);
-    const bool pic_ok = pi < pics_per_wg && pic < n_pics && pd->deblock;
     OctLds &L = lds[wave][o];
-    uint8_t *F = pd->dst;                                     // strip frame layout (device_common.h)
-    const EdgeInfo *pinfo = info + (size_t)min(pic, n_pics - 1) * g.n_mb;
-    const int seg = j >> 1, cseg = j & 3;                     // bS segment of this lane's luma / chroma lines
+    const int seg2 = (j >> 1) * 2, cseg2 = (j & 3) * 2;       // 2 x the bS segment of this lane's luma / chroma lines
     const int cp = j >> 2, cr = (j & 3) * 2;                  // chroma plane, first chroma line of this lane
     uint8_t *tile8 = (uint8_t *)L.tile;
     bool ok = true;
 
-    for (int band = wave; band < n_bands; band += n_waves) {
+    // units in band-major order: a wavefront takes unit u only after u - n_waves, and band b of a group only waits for band
+    // b - 1 of the same group, which is an earlier unit - nobody waits for a unit that has not been started
+    for (int unit = wave; unit < n_bands * n_groups; unit += n_waves) {
+        const int band = unit / n_groups, piw = (unit - band * n_groups) * PW + pi;     // picture inside the workgroup
+        const int pic = blockIdx.x * pics_per_wg + piw;
+        const PicDev *pd = pics + min(pic, n_pics - 1);
+        const bool pic_ok = pi < PW && piw < pics_per_wg && pic < n_pics && pd->deblock;
+        uint8_t *F = pd->dst;                                     // strip frame layout (device_common.h)
+        const EdgeInfo *pinfo = info + (size_t)min(pic, n_pics - 1) * g.n_mb;
+        const int alpha_off = pd->alpha_off, beta_off = pd->beta_off;
+        uint32_t last_qp = 0xffffffffu, last_avg = 0xffffffffu;   // QPs the octet's class parameters in LDS were expanded for
         const int R0 = band << rb_log2;
         const int nrows = min(RB, g.mb_h - R0), last = nrows - 1;
         const int row = R0 + gr;
         const bool have_row = pic_ok && gr < nrows;
         const bool below_in_band = gr < last;                  // the row below belongs to the next octet
         const bool top_exists = row > 0;
-        const bool from_above = have_row && gr == 0 && band > 0;   // the rows above come from the band above, through memory
+        const bool from_above = EXPD_BANDSYNC && have_row && gr == 0 && band > 0;   // the rows above come from the band above, through memory
         const int rowc = min(row, g.mb_h - 1);
         // Strip layout: macroblock x of this row owns the 256 luma bytes at x*ystrip + row*256 and the 128 chroma bytes at
         // coff + x*cstrip + row*128 (rows of 8 bytes U, 8 bytes V).  This lane's two luma rows are the 32 bytes at +32j, its
@@ -333,7 +372,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         const uint32_t sT = j < 4 ? sY : sC;
         uint8_t *topP = j < 4 ? F + (ptrdiff_t)(rowc - 1) * MB_LUMA_BYTES + 192 + j * 16
                               : F + g.coff + (ptrdiff_t)(rowc - 1) * MB_CHROMA_BYTES + (6 + (j & 1)) * 16 + ((j >> 1) & 1) * 8;
-        int *my_progress = &progress[pi & (MAX_PICS_PER_WG - 1)][band];
+        int *my_progress = &progress[piw & (MAX_PICS_PER_WG - 1)][band];
         const bool publisher = have_row && gr == last && j == 0;
         OctLds &Lnext = lds[wave][min(o + 1, 7)];
 
@@ -360,7 +399,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             if (actn) {
-                if (j < 4) fE = gload4((const uint4 *)(pinfo + row * g.mb_w + x) + j);
+                if (j == 0) fE = gload4(pinfo + row * g.mb_w + x);
                 if (from_above) {
                     if (j < 4) fT = gload4(topP + x * sT);
                     else { uint2 v2 = gload2(topP + x * sT); fT.x = v2.x; fT.y = v2.y; }
@@ -370,8 +409,12 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             }
         };
 
+#ifdef EXPD_STAMPS
+        const bool stamp_me = blockIdx.x == 100 && wave == EXPD_STAMPS && unit == wave && lane == 0;
+#endif
         prefetch(0);
         for (int t = 0; t < n_iter; t++) {
+            DB_STAMP(0);
             const int x = t - 2 * gr;
             const bool act = have_row && x >= 0 && x < g.mb_w;         // filter macroblock x
             const bool flush = have_row && x >= 1 && x <= g.mb_w;       // store macroblock x-1
@@ -384,14 +427,15 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     if (j < 4) *(uint4 *)(ring + j * 4) = fT;
                     else *(uint2 *)(ring + 16 + (j - 4) * 2) = make_uint2(fT.x, fT.y);
                 }
-                if (j < 4) *(uint4 *)(L.edge + j * 4) = fE;
+                if (j == 0) *(uint4 *)L.edge = fE;
             }
             // Everything this wave has issued is complete here (the prefetch was issued before the previous
             // iteration's horizontal pass, its stores before that): macroblocks 0 .. x-2 of this row are in memory.
             // Publish with RELEASE semantics at workgroup scope: the band below reads these macroblocks' pixels through global
             // memory on the same CU.  (The explicit wait drains the WHOLE wave's stores - the publisher lane speaks for all
             // eight octets of its wave, and a release fence only orders the publishing lane's own view.)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (EXPD_VMCNT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DB_STAMP(1);
             if (publisher) __hip_atomic_store(my_progress, min(max(x - 1, 0), g.mb_w), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             wave_lds_fence();
             // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
@@ -403,15 +447,24 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             EdgeRegs E;
             {
                 const uint4 v = act ? *(const uint4 *)L.edge : make_uint4(0, 0, 0, 0);
-                E.e[0] = v.x; E.e[1] = v.y; E.e[2] = v.z; E.e[3] = v.w; E.lds = L.edge;
+                E.e[0] = v.x; E.e[1] = v.y; E.lds = L.edge;
+                // the class parameters of the octet's LDS copy follow the macroblock's QPs: expanded again only when those change
+                const bool changed = act && (v.z != last_qp || v.w != last_avg);
+                if (__ballot(changed)) {
+                    if (act) {
+                        if (j < 6) *(uint2 *)(L.edge + 4 + 2 * j) = edge_expand(tables, v.z, v.w, j, alpha_off, beta_off);
+                        last_qp = v.z; last_avg = v.w;
+                    }
+                    wave_lds_fence();
+                }
             }
-            const bool any_edges = __ballot((E.e[0] | E.e[1] | E.e[2] | E.e[3]) != 0) != 0;
+            const bool any_edges = __ballot((E.e[0] | E.e[1]) != 0) != 0;
 
             if (any_edges) {
                 // ---------- vertical edges, in registers ----------
 #pragma unroll
-                for (int ed = 0; ed < 4; ed++) {
-                    const int b = (E.nib(0, ed) >> (4 * seg)) & 15, k = edge_class(0, ed);
+                for (int ed = 0; ed < EXPD_LUMA_EDGES; ed++) {
+                    const int b = E.code(0, ed, seg2), k = edge_class(0, ed);
                     if (__ballot(b != 0) == 0) continue;
                     pk16 p2 = pair_byte<1>(ya[ed], yb[ed]), p1 = pair_byte<2>(ya[ed], yb[ed]), p0 = pair_byte<3>(ya[ed], yb[ed]);
                     pk16 q0 = pair_byte<0>(ya[ed+1], yb[ed+1]), q1 = pair_byte<1>(ya[ed+1], yb[ed+1]), q2 = pair_byte<2>(ya[ed+1], yb[ed+1]);
@@ -419,12 +472,12 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
                     const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
                     const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
-                    const pk16 en = as_pk(mask_bs123(b));
+                    const pk16 en = as_pk(mask_bs123(b, ed));
                     const pk16 op2 = p2, op1 = p1, op0 = p0, oq0 = q0, oq1 = q1, oq2 = q2;
                     pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
                     // bS 4 exists on macroblock edges only (k_deblock_bs), and the strong filter changes nothing where the
                     // sample flag is off
-                    if (ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
+                    if (EXPD_STRONG && ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
                         const pk16 str = as_pk(mask_bs4(b));
                         pk16 sp2 = op2, sp1 = op1, sp0 = op0, sq0 = oq0, sq1 = oq1, sq2 = oq2;
                         pk_luma_strong(pair_byte<0>(ya[ed], yb[ed]), sp2, sp1, sp0, sq0, sq1, sq2, pair_byte<3>(ya[ed+1], yb[ed+1]), f & str, ap, aq, A);
@@ -437,18 +490,19 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     ya[ed+1] = perm(tq, ya[ed+1], 0x03020504u); yb[ed+1] = perm(tq, yb[ed+1], 0x03020706u);
                 }
 #pragma unroll
-                for (int ed = 0; ed < 4; ed += 2) {
-                    const int b = (E.nib(0, ed) >> (4 * cseg)) & 15, k = edge_class(0, ed) + 3, c = ed >> 1;
+                for (int ed = 0; ed < EXPD_CHROMA_EDGES; ed += 2) {
+                    const int b = E.code(0, ed, cseg2), k = edge_class(0, ed) + 3, c = ed >> 1;
                     if (__ballot(b != 0) == 0) continue;
                     pk16 p1 = pair_byte<2>(ca[c], cb[c]), p0 = pair_byte<3>(ca[c], cb[c]);
                     pk16 q0 = pair_byte<0>(ca[c+1], cb[c+1]), q1 = pair_byte<1>(ca[c+1], cb[c+1]);
                     const EdgeParams ep(E, k);
                     const pk16 f = pk_edge_flag(p1, p0, q0, q1, as_pk(ep.alpha2()), as_pk(ep.beta2()));
-                    pk_chroma(p1, p0, q0, q1, f, as_pk(mask_bs123(b)), as_pk(mask_bs4(b)), __ballot(b == 4) != 0, as_pk(ep.tc2(b)));
+                    pk_chroma(p1, p0, q0, q1, f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
                     ca[c] = perm(as_u(p0), ca[c], 0x04020100u);     cb[c] = perm(as_u(p0), cb[c], 0x06020100u);
                     ca[c+1] = perm(as_u(q0), ca[c+1], 0x03020104u); cb[c+1] = perm(as_u(q0), cb[c+1], 0x03020106u);
                 }
             }
+            DB_STAMP(2);
             // ---- macroblock x-1 is final now: columns 0..11 still sit in the tile, its last four columns are ya[0]/yb[0].
             // Store it as whole rows; rows 12..15 go to the octet below instead, which stores them as its "rows above".
             if (flush) {
@@ -468,9 +522,11 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 *(uint2 *)tCa = make_uint2(ca[1], ca[2]);               *(uint2 *)tCb = make_uint2(cb[1], cb[2]);
             }
             wave_lds_fence();
+            DB_STAMP(3);
             if (t + 1 < n_iter) prefetch(t + 1);                      // the next iteration's loads travel during the horizontal pass
             // ---------- horizontal edges: column pairs out of the tile, filtered, back into the tile ----------
-            const bool h_edges = __ballot((E.e[2] | E.e[3]) != 0) != 0;
+            DB_STAMP(4);
+            const bool h_edges = EXPD_HPASS && __ballot(E.e[1] != 0) != 0;
             if (h_edges) {
                 if (act) {
                     // luma: columns 2j, 2j+1
@@ -481,18 +537,18 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
 #pragma unroll
                     for (int r = 0; r < 16; r++) { uint32_t v = *(const uint16_t *)(col + r * 16); c[4 + r] = as_pk(perm(v, v, 0x0c010c00u)); }
 #pragma unroll
-                    for (int ed = 0; ed < 4; ed++) {
-                        const int b = (E.nib(1, ed) >> (4 * seg)) & 15, k = edge_class(1, ed);
+                    for (int ed = 0; ed < EXPD_LUMA_EDGES; ed++) {
+                        const int b = E.code(1, ed, seg2), k = edge_class(1, ed);
                         if (__ballot(b != 0) == 0) continue;
                         pk16 &p3 = c[4*ed], &p2 = c[4*ed+1], &p1 = c[4*ed+2], &p0 = c[4*ed+3], &q0 = c[4*ed+4], &q1 = c[4*ed+5], &q2 = c[4*ed+6], &q3 = c[4*ed+7];
                         const EdgeParams ep(E, k);
                         const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
                         const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
                         const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
-                        const pk16 en = as_pk(mask_bs123(b));
+                        const pk16 en = as_pk(mask_bs123(b, ed));
                         pk16 sp2 = p2, sp1 = p1, sp0 = p0, sq0 = q0, sq1 = q1, sq2 = q2;
                         pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
-                        if (ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
+                        if (EXPD_STRONG && ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
                             const pk16 str = as_pk(mask_bs4(b));
                             pk_luma_strong(p3, sp2, sp1, sp0, sq0, sq1, sq2, q3, f & str, ap, aq, A);
                             p2 = pk_sel(str, sp2, p2); p1 = pk_sel(str, sp1, p1); p0 = pk_sel(str, sp0, p0);
@@ -513,12 +569,12 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
 #pragma unroll
                     for (int r = 0; r < 8; r++) { uint32_t v = *(const uint16_t *)(ccol + r * 8); d[2 + r] = as_pk(perm(v, v, 0x0c010c00u)); }
 #pragma unroll
-                    for (int ed = 0; ed < 4; ed += 2) {
-                        const int b = (E.nib(1, ed) >> (4 * cseg)) & 15, k = edge_class(1, ed) + 3;
+                    for (int ed = 0; ed < EXPD_CHROMA_EDGES; ed += 2) {
+                        const int b = E.code(1, ed, cseg2), k = edge_class(1, ed) + 3;
                         if (__ballot(b != 0) == 0) continue;
                         const EdgeParams ep(E, k);
                         const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], as_pk(ep.alpha2()), as_pk(ep.beta2()));
-                        pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], f, as_pk(mask_bs123(b)), as_pk(mask_bs4(b)), __ballot(b == 4) != 0, as_pk(ep.tc2(b)));
+                        pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
                     }
                     *(uint16_t *)((uint8_t *)ring + 64 + cp * 16 + cr + 8) = (uint16_t)perm(as_u(d[1]), as_u(d[1]), 0x0c0c0200u);
                     *(uint16_t *)(ccol) = (uint16_t)perm(as_u(d[2]), as_u(d[2]), 0x0c0c0200u);
@@ -527,6 +583,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 }
                 wave_lds_fence();
             }
+            DB_STAMP(5);
             // the last four columns of this macroblock are the next one's columns -4..-1
             if (act) { ya0 = tYa[3]; yb0 = tYb[3]; ca0 = tCa[1]; cb0 = tCb[1]; }
             wave_lds_fence();

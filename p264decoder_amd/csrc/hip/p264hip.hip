@@ -89,7 +89,7 @@ struct p264hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[4] = {};
     bool concurrent = false;      // P264AMD_CONCURRENT=1: measured no gain at full batches (every kernel fills the chip on its own), kept as a knob
     // tuning knobs, read from the environment ONCE (p264hip_create); 0 = built-in choice
-    int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0;
+    int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0;
     hipEvent_t markers[P264HIP_MARKERS] = {};
     int next_marker = 0;
     bool timing = false;
@@ -142,6 +142,7 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     if (const char *env = getenv("P264AMD_INTRA_WAVES")) c->tune_intra_waves = atoi(env);
     if (const char *env = getenv("P264AMD_DEBLOCK_RB_LOG2")) c->tune_rb_log2 = atoi(env);
     if (const char *env = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) c->tune_pics_per_wg = atoi(env);
+    if (const char *env = getenv("P264AMD_DEBLOCK_WAVES")) c->tune_db_waves = atoi(env);
     if (e == hipSuccess) e = hipMalloc((void **)&c->frames, c->frame_bytes * (size_t)n_streams * slots);
     if (e == hipSuccess) e = hipMemsetAsync(c->frames, 0, c->frame_bytes * (size_t)n_streams * slots, c->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int));
@@ -458,10 +459,13 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         if (per_wg < 1) per_wg = 1;
         if (per_wg > 4) per_wg = 4;
         int rb_log2 = per_wg == 1 ? 3 : per_wg == 2 ? 2 : 1;
-        if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) { rb_log2 = c->tune_rb_log2; per_wg = 8 >> rb_log2; }
-        if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= (8 >> rb_log2)) per_wg = c->tune_pics_per_wg;
+        // (a wavefront holds 8 >> rb_log2 pictures; a workgroup with more pictures than that works on them in groups)
+        if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) rb_log2 = c->tune_rb_log2;
+        if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= 4) per_wg = c->tune_pics_per_wg;
         const int n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
-        const int waves = n_bands < ROW_WAVES ? n_bands : ROW_WAVES;
+        const int n_units = n_bands * ((per_wg + (8 >> rb_log2) - 1) / (8 >> rb_log2));
+        int waves = n_units < ROW_WAVES ? n_units : ROW_WAVES;
+        if (c->tune_db_waves >= 1 && c->tune_db_waves < waves) waves = c->tune_db_waves;
         hipLaunchKernelGGL(k_deblock, dim3((n + per_wg - 1) / per_wg), dim3(waves * 64), 0, c->stream, c->d_batch[r], g,
                            (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2, per_wg);
     }
@@ -500,6 +504,16 @@ static int drain_stamps(p264hip_ctx *c)
 
 extern "C" int p264hip_sync(p264hip_ctx *c)
 {
+#ifdef EXPD_STAMPS
+    if (const char *path = getenv("P264AMD_STAMPS_OUT")) {     // diagnostic build: the clock stamps of one k_deblock wavefront
+        static unsigned long long h[256 * 8];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_db_stamps), sizeof h) == hipSuccess) {
+            FILE *f = fopen(path, "w");
+            if (f) { for (int i = 0; i < 256; i++) { for (int k = 0; k < 8; k++) fprintf(f, "%llu ", h[i * 8 + k]); fprintf(f, "\n"); } fclose(f); }
+        }
+    }
+#endif
     if (!c) return fail(P264HIP_EINVAL, "null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -18,7 +18,7 @@ for i, r in enumerate(rows):
         d = [r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], nxt - r[5]]
         if all(0 <= x < 10**7 for x in d):
             for k in range(6): segs[k].append(d[k])
-names = ["land+vmcnt", "publish+Vpass", "flush+tile", "prefetch(+spin)", "Hpass", "tail"]
+names = (sys.argv[2].split(",") if len(sys.argv) > 2 else ["land+vmcnt", "publish+Vpass", "flush+tile", "prefetch(+spin)", "Hpass", "tail"])
 tot = 0
 for k in range(6):
     if segs[k]:

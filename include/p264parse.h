@@ -24,8 +24,10 @@ typedef struct p264parse p264parse;
 
 enum {
     P264PARSE_OPT_QUIET  = 1,   /* do not print SPS/PPS/size lines to stderr (the reference prints them) */
-    P264PARSE_OPT_STRICT = 2    /* H.264-conformant QP accumulation instead of the reference's
-                                   (decoder/macroblock.c:568, core/macroblock.c:1247-1252; SURVEY A-Q2) */
+    P264PARSE_OPT_STRICT = 2    /* H.264-conformant QP accumulation also for Baseline CAVLC streams, where the default is the
+                                   reference's rule (decoder/macroblock.c:568, core/macroblock.c:1247-1252; SURVEY A-Q2).
+                                   CABAC, B slices and every profile but Baseline - none of which the reference decodes -
+                                   always get the conformant chain */
 };
 
 p264parse *p264parse_open(int options);

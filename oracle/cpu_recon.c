@@ -17,8 +17,11 @@
  * [4] chroma edge lines with bS>0, [5] of those modified, [6] macroblock edges with bS>0 whose two macroblocks have
  * different QPs (the filter parameters come from the mean), [7] dequantised luma/chroma AC coefficients whose int16 store
  * wrapped (A-Q8). */
-static long long g_stats[8], g_bipred_blocks;
-void oracle_stats_reset(void) { memset(g_stats, 0, sizeof g_stats); g_bipred_blocks = 0; }
+static long long g_stats[8], g_bipred_blocks, g_bs_by_picture;
+void oracle_stats_reset(void) { memset(g_stats, 0, sizeof g_stats); g_bipred_blocks = 0; g_bs_by_picture = 0; }
+/* B pictures: edge segments whose strength by reference PICTURES (H.264 8.7.2.1) differs from the list-by-list comparison of
+ * reference INDICES the reference's encoder-side loop makes (core/frame.c:565-577) */
+long long oracle_bs_by_picture(void) { return g_bs_by_picture; }
 long long oracle_bipred_blocks(void) { return g_bipred_blocks; }
 void oracle_stats_get(long long out[8]) { memcpy(out, g_stats, sizeof g_stats); }
 
@@ -630,6 +633,38 @@ static void edge(const p264hip_picture_t *pic, uint8_t *pix, int stride, int dir
     }
 }
 
+/* B pictures, H.264 8.7.2.1: the two blocks either side of an edge segment get strength 1 when they predict from different
+ * reference PICTURES or a different number of vectors, or when vectors that belong to the same picture differ by >= 4
+ * quarter-pels in a component.  The reference's loop (core/frame.c:565-577, encoder side: its decoder never gets here,
+ * decoder/macroblock.c:168-171) compares list by list on the indices, which is only the same thing while no picture sits in
+ * both lists.  Pictures are told apart by their frame-store slot; an unused list is slot -1 with a zero vector (the parser
+ * keeps that), a quadrant without any list predicts from list 0, entry 0 (as the motion compensation reads it). */
+static int b_slot(const p264hip_picture_t *pic, int list, int idx)
+{
+    if (idx < 0) return -1;
+    if (list == 0) return pic->ref_slot[idx < pic->n_ref ? idx : 0];
+    return pic->ref_slot_l1[idx < pic->n_ref_l1 ? idx : 0];
+}
+static int mv_far(const int16_t *a, const int16_t *b) { return iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4; }
+static int b_motion_strength(const p264hip_picture_t *pic, int mbi, int x, int y, int nbi, int xn, int yn)
+{
+    const int qp_ = mbi*4 + (y >> 1)*2 + (x >> 1), qn_ = nbi*4 + (yn >> 1)*2 + (xn >> 1);
+    int p0 = b_slot(pic, 0, pic->ref_idx[qp_]), p1 = b_slot(pic, 1, pic->ref_idx_l1[qp_]);
+    int q0 = b_slot(pic, 0, pic->ref_idx[qn_]), q1 = b_slot(pic, 1, pic->ref_idx_l1[qn_]);
+    if (p0 < 0 && p1 < 0) p0 = pic->ref_slot[0];
+    if (q0 < 0 && q1 < 0) q0 = pic->ref_slot[0];
+    const int16_t *vp0 = pic->mv + (mbi*16 + y*4 + x)*2, *vq0 = pic->mv + (nbi*16 + yn*4 + xn)*2;
+    const int16_t *vp1 = pic->mv_l1 + (mbi*16 + y*4 + x)*2, *vq1 = pic->mv_l1 + (nbi*16 + yn*4 + xn)*2;
+    const int straight = p0 == q0 && p1 == q1 && !mv_far(vp0, vq0) && !mv_far(vp1, vq1);
+    const int crossed  = p0 == q1 && p1 == q0 && !mv_far(vp0, vq1) && !mv_far(vp1, vq0);
+    const int bs = !(straight || crossed);
+    {   /* coverage: what the list-by-list comparison of indices would have said */
+        int by_index = pic->ref_idx[qp_] != pic->ref_idx[qn_] || mv_far(vp0, vq0) || pic->ref_idx_l1[qp_] != pic->ref_idx_l1[qn_] || mv_far(vp1, vq1);
+        if (by_index != bs) g_bs_by_picture++;
+    }
+    return bs;
+}
+
 int oracle_deblock_picture(const p264hip_picture_t *pic, uint8_t **planes)
 {
     int w = pic->mb_w * 16, cw = w / 2;
@@ -654,12 +689,8 @@ int oracle_deblock_picture(const p264hip_picture_t *pic, uint8_t **planes)
                         else {
                             int rp = pic->ref_idx[mbi*4 + (y >> 1)*2 + (x >> 1)], rq = pic->ref_idx[nbi*4 + (yn >> 1)*2 + (xn >> 1)];
                             const int16_t *vp = pic->mv + (mbi*16 + y*4 + x)*2, *vq = pic->mv + (nbi*16 + yn*4 + xn)*2;
-                            bS[i] = (rp != rq || iabs(vp[0] - vq[0]) >= 4 || iabs(vp[1] - vq[1]) >= 4) ? 1 : 0;
-                            if (pic->slice_type == P264_SLICE_B && !bS[i]) {             /* the loop over l, core/frame.c:565-577 */
-                                rp = pic->ref_idx_l1[mbi*4 + (y >> 1)*2 + (x >> 1)]; rq = pic->ref_idx_l1[nbi*4 + (yn >> 1)*2 + (xn >> 1)];
-                                vp = pic->mv_l1 + (mbi*16 + y*4 + x)*2; vq = pic->mv_l1 + (nbi*16 + yn*4 + xn)*2;
-                                bS[i] = (rp != rq || iabs(vp[0] - vq[0]) >= 4 || iabs(vp[1] - vq[1]) >= 4) ? 1 : 0;
-                            }
+                            bS[i] = (rp != rq || iabs(vp[0] - vq[0]) >= 4 || iabs(vp[1] - vq[1]) >= 4) ? 1 : 0;   /* :565-577, one list */
+                            if (pic->slice_type == P264_SLICE_B) bS[i] = b_motion_strength(pic, mbi, x, y, nbi, xn, yn);
                         }
                     }
                     int qp = m->qp, qpn = n->qp;

@@ -25,6 +25,7 @@ int oracle_deblock_picture(const p264hip_picture_t *pic, uint8_t **planes);
 /* coverage counters, see cpu_recon.c */
 void oracle_stats_reset(void);
 void oracle_stats_get(long long out[8]);
+long long oracle_bs_by_picture(void);
 long long oracle_bipred_blocks(void);      /* bi-predicted 4x4 blocks since the last reset (B pictures) */
 
 /* kernel-level entry points, one per reference function table entry (for known-answer tests) */

@@ -85,14 +85,40 @@ __device__ __forceinline__ int bs_motion(int vp, int vq, int rp, int rq)
     return (int)(rp != rq) | (int)(abs(dx) >= 4) | (int)(abs(dy) >= 4);
 }
 
-// TWO_LISTS: the batch holds B pictures - the motion test runs over both lists, as the reference's loop over l does
-// (core/frame.c:565-577; list by list, on the list INDICES, unused list = index -1 and zero vectors)
+__device__ __forceinline__ bool mv_far(int a, int b)
+{
+    return abs((int)(int16_t)a - (int)(int16_t)b) >= 4 || abs((a >> 16) - (b >> 16)) >= 4;
+}
+// B pictures, H.264 8.7.2.1: strength 1 when the two blocks predict from different reference PICTURES or a different number
+// of vectors, or when vectors belonging to the same picture differ by >= 4 quarter-pels.  p0 / p1, q0 / q1: the pictures the
+// two blocks read through list 0 / list 1 (told apart by their place in the frame store; ~0 = list unused, whose vector is
+// zero).  Either the lists correspond as they stand or crossed - with the same picture in both lists both are tried.  (The
+// reference's encoder-side loop, core/frame.c:565-577, compares list by list on the indices: the same thing only while no
+// picture sits in both lists.  Its decoder never gets here, decoder/macroblock.c:168-171.)
+__device__ __forceinline__ int bs_motion_b(uint32_t p0, uint32_t p1, uint32_t q0, uint32_t q1, int vp0, int vp1, int vq0, int vq1)
+{
+    const bool straight = p0 == q0 && p1 == q1 && !mv_far(vp0, vq0) && !mv_far(vp1, vq1);
+    const bool crossed  = p0 == q1 && p1 == q0 && !mv_far(vp0, vq1) && !mv_far(vp1, vq0);
+    return !(straight || crossed);
+}
+
+// TWO_LISTS: the batch holds B pictures (their motion test: bs_motion_b)
 template <bool TWO_LISTS>
 __global__ __launch_bounds__(256)
 void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info, uint32_t inv_mbw)
 {
     const PicDev *pd = pics + blockIdx.y;
     if (!pd->deblock) return;
+    const bool b_pic = TWO_LISTS && pd->slice_type == P264_SLICE_B;
+    // reference index -> picture (its offset in the frame store), both lists: lane-varying look-ups, so in LDS
+    __shared__ uint32_t pic_of[2][P264HIP_MAX_REFS];
+    if (TWO_LISTS) {
+        if (b_pic && threadIdx.x < 2 * P264HIP_MAX_REFS) {
+            const int l = threadIdx.x / P264HIP_MAX_REFS, k = threadIdx.x % P264HIP_MAX_REFS;
+            pic_of[l][k] = l == 0 ? pd->ref_off[k < pd->n_ref ? k : 0] : pd->ref_off_l1[k < pd->n_ref_l1 ? k : 0];
+        }
+        __syncthreads();
+    }
     const int mbi = blockIdx.x * 256 + threadIdx.x;
     if (mbi >= g.n_mb) return;
     int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
@@ -115,7 +141,9 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
     // list 1 of a B picture (everything zero otherwise: the extra test below is then always false)
     int mv1[16] = { 0 }, mv1Top[4] = { 0 }, mv1L[4] = { 0 };
     uint32_t refs1 = 0, refs1L = 0, refs1T = 0;
-    if (TWO_LISTS && pd->slice_type == P264_SLICE_B) {
+    // pictures per 8x8 quadrant: own (4), right column of the left macroblock (quadrants 1, 3), bottom row of the one above (2, 3)
+    uint32_t own0[4] = { 0 }, own1[4] = { 0 }, lft0[2] = { 0 }, lft1[2] = { 0 }, top0[2] = { 0 }, top1[2] = { 0 };
+    if (b_pic) {
         const int *m1 = pd->mv_l1;
         const uint4 a0 = gload4(m1 + mbi * 16), a1 = gload4(m1 + mbi * 16 + 4), a2 = gload4(m1 + mbi * 16 + 8), a3 = gload4(m1 + mbi * 16 + 12);
         const uint4 aT = gload4(m1 + ti * 16 + 12);
@@ -127,6 +155,16 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
 #pragma unroll
         for (int i = 0; i < 16; i++) mv1[i] = t[i];
         mv1Top[0] = (int)aT.x; mv1Top[1] = (int)aT.y; mv1Top[2] = (int)aT.z; mv1Top[3] = (int)aT.w;
+        auto pics_of = [&](uint32_t r0, uint32_t r1, int q, uint32_t &a, uint32_t &b) {
+            const int i0 = (int)(int8_t)(r0 >> (8 * q)), i1 = (int)(int8_t)(r1 >> (8 * q));
+            a = i0 < 0 ? ~0u : pic_of[0][i0 & (P264HIP_MAX_REFS - 1)];
+            b = i1 < 0 ? ~0u : pic_of[1][i1 & (P264HIP_MAX_REFS - 1)];
+            if (i0 < 0 && i1 < 0) a = pic_of[0][0];          // (no list at all: list 0, entry 0, as the motion compensation reads it)
+        };
+#pragma unroll
+        for (int q = 0; q < 4; q++) pics_of(refs, refs1, q, own0[q], own1[q]);
+        pics_of(refsL, refs1L, 1, lft0[0], lft1[0]); pics_of(refsL, refs1L, 3, lft0[1], lft1[1]);
+        pics_of(refsT, refs1T, 2, top0[0], top1[0]); pics_of(refsT, refs1T, 3, top0[1], top1[1]);
     }
 
     const int m_type = rec.x & 255, m_qp = (rec.x >> 8) & 255, m_edges = (rec.w >> 8) & 255;
@@ -152,9 +190,11 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
                 const int vq = mv[y * 4 + x], vp = !outer ? mv[yn * 4 + xn] : dir == 0 ? mL[y] : mvTop[x];
                 const int rq = ref_of(refs, x, y), rp = ref_of(!outer ? refs : dir == 0 ? refsL : refsT, xn, yn);
                 int bS = bs_motion(vp, vq, rp, rq);
-                if (TWO_LISTS) {
+                if (TWO_LISTS && b_pic) {
                     const int wq = mv1[y * 4 + x], wp = !outer ? mv1[yn * 4 + xn] : dir == 0 ? mv1L[y] : mv1Top[x];
-                    bS |= bs_motion(wp, wq, ref_of(!outer ? refs1 : dir == 0 ? refs1L : refs1T, xn, yn), ref_of(refs1, x, y));
+                    const int qq = (y >> 1) * 2 + (x >> 1), qn = (yn >> 1) * 2 + (xn >> 1);
+                    const uint32_t p0 = !outer ? own0[qn] : dir == 0 ? lft0[y >> 1] : top0[x >> 1], p1 = !outer ? own1[qn] : dir == 0 ? lft1[y >> 1] : top1[x >> 1];
+                    bS = bs_motion_b(p0, p1, own0[qq], own1[qq], vp, wp, vq, wq);
                 }
                 if (((mmask >> blk_at(x, y)) | (n_mask >> blk_at(xn, yn))) & 1) bS = 2;
                 if (m_intra | n_intra) bS = 3;                    // on a macroblock edge: the code of strength 4

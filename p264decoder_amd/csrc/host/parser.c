@@ -99,7 +99,8 @@ struct p264parse {
     dpb_frame_t dpb[P264HIP_MAX_REFS + 1];
     int cur_slot;
     int last_qp;                              /* never reset, like h->mb.i_last_qp (core/macroblock.c:1248-1252) */
-    int qp_pred;                              /* strict mode only */
+    int qp_pred;                              /* conformant chain only (strict_qp) */
+    int strict_qp;                            /* this slice: QP_Y = (QP_Y,PRED + mb_qp_delta + 52) % 52 (H.264 7.4.5) */
 
     /* current MB */
     int mbx, mby, mbi;
@@ -793,7 +794,7 @@ static void begin_mb(p264parse *p, p264hip_mb_t *m)
 /* QP bookkeeping of core/macroblock.c:1247-1252 (or the conformant chain in strict mode) */
 static void finish_mb_qp(p264parse *p, p264hip_mb_t *m, int has_residual_syntax, int qp)
 {
-    if (p->opts & P264PARSE_OPT_STRICT) {
+    if (p->strict_qp) {
         if (!has_residual_syntax) qp = p->qp_pred;
         p->qp_pred = qp;
     } else {
@@ -911,7 +912,7 @@ static int parse_mb_t(p264parse *p, bitrd_t *b, unsigned t, int intra_t)
     if (has_res) {
         int dqp = rd_mb_qp_delta(p, b);
         if (dqp < -52 || dqp > 52) { ERR(p, "mb_qp_delta out of range"); return -1; }
-        if (p->opts & P264PARSE_OPT_STRICT) qp = (p->qp_pred + dqp + 52) % 52;
+        if (p->strict_qp) qp = (p->qp_pred + dqp + 52) % 52;
         else qp = p->sh.qp + dqp;                 /* delta is NOT accumulated: decoder/macroblock.c:568 */
         if (rd_residual(p, b, m, &cf) < 0) { ERR(p, "read residual data failed"); return -1; }
     } else { memset(p->nnz + (size_t)p->mbi * 24, 0, 24); p->last_dqp = 0; }
@@ -1129,7 +1130,7 @@ static int parse_mb_b_t(p264parse *p, bitrd_t *b, unsigned t)
     if (has_res) {
         int dqp = rd_mb_qp_delta(p, b);
         if (dqp < -52 || dqp > 52) { ERR(p, "mb_qp_delta out of range"); return -1; }
-        if (p->opts & P264PARSE_OPT_STRICT) qp = (p->qp_pred + dqp + 52) % 52;
+        if (p->strict_qp) qp = (p->qp_pred + dqp + 52) % 52;
         else qp = p->sh.qp + dqp;
         if (rd_residual(p, b, m, &cf) < 0) { ERR(p, "read residual data failed"); return -1; }
     } else { memset(p->nnz + (size_t)p->mbi * 24, 0, 24); p->last_dqp = 0; }
@@ -1257,6 +1258,10 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
         }
     }
     p->qp_pred = sh.qp;
+    /* The reference's QP bookkeeping (delta added to the slice QP, last QP carried over residual-free macroblocks and across
+     * pictures: SURVEY A-Q2) is kept for what the reference decodes - Baseline CAVLC I / P slices.  It decodes neither CABAC nor
+     * B slices nor any other profile: there is no behaviour to match there, those streams get the standard's chain. */
+    p->strict_qp = (p->opts & P264PARSE_OPT_STRICT) || pps->cabac || p->sps[pps->sps_id].profile_idc != 66 || sh.type == P264_SLICE_B;
 
     p->cabac_on = pps->cabac;
     p->last_dqp = 0;

@@ -79,10 +79,13 @@ def _levels(rng, n, style):
 
 
 def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=0, level_style="small", qp_mode="random",
-                 mv_range=80, sub8x8=True, intra_share=0.15, slices=1, deblock_offsets=True, b_picture=False, n_ref_l1=1, weighted=None):
+                 mv_range=80, sub8x8=True, intra_share=0.15, slices=1, deblock_offsets=True, b_picture=False, n_ref_l1=1, weighted=None, mirror_l1=0.0):
     """Draw one picture.  qp_mode: 'random' (0..51 per macroblock), 'two' (two values), or an int (constant).
     b_picture: a B picture - every inter macroblock is P264_MB_B, each 8x8 quadrant predicts from list 0, list 1 or both
-    (a negative index = list unused, its vectors 0); weighted: None = drawn, else weighted_bipred on / off."""
+    (a negative index = list unused, its vectors 0); weighted: None = drawn, else weighted_bipred on / off; mirror_l1: share of
+    the B macroblocks whose list-1 vectors repeat their list-0 vectors (with the same frames in both lists: blocks that read the
+    same picture through different lists with equal vectors - the case where H.264 8.7.2.1's boundary strength by PICTURE and a
+    list-by-list comparison of indices differ)."""
     pic = SeamPicture(mb_w, mb_h)
     d = pic.desc
     n = mb_w * mb_h
@@ -224,6 +227,8 @@ def make_picture(rng, mb_w, mb_h, *, p_picture=True, n_ref=1, slots=2, dst_slot=
                         c1[(q >> 1) * 2:(q >> 1) * 2 + 2, (q & 1) * 2:(q & 1) * 2 + 2] = vec()
                 else:
                     c1 = rng.integers(-mv_range, mv_range + 1, size=(4, 4, 2))
+                if rng.random() < mirror_l1:
+                    c1 = cells.copy()
                 if skip:                            # (B_Skip / direct: whatever the derivation gave - here: both lists, one vector each)
                     dirs = [2] * 4
                 for q in range(4):

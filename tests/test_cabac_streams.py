@@ -33,7 +33,9 @@ def make(tmp_path, args, tag):
 
 @pytest.mark.parametrize("args", STREAMS)
 def test_cabac_and_cavlc_forms_parse_to_the_same_pictures(lib, tmp_path, args):
-    a = Parser(quiet=True, lib=lib).parse_stream(make(tmp_path, args, "cavlc"))
+    # (CABAC streams always get the standard's QP chain - the reference's own bookkeeping, SURVEY A-Q2, is kept for the Baseline
+    # CAVLC streams it can decode; the CAVLC twin of a stream without B pictures is Baseline: parsed strictly for the comparison)
+    a = Parser(quiet=True, strict=True, lib=lib).parse_stream(make(tmp_path, args, "cavlc"))
     c = Parser(quiet=True, lib=lib).parse_stream(make(tmp_path, args + " --cabac", "cabac"))
     assert len(a) == len(c) == int(args.split("--frames ")[1].split()[0])
     n_coef = 0
@@ -48,6 +50,23 @@ def test_cabac_and_cavlc_forms_parse_to_the_same_pictures(lib, tmp_path, args):
             assert list(p.desc.bipred_weight) == list(q.desc.bipred_weight)
         n_coef += p.desc.n_coef_blocks
     assert n_coef > 100
+
+
+def test_main_profile_streams_get_the_conformant_qp_chain(lib, tmp_path):
+    """mb_qp_delta accumulates (QP_Y = (QP_Y,PRED + delta + 52) % 52, H.264 7.4.5) in every stream the reference cannot decode -
+    CABAC, B slices, profiles other than Baseline - whether or not the strict option is set; Baseline CAVLC keeps the reference's
+    rule (delta added to the slice QP, decoder/macroblock.c:568) unless it is."""
+    qps = lambda pics: np.concatenate([p.mb_records()["qp"] for p in pics])
+    for args in (STREAMS[0] + " --cabac", STREAMS[4], STREAMS[4] + " --cabac"):            # CABAC I + P; Main CAVLC with B; Main CABAC with B
+        data = make(tmp_path, args, "m")
+        d, s = Parser(quiet=True, lib=lib).parse_stream(data), Parser(quiet=True, strict=True, lib=lib).parse_stream(data)
+        assert np.array_equal(qps(d), qps(s)), args
+        assert len(set(qps(d).tolist())) > 8
+    base = make(tmp_path, STREAMS[0], "b")                                                  # Baseline CAVLC, the same deltas
+    d, s = Parser(quiet=True, lib=lib).parse_stream(base), Parser(quiet=True, strict=True, lib=lib).parse_stream(base)
+    assert not np.array_equal(qps(d), qps(s))
+    # the reference's rule keeps every QP within +-6 of the slice QP (the writer draws its deltas that way); the chain wanders
+    assert int(np.abs(qps(d).astype(int) - 26).max()) <= 6 < int(np.abs(qps(s).astype(int) - 26).max())
 
 
 def test_truncated_and_damaged_cabac_streams_do_not_crash(lib, tmp_path):

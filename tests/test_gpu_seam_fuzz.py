@@ -29,6 +29,10 @@ CONFIGS = [
     ("b_pictures", 9, 7, 8, dict(level_style="small", qp_mode="random", n_ref=2, slots=4, b_picture=True, n_ref_l1=2)),
     ("b_pictures_far_wrap", 7, 6, 6, dict(level_style="mixed", qp_mode="random", n_ref=1, slots=3, b_picture=True, n_ref_l1=2, mv_range=500, slices=2)),
     ("b_pictures_weighted_smooth", 10, 6, 6, dict(level_style="small", qp_mode="two", n_ref=3, slots=4, b_picture=True, n_ref_l1=1, weighted=True, mv_range=12)),
+    # the same two frames in both lists, in opposite order, and list-1 vectors that often repeat the list-0 vectors: neighbouring
+    # blocks reach one picture through different lists (or crossed) with equal vectors - boundary strength 0 by H.264 8.7.2.1,
+    # 1 by a list-by-list comparison of the indices (what core/frame.c:565-577 does)
+    ("b_same_frames_swapped_lists", 10, 7, 8, dict(level_style="small", qp_mode="two", n_ref=2, slots=3, b_picture=True, n_ref_l1=2, mv_range=6, mirror_l1=0.7, sub8x8=False)),
 ]
 
 
@@ -127,7 +131,12 @@ def test_seam_fuzz(lib, oracle, name, mb_w, mb_h, n_pics, kw):
         assert oracle.oracle_bipred_blocks() > 100, "hardly any bi-predicted block"
         assert seen["dirs"] == {1, 2, 3}, "not every prediction direction (list 0, list 1, both) occurred: %s" % seen["dirs"]
         assert seen["weighted"] == ({1} if kw.get("weighted") else {0, 1}), seen["weighted"]
-        assert seen["b_roads"] >= {"list0 only", "list1 only", "generic", "second pass whole", "second pass quadrants", "second pass with carried quadrants"}, seen["b_roads"]
+        if kw.get("sub8x8", True):
+            assert seen["b_roads"] >= {"list0 only", "list1 only", "generic", "second pass whole", "second pass quadrants", "second pass with carried quadrants"}, seen["b_roads"]
+        if kw.get("mirror_l1"):
+            oracle.oracle_bs_by_picture.restype = C.c_longlong
+            assert oracle.oracle_bs_by_picture() > 20, "no edge segment whose strength by picture differs from the one by list index"
+
         assert {N.MB_I4x4, N.MB_I16x16, N.MB_B} <= seen["types"]
     else:
         assert {N.MB_I4x4, N.MB_I16x16, N.MB_P_L0, N.MB_P_8x8, N.MB_P_SKIP} <= seen["types"]

@@ -63,3 +63,6 @@ def test_fuzz_configurations_reach_the_paths_they_are_meant_for(oracle):
             assert st[6] > 0, (name, list(st))
         if kw["level_style"] in ("wrap", "mixed"):
             assert st[7] > 0, (name, list(st))
+        if kw.get("mirror_l1"):
+            oracle.oracle_bs_by_picture.restype = C.c_longlong
+            assert oracle.oracle_bs_by_picture() > 20, (name, oracle.oracle_bs_by_picture())

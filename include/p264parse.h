@@ -65,6 +65,25 @@ int p264_annexb_next(const uint8_t *buf, int64_t size, int64_t *pos, int64_t *na
 int p264cabac_decode_ops(const uint8_t *data, size_t bytes, int is_i_slice, int cabac_init_idc, int slice_qp,
                          const int16_t *ops, int n_ops, uint8_t *bins);
 
+/* Known-answer surface of the B-picture derivations (the macroblock layer's own static functions, run on hand-made state;
+ * tests/test_direct_kat.py drives them with vectors recorded from the reference's encoder-side
+ * p264_macroblock_bipred_init / p264_mb_predict_mv_direct16x16, core/macroblock.c:1400-1430, 254-413).
+ *
+ * p264parse_kat_bipred: implicit weights (H.264 8.4.2.3.1) of every (list-0, list-1) index pair, weights[r0 * 16 + r1] = weight
+ * of the list-0 prediction, from the picture order counts of the list entries (n0, n1 <= 8) and of the current picture.
+ *
+ * p264parse_kat_direct: direct prediction (8.4.1.2) of one macroblock.  nb_ref[l * 4 + n], nb_mv[(l * 4 + n) * 2 + c]: reference
+ * index and vector of the macroblock's neighbours n = A (left), B (top), C (top right), D (top left) in list l (-2 = not
+ * available, -1 = intra / list unused); col_*: the co-located macroblock of RefPicList1[0] - intra or not, col_ref[l * 4 + q]
+ * per 8x8 quadrant, col_mv[(l * 16 + b) * 2 + c] per 4x4 block in raster order; poc0[n0]: order counts of the current list 0,
+ * poc1_0 of RefPicList1[0], cur_poc of the current picture; col_list_poc[n_col_list]: order counts of the list 0 the co-located
+ * picture was decoded with.  direct_8x8_inference off, no long-term pictures.  out_ref[l * 4 + q], out_mv[(l * 16 + b) * 2 + c].
+ * Both return 0, or -1 on a bad argument. */
+int p264parse_kat_bipred(int n0, const int *poc0, int n1, const int *poc1, int cur_poc, int16_t *weights);
+int p264parse_kat_direct(int spatial, const int8_t *nb_ref, const int16_t *nb_mv, int col_intra, const int8_t *col_ref, const int16_t *col_mv,
+                         int n0, const int *poc0, int poc1_0, int cur_poc, int n_col_list, const int *col_list_poc,
+                         int8_t *out_ref, int16_t *out_mv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,3 +145,68 @@ int refk_cabac_encode(int slice_type, int qp, int model, const int16_t *ops, con
 }
 int refk_slice_type_i(void) { return SLICE_TYPE_I; }
 int refk_slice_type_p(void) { return SLICE_TYPE_P; }
+
+/* ---- B pictures: implicit weights and direct prediction (SURVEY 8c "partial pins" for configs 4-5) -----------------------
+ *      p264_macroblock_bipred_init (core/macroblock.c:1400-1430) and p264_mb_predict_mv_direct16x16 (:254-413) are encoder-side
+ *      code the reference's decoder never reaches, but they are non-static: driven here on hand-made state. */
+static p264_frame_t g_l0[16], g_l1[16], g_cur, g_col;
+static int8_t g_col_type[1], g_col_ref[2][4];
+static int16_t g_col_mv[2][16][2];
+
+/* weights / distance scale factors of every (list-0, list-1) index pair from the pictures' order counts */
+void refk_bipred_init(int n0, const int *poc0, int n1, const int *poc1, int cur_poc, int weighted, int *dsf_out, int *w_out)
+{
+    for (int i = 0; i < n0; i++) { g_l0[i].i_poc = poc0[i]; g_h->fref0[i] = &g_l0[i]; }
+    for (int i = 0; i < n1; i++) { g_l1[i].i_poc = poc1[i]; g_h->fref1[i] = &g_l1[i]; }
+    g_h->i_ref0 = n0; g_h->i_ref1 = n1;
+    g_cur.i_poc = cur_poc; g_h->fdec = &g_cur;
+    g_h->param.analyse.b_weighted_bipred = weighted;
+    p264_macroblock_bipred_init(g_h);
+    for (int i = 0; i < 16; i++)
+        for (int k = 0; k < 16; k++) { dsf_out[i * 16 + k] = g_h->mb.dist_scale_factor[i][k]; w_out[i * 16 + k] = g_h->mb.bipred_weight[i][k]; }
+}
+
+/* Direct prediction of one macroblock.
+ *   nb_ref[l][n], nb_mv[l][n][2]: the neighbours A (left), B (top), C (top right), D (top left) of the macroblock per list;
+ *                                 ref -2 = not available, -1 = intra / list unused
+ *   col_*: the co-located macroblock in RefPicList1[0]: intra or not, reference indices per 8x8 and vectors per 4x4 (raster),
+ *          both lists
+ *   temporal only: map_col[i] = index in the current list 0 of the picture the co-located picture's list-0 index i names
+ *          (-2 = not there), dsf[i] = dist_scale_factor[i][0] (refk_bipred_init)
+ * Returns what the function returns (0 = "direct prediction not available"); out_ref[l][q], out_mv[l][4x4 raster][2]. */
+int refk_direct(int spatial, const int8_t *nb_ref, const int16_t *nb_mv, int col_intra, const int8_t *col_ref, const int16_t *col_mv,
+                const int *map_col, const int *dsf, int8_t *out_ref, int16_t *out_mv)
+{
+    p264_t *h = g_h;
+    static const int nb_at[4] = { P264_SCAN8_0 - 1, P264_SCAN8_0 - 8, P264_SCAN8_0 - 8 + 4, P264_SCAN8_0 - 8 - 1 };
+    memset(&h->mb.cache, 0, sizeof h->mb.cache);
+    for (int l = 0; l < 2; l++) {
+        memset(h->mb.cache.ref[l], -2, sizeof h->mb.cache.ref[l]);
+        for (int n = 0; n < 4; n++) {
+            h->mb.cache.ref[l][nb_at[n]] = nb_ref[l * 4 + n];
+            h->mb.cache.mv[l][nb_at[n]][0] = nb_mv[(l * 4 + n) * 2]; h->mb.cache.mv[l][nb_at[n]][1] = nb_mv[(l * 4 + n) * 2 + 1];
+        }
+    }
+    g_col_type[0] = col_intra ? I_4x4 : P_L0;
+    memcpy(g_col_ref, col_ref, sizeof g_col_ref);
+    memcpy(g_col_mv, col_mv, sizeof g_col_mv);
+    g_col.mb_type = g_col_type;
+    for (int l = 0; l < 2; l++) { g_col.ref[l] = g_col_ref[l]; g_col.mv[l] = g_col_mv[l]; }
+    h->fref1[0] = &g_col;
+    h->mb.i_mb_x = h->mb.i_mb_y = h->mb.i_mb_xy = h->mb.i_b8_xy = h->mb.i_b4_xy = 0;
+    h->mb.i_mb_stride = 1; h->mb.i_b8_stride = 2; h->mb.i_b4_stride = 4;
+    h->mb.i_partition = D_16x16;
+    h->param.analyse.i_direct_mv_pred = spatial ? P264_DIRECT_PRED_SPATIAL : P264_DIRECT_PRED_TEMPORAL;
+    h->sh.b_direct_spatial_mv_pred = spatial;
+    h->mb.map_col_to_list0[-1] = -1; h->mb.map_col_to_list0[-2] = -2;
+    for (int i = 0; i < 16; i++) { h->mb.map_col_to_list0[i] = map_col[i]; h->mb.dist_scale_factor[i][0] = dsf[i]; }
+    const int ok = p264_mb_predict_mv_direct16x16(h);
+    for (int l = 0; l < 2; l++) {
+        for (int q = 0; q < 4; q++) out_ref[l * 4 + q] = h->mb.cache.ref[l][P264_SCAN8_0 + (q & 1) * 2 + (q >> 1) * 16];
+        for (int b = 0; b < 16; b++) {
+            out_mv[(l * 16 + b) * 2] = h->mb.cache.mv[l][P264_SCAN8_0 + (b & 3) + (b >> 2) * 8][0];
+            out_mv[(l * 16 + b) * 2 + 1] = h->mb.cache.mv[l][P264_SCAN8_0 + (b & 3) + (b >> 2) * 8][1];
+        }
+    }
+    return ok;
+}

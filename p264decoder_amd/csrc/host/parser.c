@@ -1394,3 +1394,98 @@ int p264_annexb_next(const uint8_t *buf, int64_t size, int64_t *pos, int64_t *na
     *nal_off = start; *nal_len = end - start;
     return 1;
 }
+
+/* ---------------------------------------------------------------- known-answer surface ---- */
+/* B-picture derivations on hand-made state (tests/test_direct_kat.py drives them with the vectors recorded from the reference's
+ * encoder-side functions, tests/golden/kat_direct.npz): the same static functions the macroblock layer calls, on a parser whose
+ * picture is 3 x 2 macroblocks with the current one at (1, 1). */
+static p264parse *kat_state(void)
+{
+    p264parse *p = (p264parse *)calloc(1, sizeof *p);
+    if (!p) return NULL;
+    p->mb_w = 3; p->mb_h = 2; p->n_mb = 6; p->slots = P264HIP_MAX_REFS + 1;
+    picbuf_t *q = &p->buf[0];
+    q->mv = (int16_t *)calloc(6 * 32, sizeof(int16_t)); q->mv1 = (int16_t *)calloc(6 * 32, sizeof(int16_t));
+    q->ref = (int8_t *)malloc(6 * 4); q->ref1 = (int8_t *)malloc(6 * 4);
+    for (int i = 0; i <= P264HIP_MAX_REFS; i++) {
+        p->col_mv[i] = (int16_t *)calloc(6 * 32, sizeof(int16_t)); p->col_ref[i] = (int8_t *)malloc(6 * 4); p->col_uid[i] = (int32_t *)malloc(6 * 4 * sizeof(int32_t));
+    }
+    p->has_col = 1; p->active_sps = 0;
+    p->mbx = 1; p->mby = 1; p->mbi = 4;
+    return p;
+}
+static void kat_free(p264parse *p)
+{
+    free(p->buf[0].mv); free(p->buf[0].mv1); free(p->buf[0].ref); free(p->buf[0].ref1);
+    for (int i = 0; i <= P264HIP_MAX_REFS; i++) { free(p->col_mv[i]); free(p->col_ref[i]); free(p->col_uid[i]); }
+    free(p);
+}
+/* lists of a B picture from picture order counts: slot i holds list-0 entry i, slot n0 + k list-1 entry k unless that picture
+ * (same order count) already sits in list 0 */
+static void kat_lists(p264parse *p, int n0, const int *poc0, int n1, const int *poc1, int cur_poc)
+{
+    int n = 0;
+    for (int i = 0; i < n0; i++) { p->dpb[n].used = 1; p->dpb[n].poc = poc0[i]; p->dpb[n].uid = (uint32_t)(poc0[i] + 4096); p->list0[i] = n++; }
+    for (int k = 0; k < n1; k++) {
+        int s = -1;
+        for (int i = 0; i < n0; i++) if (poc0[i] == poc1[k]) { s = p->list0[i]; break; }
+        if (s < 0) { p->dpb[n].used = 1; p->dpb[n].poc = poc1[k]; p->dpb[n].uid = (uint32_t)(poc1[k] + 4096); s = n++; }
+        p->list1[k] = s;
+    }
+    p->n_list0 = n0; p->n_list1 = n1; p->cur_poc = cur_poc;
+}
+
+int p264parse_kat_bipred(int n0, const int *poc0, int n1, const int *poc1, int cur_poc, int16_t *weights)
+{
+    if (n0 < 0 || n1 < 0 || n0 > 8 || n1 > 8) return -1;
+    p264parse *p = kat_state();
+    if (!p) return -1;
+    kat_lists(p, n0, poc0, n1, poc1, cur_poc);
+    p->weighted_bipred = 1;
+    implicit_weights(p);
+    memcpy(weights, p->bipred_weight, sizeof p->bipred_weight);
+    kat_free(p);
+    return 0;
+}
+
+int p264parse_kat_direct(int spatial, const int8_t *nb_ref, const int16_t *nb_mv, int col_intra, const int8_t *col_ref, const int16_t *col_mv,
+                         int n0, const int *poc0, int poc1_0, int cur_poc, int n_col_list, const int *col_list_poc,
+                         int8_t *out_ref, int16_t *out_mv)
+{
+    if (n0 < 1 || n0 > 8 || n_col_list < 0 || n_col_list > 8) return -1;
+    p264parse *p = kat_state();
+    if (!p) return -1;
+    kat_lists(p, n0, poc0, 1, &poc1_0, cur_poc);
+    p->sh.direct_spatial = spatial;
+    picbuf_t *q = &p->buf[0];
+    memset(q->ref, -1, 24); memset(q->ref1, -1, 24);
+    /* neighbours A, B, C, D: the 4x4 block left of / above / above right of / above left of the macroblock's first block */
+    static const int nb_mb[4] = { 3, 1, 2, 0 }, nb_quad[4] = { 1, 2, 2, 3 }, nb_sub[4] = { 3, 12, 12, 15 };
+    static const int nb_flag[4] = { P264_AVAIL_LEFT, P264_AVAIL_TOP, P264_AVAIL_TOPRIGHT, P264_AVAIL_TOPLEFT };
+    p->cur_avail = 0;
+    for (int n = 0; n < 4; n++) {
+        if (nb_ref[n] != -2) p->cur_avail |= nb_flag[n];        /* (availability is a property of the macroblock: both lists agree) */
+        for (int l = 0; l < 2; l++) {
+            (l ? q->ref1 : q->ref)[nb_mb[n] * 4 + nb_quad[n]] = nb_ref[l * 4 + n] < 0 ? -1 : nb_ref[l * 4 + n];
+            int16_t *mv = (l ? q->mv1 : q->mv) + (nb_mb[n] * 16 + nb_sub[n]) * 2;
+            mv[0] = nb_mv[(l * 4 + n) * 2]; mv[1] = nb_mv[(l * 4 + n) * 2 + 1];
+        }
+    }
+    /* the co-located macroblock as finish_picture_marking would have left it: the list-0 motion where there is one, else list 1 */
+    const int cs = p->list1[0];
+    for (int q8 = 0; q8 < 4; q8++) {
+        const int r0 = col_intra ? -1 : col_ref[q8], r1 = col_intra ? -1 : col_ref[4 + q8], r = r0 >= 0 ? r0 : r1;
+        p->col_ref[cs][p->mbi * 4 + q8] = (int8_t)r;
+        p->col_uid[cs][p->mbi * 4 + q8] = r < 0 || r >= n_col_list ? -1 : col_list_poc[r] + 4096;   /* (list 1 of the co-located picture: not modelled, see the test) */
+        for (int k = 0; k < 4; k++) {
+            const int blk = (q8 >> 1) * 8 + (q8 & 1) * 2 + (k >> 1) * 4 + (k & 1);
+            const int16_t *src = col_mv + ((r0 >= 0 ? 0 : 16) + blk) * 2;
+            p->col_mv[cs][(p->mbi * 16 + blk) * 2] = r < 0 ? 0 : src[0]; p->col_mv[cs][(p->mbi * 16 + blk) * 2 + 1] = r < 0 ? 0 : src[1];
+        }
+    }
+    direct_t d;
+    direct_predict(p, &d);
+    memcpy(out_ref, d.ref, sizeof d.ref); memcpy(out_mv, d.mv, sizeof d.mv);
+    kat_free(p);
+    return 0;
+}

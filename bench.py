@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 MB_W, MB_H = 120, 68
 N_MB = MB_W * MB_H
 DISTINCT = 4                   # distinct synthetic streams per rank; the S streams cycle through private copies of them
-STAGE_KERNELS = {"inter": "k_mc_sort + k_mc", "intra": "k_intra",
+STAGE_KERNELS = {"inter": "k_mc_sort + k_mc", "intra": "k_intra_sparse",      # (the timed launches hold P pictures only: the sparse build of k_intra)
                  "deblock": "k_deblock_bs + k_deblock"}
 
 
@@ -150,8 +150,8 @@ def extras(lib):
                                                 "last_picture_matches_oracle": digest == synth_cases.oracle_golden(name)[1][-1],
                                                 "cabac_parse_fps_one_thread": round(parse_fps, 1),
                                                 "what": "BASELINE config 4: 1920x1080 Main profile, CABAC, I+P+B (two B pictures between reference pictures, implicit weights, "
-                                                        "direct prediction), deblocking; reconstruction of resident inputs as in `value`.  B macroblocks take the generic "
-                                                        "two-list class of the MC kernels.  Pinned to the CPU oracle only - the reference decodes neither CABAC nor B pictures"}
+                                                        "direct prediction), deblocking; reconstruction of resident inputs as in `value`.  Bi-predicted blocks take two passes "
+                                                        "through the MC stage (k_mc, k_mc_second).  Pinned to the CPU oracle only - the reference decodes neither CABAC nor B pictures"}
     except Exception as e:
         out["config4_1080p_main_cabac_ipb"] = {"error": str(e)}
     # end to end: Annex-B bytes in host memory -> pictures in HBM, host CAVLC parse and PCIe uploads included.  The parse is

@@ -102,39 +102,29 @@ __device__ __forceinline__ int bs_motion_b(uint32_t p0, uint32_t p1, uint32_t q0
     return !(straight || crossed);
 }
 
-// TWO_LISTS: the batch holds B pictures (their motion test: bs_motion_b)
-template <bool TWO_LISTS>
-__global__ __launch_bounds__(256)
-void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info, uint32_t inv_mbw)
+// The edge info of one macroblock from its record, vectors and reference indices plus what it loads of the neighbours.  TWO_LISTS: B pictures in the batch (their motion test:
+// bs_motion_b; pic_of = reference index -> picture, both lists, in LDS).
+struct PicOf { uint32_t of[2][P264HIP_MAX_REFS]; };
+__device__ __forceinline__ void pic_of_init(PicOf &T, const PicDev *pd)
 {
-    const PicDev *pd = pics + blockIdx.y;
-    if (!pd->deblock) return;
-    const bool b_pic = TWO_LISTS && pd->slice_type == P264_SLICE_B;
-    // reference index -> picture (its offset in the frame store), both lists: lane-varying look-ups, so in LDS
-    __shared__ uint32_t pic_of[2][P264HIP_MAX_REFS];
-    if (TWO_LISTS) {
-        if (b_pic && threadIdx.x < 2 * P264HIP_MAX_REFS) {
-            const int l = threadIdx.x / P264HIP_MAX_REFS, k = threadIdx.x % P264HIP_MAX_REFS;
-            pic_of[l][k] = l == 0 ? pd->ref_off[k < pd->n_ref ? k : 0] : pd->ref_off_l1[k < pd->n_ref_l1 ? k : 0];
-        }
-        __syncthreads();
+    if (threadIdx.x < 2 * P264HIP_MAX_REFS) {
+        const int l = threadIdx.x / P264HIP_MAX_REFS, k = threadIdx.x % P264HIP_MAX_REFS;
+        T.of[l][k] = l == 0 ? pd->ref_off[k < pd->n_ref ? k : 0] : pd->ref_off_l1[k < pd->n_ref_l1 ? k : 0];
     }
-    const int mbi = blockIdx.x * 256 + threadIdx.x;
-    if (mbi >= g.n_mb) return;
-    int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
-    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
-    const int mbx = mbi - mby * g.mb_w;
+}
+template <bool TWO_LISTS>
+__device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, int mbi, int mbx, int mby, const uint4 rec,
+                                              const uint4 m0, const uint4 m1, const uint4 m2, const uint4 m3, const uint32_t refs, const PicOf *pic_tab)
+{
+    const bool b_pic = TWO_LISTS && pd->slice_type == P264_SLICE_B;
     const int li = mbx > 0 ? mbi - 1 : mbi, ti = mby > 0 ? mbi - g.mb_w : mbi;       // neighbours (self where there is none: unused)
-
-    // ---- all loads ----
     const uint4 *recs = (const uint4 *)pd->mb;
-    const uint4 rec = gload4(recs + mbi), recL = gload4(recs + li), recT = gload4(recs + ti);
+    const uint4 recL = gload4(recs + li), recT = gload4(recs + ti);
     const int *mvs = pd->mv;
-    const uint4 m0 = gload4(mvs + mbi * 16), m1 = gload4(mvs + mbi * 16 + 4), m2 = gload4(mvs + mbi * 16 + 8), m3 = gload4(mvs + mbi * 16 + 12);
     const uint4 mT = gload4(mvs + ti * 16 + 12);                                       // bottom row of the macroblock above
     const AS1 int *mvg = glob(mvs);
     const int mL[4] = { mvg[li * 16 + 3], mvg[li * 16 + 7], mvg[li * 16 + 11], mvg[li * 16 + 15] };   // right column of the left one
-    const uint32_t refs = gload1(pd->ref_idx + mbi * 4), refsL = gload1(pd->ref_idx + li * 4), refsT = gload1(pd->ref_idx + ti * 4);
+    const uint32_t refsL = gload1(pd->ref_idx + li * 4), refsT = gload1(pd->ref_idx + ti * 4);
     const int mv[16] = { (int)m0.x, (int)m0.y, (int)m0.z, (int)m0.w, (int)m1.x, (int)m1.y, (int)m1.z, (int)m1.w,
                          (int)m2.x, (int)m2.y, (int)m2.z, (int)m2.w, (int)m3.x, (int)m3.y, (int)m3.z, (int)m3.w };
     const int mvTop[4] = { (int)mT.x, (int)mT.y, (int)mT.z, (int)mT.w };
@@ -157,9 +147,9 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
         mv1Top[0] = (int)aT.x; mv1Top[1] = (int)aT.y; mv1Top[2] = (int)aT.z; mv1Top[3] = (int)aT.w;
         auto pics_of = [&](uint32_t r0, uint32_t r1, int q, uint32_t &a, uint32_t &b) {
             const int i0 = (int)(int8_t)(r0 >> (8 * q)), i1 = (int)(int8_t)(r1 >> (8 * q));
-            a = i0 < 0 ? ~0u : pic_of[0][i0 & (P264HIP_MAX_REFS - 1)];
-            b = i1 < 0 ? ~0u : pic_of[1][i1 & (P264HIP_MAX_REFS - 1)];
-            if (i0 < 0 && i1 < 0) a = pic_of[0][0];          // (no list at all: list 0, entry 0, as the motion compensation reads it)
+            a = i0 < 0 ? ~0u : pic_tab->of[0][i0 & (P264HIP_MAX_REFS - 1)];
+            b = i1 < 0 ? ~0u : pic_tab->of[1][i1 & (P264HIP_MAX_REFS - 1)];
+            if (i0 < 0 && i1 < 0) a = pic_tab->of[0][0];          // (no list at all: list 0, entry 0, as the motion compensation reads it)
         };
 #pragma unroll
         for (int q = 0; q < 4; q++) pics_of(refs, refs1, q, own0[q], own1[q]);
@@ -209,7 +199,33 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
     const uint32_t avg = (uint32_t)((m_qp + qpL + 1) >> 1) | (uint32_t)((m_qp + qpT + 1) >> 1) << 6
                        | (uint32_t)((cq_own + chroma_qp(clip3i(qpL + cqo, 0, 51)) + 1) >> 1) << 12
                        | (uint32_t)((cq_own + chroma_qp(clip3i(qpT + cqo, 0, 51)) + 1) >> 1) << 18 | (uint32_t)cq_own << 24;
-    gstore4(info + (size_t)blockIdx.y * g.n_mb + mbi, make_uint4(word[0], word[1], (uint32_t)m_qp, avg));
+    return make_uint4(word[0], word[1], (uint32_t)m_qp, avg);
+}
+
+// One lane per macroblock.  (Round 4 also had the work-list sort of the MC stage write the edge info while it holds the same
+// arrays in registers - scratch/r4_fuse/: the sort went from 0.32 to 0.49 ms (112 bytes per lane of spills), this kernel's
+// 0.19 ms went away: -0.03 ms per step, and 0.16 ms of loop-filter work booked on the MC stage.  Not adopted.)
+template <bool TWO_LISTS>
+__global__ __launch_bounds__(256)
+void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict__ info, uint32_t inv_mbw)
+{
+    const PicDev *pd = pics + blockIdx.y;
+    if (!pd->deblock) return;
+    __shared__ PicOf pic_tab;
+    if (TWO_LISTS) {
+        if (pd->slice_type == P264_SLICE_B) pic_of_init(pic_tab, pd);
+        __syncthreads();
+    }
+    const int mbi = blockIdx.x * 256 + threadIdx.x;
+    if (mbi >= g.n_mb) return;
+    int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+    if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+    const int mbx = mbi - mby * g.mb_w;
+    const uint4 rec = gload4((const uint4 *)pd->mb + mbi);
+    const int *mvs = pd->mv;
+    const uint4 m0 = gload4(mvs + mbi * 16), m1 = gload4(mvs + mbi * 16 + 4), m2 = gload4(mvs + mbi * 16 + 8), m3 = gload4(mvs + mbi * 16 + 12);
+    const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
+    gstore4(info + (size_t)blockIdx.y * g.n_mb + mbi, edge_info_of<TWO_LISTS>(pd, g, mbi, mbx, mby, rec, m0, m1, m2, m3, refs, &pic_tab));
 }
 
 // alpha | tc0 of strengths 1..3 (one dword per index A) and beta (per index B): core/frame.c:262-291

@@ -40,6 +40,13 @@
 // core/quant.c:66-99,138-159, core/dct.c:55-68,205-247 with their int16 stores (A-Q8).
 #pragma once
 #include "device_common.h"
+// timing experiments (scratch/r4_mcexp.sh): results are wrong unless all defaults hold
+#ifndef EXPM_LUMA_COPY
+#define EXPM_LUMA_COPY 0
+#endif
+#ifndef EXPM_RESID
+#define EXPM_RESID 1
+#endif
 
 // ------------------------------------------------------------------------------------------
 // work lists
@@ -902,7 +909,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         }
         wave_lds_fence();
         const LWin<I::PITCH> w = { img, xs & ~3, wy };
-        mc_luma_class(pc, out, w, ix, iy, fx, fy);
+        mc_luma_class(EXPM_LUMA_COPY ? PC_COPY : pc, out, w, ix, iy, fx, fy);
     } else {
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
         // straight from memory, one pass per phase class present among the lanes.
@@ -966,7 +973,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         for (int y = 0; y < 4; y++) out[y] = pd->weighted ? bipred_weight4(p0[y], out[y], wgt) : bipred_avg4(p0[y], out[y]);
     }
     // ---- residual (decoder/macroblock.c:839-847) ----
-    if ((key & MCY_RESID) && __ballot(coded)) {
+    if (EXPM_RESID && (key & MCY_RESID) && __ballot(coded)) {
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<false>(lv, col);
@@ -1225,7 +1232,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
         }
     }
     // ---- residual (decoder/macroblock.c:851-890): chroma DC through the 2x2 transform, AC, inverse transform ----
-    if ((key & MCC_RESID) && __ballot(has_res)) {
+    if (EXPM_RESID && (key & MCC_RESID) && __ballot(has_res)) {
         const int qpc = chroma_qp(clip3i((int)(e.z >> 26) + pd->chroma_qp_offset, 0, 51));
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];

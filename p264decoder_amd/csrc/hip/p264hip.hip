@@ -11,9 +11,9 @@
 #include <vector>
 #include "p264hip.h"
 #include "device_common.h"
+#include "kernel_deblock.h"
 #include "kernel_mc.h"
 #include "kernel_intra.h"
-#include "kernel_deblock.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, ...)
@@ -82,12 +82,6 @@ struct p264hip_ctx {
     McLayout ml;
     std::vector<int> stream_seen;          // p264hip_reconstruct: batch index + 1 that last named a stream in the current call
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
-    // side streams: the four motion-compensation kernels write disjoint samples (luma / chroma, whole macroblocks /
-    // quadrants) and k_deblock_bs reads no samples at all, so they run next to each other; events fork them off the
-    // context's stream and join them back
-    hipStream_t side[4] = {};
-    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[4] = {};
-    bool concurrent = false;      // P264AMD_CONCURRENT=1: measured no gain at full batches (every kernel fills the chip on its own), kept as a knob
     // tuning knobs, read from the environment ONCE (p264hip_create); 0 = built-in choice
     int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0;
     hipEvent_t markers[P264HIP_MARKERS] = {};
@@ -134,10 +128,6 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     c->pics.resize((size_t)max_pictures);
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming); }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming);
-    if (const char *env = getenv("P264AMD_CONCURRENT")) c->concurrent = atoi(env) != 0;
     if (const char *env = getenv("P264AMD_MC_WGS_PER_PIC")) c->tune_mc_wgs = atoi(env);
     if (const char *env = getenv("P264AMD_INTRA_WAVES")) c->tune_intra_waves = atoi(env);
     if (const char *env = getenv("P264AMD_DEBLOCK_RB_LOG2")) c->tune_rb_log2 = atoi(env);
@@ -175,9 +165,6 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     if (c->d_mc) (void)hipFree(c->d_mc);
     if (c->d_planar) (void)hipFree(c->d_planar);
     for (auto &m : c->markers) if (m) (void)hipEventDestroy(m);
-    for (int i = 0; i < 4; i++) { if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); } }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -398,19 +385,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     HIPCHK(hipMemcpyAsync(c->d_batch[r], hb, (size_t)n * sizeof(PicDev), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->batch_free[r], c->stream));
     const Geom g = c->g;
-    const bool conc = c->concurrent;
     const uint32_t inv_mbw = (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w);
-    // the boundary strengths depend on the parsed arrays only: k_deblock_bs runs beside everything up to the sample filter
-    hipStream_t bs_stream = conc ? c->side[3] : c->stream;
-    auto launch_bs = [&]() {
-        if (any_b) hipLaunchKernelGGL(k_deblock_bs<true>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, bs_stream, c->d_batch[r], g, c->d_edge, inv_mbw);
-        else       hipLaunchKernelGGL(k_deblock_bs<false>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, bs_stream, c->d_batch[r], g, c->d_edge, inv_mbw);
-    };
-    bool bs_forked = false;
-    if (conc) {
-        HIPCHK(hipEventRecord(c->ev_fork, c->stream));               // behind the descriptor copy
-        HIPCHK(hipStreamWaitEvent(c->side[3], c->ev_fork, 0));
-    }
     if (any_p) {
         // motion compensation + residual of all inter macroblocks: device-side counting sort of the work items by what the
         // interpolation has to do, then the luma and chroma kernels over the sorted lists (kernel_mc.h), side by side
@@ -435,7 +410,6 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
             hipLaunchKernelGGL(k_mc_second, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, c->stream, (const PicDev *)c->d_batch[r], (const uint32_t *)c->d_mc, g, ml,
                                wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
     }
-    if (conc) { launch_bs(); HIPCHK(hipEventRecord(c->ev_join[3], c->side[3])); bs_forked = true; }
     {
         ScopedStamp t(c, 1);
         // one workgroup per picture: 16 wavefronts while every picture can have a CU to itself, else 8 or 4 so that two or
@@ -449,7 +423,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     }
     {
         ScopedStamp t(c, 2);
-        if (bs_forked) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[3], 0)); else launch_bs();
+        // edge info (boundary strengths, averaged QPs per edge class): everything about an edge that does not depend on samples
+        if (any_b) hipLaunchKernelGGL(k_deblock_bs<true>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, inv_mbw);
+        else       hipLaunchKernelGGL(k_deblock_bs<false>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, inv_mbw);
         // a wavefront filters 8 macroblock rows at a time: 8 rows of one picture while there are no more
         // pictures than compute units, else 4 rows of two pictures (or 2 of four) per workgroup
         // pictures per workgroup = as many as it takes to cover the batch with one workgroup per CU (at most 4; a

@@ -11,7 +11,7 @@ void p264cabac_init_contexts(p264cabac_t *c, int is_i_slice, int cabac_init_idc,
     for (int i = 0; i < P264_CABAC_CONTEXTS; i++) {
         int pre = ((cabac_mn[i][t][0] * qp) >> 4) + cabac_mn[i][t][1];           /* preCtxState, 9.3.1.1 */
         pre = pre < 1 ? 1 : pre > 126 ? 126 : pre;
-        c->state[i] = pre <= 63 ? (uint8_t)((63 - pre) << 1) : (uint8_t)((pre - 64) << 1 | 1);
+        c->state[i] = pre <= 63 ? (uint16_t)((63 - pre) << 1) : (uint16_t)((pre - 64) << 1 | 1);
     }
     /* state transitions (9.3.3.2.1.1) on the packed state byte: MPS -> transIdxMPS = min(pStateIdx + 1, 62); LPS -> table 9-45,
      * and at pStateIdx 0 the MPS flips */

@@ -28,7 +28,9 @@ typedef struct p264cabac {
     const uint8_t *data;
     size_t   size, pos;                /* bytes of the data / bytes taken so far (counts on behind the end: zeros) */
     uint8_t  next[128][2];             /* state byte behind a bin decoded as the MPS / as the LPS */
-    uint8_t  state[P264_CABAC_CONTEXTS];   /* pStateIdx << 1 | valMPS */
+    /* (16-bit entries although a byte would do: a byte store may alias every field of this struct, and the compiler then reloads
+     * range, n and low from memory after each bin; with a 16-bit store they stay in registers across a run of bins) */
+    uint16_t state[P264_CABAC_CONTEXTS];   /* pStateIdx << 1 | valMPS */
 } p264cabac_t;
 
 /* 9.3.1.1: every context from its (m, n) pair.  is_i_slice: table of I slices, else of cabac_init_idc (0..2). */

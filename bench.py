@@ -92,9 +92,10 @@ def cpu_model():
     return "unknown"
 
 
-def run_batched(lib, pics, S, mb_w, mb_h, slots):
+def run_batched(lib, pics, S, mb_w, mb_h, slots, stages=None):
     """All pictures of one parsed stream on S streams side by side (private clones), inputs resident: pictures/s and the
-    hash of stream S-1's last picture."""
+    hash of stream S-1's last picture.  stages: a dict that receives, per slice type, the stage times of one more (untimed)
+    pass over the pictures, measured with HIP events on the context's stream like the metric's."""
     from p264decoder_amd import HipReconstructor
     from tests.conftest import frame_sha256
     T = len(pics)
@@ -113,8 +114,48 @@ def run_batched(lib, pics, S, mb_w, mb_h, slots):
     hip.sync()
     dt = time.perf_counter() - t0
     digest = frame_sha256(*hip.read_frame(S - 1, pics[-1].desc.dst_slot))
+    if stages is not None:
+        hip.timing_enable(True)
+        acc = {}
+        for t in range(T):
+            hip.timing_reset()
+            hip.reconstruct([s * T + t for s in streams], streams)
+            hip.sync()
+            a = acc.setdefault("IPB"[(2, 0, 1).index(pics[t].desc.slice_type)], {"launches": 0, "inter": 0.0, "intra": 0.0, "deblock": 0.0, "reconstruct": 0.0})
+            a["launches"] += 1
+            for k, (ms, cnt) in hip.timing_read().items():
+                a[k] += ms
+        hip.timing_enable(False)
+        for a in acc.values():
+            for k in ("inter", "intra", "deblock", "reconstruct"):
+                a[k] = round(a[k] / a["launches"], 4)
+        stages.update(acc)
     hip.close()
     return S * T / dt, digest
+
+
+def bipred_bytes(pics):
+    """SURVEY 8d's count for the MC stage of B pictures: per 8x8 quadrant and list used 96 bytes of reference samples read, per
+    macroblock and list used 64 + 4 bytes of motion, 384 bytes written per inter macroblock (one list: the 836 bytes of a P
+    macroblock).  Returns (bytes per B launch and stream, inter macroblocks, share of quadrants that use both lists)."""
+    import numpy as np
+    total = n_inter = 0
+    bi = quads = 0
+    nb = 0
+    for p in pics:
+        if p.desc.slice_type != 1:
+            continue
+        nb += 1
+        rec = p.mb_records()
+        inter = rec["mb_type"] > 2                                  # (_native: MB_IPCM = 2)
+        r0 = p.ref_idx.reshape(-1, 4)[inter] >= 0
+        r1 = p.ref_idx_l1.reshape(-1, 4)[inter] >= 0
+        used0, used1 = r0 | ~r1, r1                                   # (no list at all reads list 0)
+        total += int(used0.sum() + used1.sum()) * 96 + int(used0.any(axis=1).sum() + used1.any(axis=1).sum()) * 68 + int(inter.sum()) * 384
+        n_inter += int(inter.sum())
+        bi += int((used0 & used1).sum())
+        quads += int(inter.sum()) * 4
+    return (total // max(nb, 1), n_inter // max(nb, 1), bi / max(quads, 1))
 
 
 def extras(lib):
@@ -144,8 +185,16 @@ def extras(lib):
         t0 = time.perf_counter()
         pics = Parser(quiet=True, lib=lib).parse_stream(data)
         parse_fps = len(pics) / (time.perf_counter() - t0)
-        fps, digest = run_batched(lib, pics, 1024, MB_W, MB_H, 3)
+        stages = {}
+        fps, digest = run_batched(lib, pics, 1024, MB_W, MB_H, 3, stages)
+        bytes_b, inter_b, bi_share = bipred_bytes(pics)
+        if "B" in stages and stages["B"]["inter"] > 0:
+            gbps = bytes_b * 1024 / (stages["B"]["inter"] * 1e-3) / 1e9
+            stages["B"]["mc_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_launch": bytes_b * 1024, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(gbps / HBM_PEAK_GBS, 4), "inter_mb_per_picture": inter_b, "quadrants_from_both_lists": round(bi_share, 3),
+                                          "kernels": "k_mc_sort_b + k_mc + k_mc_second"}
         out["config4_1080p_main_cabac_ipb"] = {"value": round(fps, 1), "unit": "frames/s", "streams": 1024, "pictures_per_stream": len(pics),
+                                                "stage_ms_per_launch": stages,
                                                 "b_pictures_per_stream": sum(1 for p in pics if p.desc.slice_type == 1),
                                                 "last_picture_matches_oracle": digest == synth_cases.oracle_golden(name)[1][-1],
                                                 "cabac_parse_fps_one_thread": round(parse_fps, 1),

@@ -20,7 +20,9 @@
  * pictures; the worker reconstructs them and answers with ONE fixed-size status block (0 or its error text) followed, when
  * the status is 0, by the planes.  A worker that fails keeps answering (with its error) until the root says "finished",
  * which it only does where a worker expects a control block: no failure on either side leaves the other one waiting
- * inside a round.  All sends and receives of a step are posted between group_begin / group_end (ncclGroupStart /
+ * inside a round.  A rank that cannot even stay in step (no memory to receive a message into, a control block out of range)
+ * aborts the transport before it returns, and the RCCL transport bounds every wait (P264AMD_FAN_TIMEOUT_S, default 120 s,
+ * then ncclCommAbort): a dead peer ends the job with an error, not with a hang.  All sends and receives of a step are posted between group_begin / group_end (ncclGroupStart /
  * ncclGroupEnd).  Rounds are double-buffered on the root: while round r is exchanged and reconstructed, round r+1 is
  * parsed (one host thread per stream) and packed.
  */
@@ -45,6 +47,10 @@ typedef struct p264fan_transport {
     int (*group_end)(void *ctx);
     void (*close)(void *ctx);
     const char *name;
+    /* optional: give up on the peers NOW - pending and later calls fail instead of waiting (RCCL: ncclCommAbort; TCP: the
+     * sockets are shut down, the peers see "peer closed").  A rank that cannot go on inside a round (out of memory for a
+     * message, a control block that makes no sense) calls it before it leaves, so that nobody waits for it. */
+    void (*abort)(void *ctx);
 } p264fan_transport_t;
 
 /* Reconstruction of one picture of one local stream; i420 receives the MB-aligned planes Y, U, V back to back. */

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 #include <vector>
 #include "p264fan.h"
 
@@ -21,7 +23,8 @@ typedef int (*fn_sr)(void *, size_t, int, int, Comm, hipStream_t);
 typedef int (*fn_v)();
 typedef int (*fn_destroy)(Comm);
 typedef const char *(*fn_err)(int);
-struct Api { void *lib = nullptr; fn_uid uid; fn_init init; fn_sr send, recv; fn_v gstart, gend; fn_destroy destroy, abort; fn_err err; };
+typedef int (*fn_async)(Comm, int *);
+struct Api { void *lib = nullptr; fn_uid uid; fn_init init; fn_sr send, recv; fn_v gstart, gend; fn_destroy destroy, abort; fn_err err; fn_async async_err; };
 Api g_api;
 const char *nccl_str(int e) { return g_api.err ? g_api.err(e) : "RCCL error"; }
 #define RFAIL(what, e) p264fan_set_error("rccl transport: %s: %s (%d)", what, nccl_str(e), e)
@@ -41,6 +44,7 @@ bool load_api()
     g_api.gstart = (fn_v)dlsym(l, "ncclGroupStart"); g_api.gend = (fn_v)dlsym(l, "ncclGroupEnd");
     g_api.destroy = (fn_destroy)dlsym(l, "ncclCommDestroy"); g_api.abort = (fn_destroy)dlsym(l, "ncclCommAbort");
     g_api.err = (fn_err)dlsym(l, "ncclGetErrorString");
+    g_api.async_err = (fn_async)dlsym(l, "ncclCommGetAsyncError");
     if (!g_api.uid || !g_api.init || !g_api.send || !g_api.recv || !g_api.gstart || !g_api.gend || !g_api.destroy) { dlclose(l); p264fan_set_error("rccl transport: librccl.so lacks a symbol"); return false; }
     g_api.lib = l;
     return true;
@@ -51,7 +55,17 @@ struct Rccl {
     std::vector<void *> stage; std::vector<size_t> cap; size_t used = 0;      // staging buffers of the current group
     std::vector<Pending> pending;
     bool in_group = false, broken = false;
+    double timeout_s = 120.0;                                 // P264AMD_FAN_TIMEOUT_S: longest wait for a group before the communicator is aborted
 };
+double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+void rc_abort(void *c)
+{
+    Rccl *r = (Rccl *)c;
+    if (!r || !r->comm) return;
+    (void)hipSetDevice(r->device);
+    if (g_api.abort) g_api.abort(r->comm);                     // pending operations of every rank of the communicator fail instead of waiting
+    r->comm = nullptr; r->broken = true;
+}
 void *stage_buf(Rccl *r, size_t bytes)
 {
     if (r->used == r->stage.size()) { r->stage.push_back(nullptr); r->cap.push_back(0); }
@@ -70,7 +84,28 @@ int finish(Rccl *r)
 {
     hipError_t e = hipSuccess;
     for (auto &p : r->pending) if (e == hipSuccess) e = hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, r->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    // a bounded wait: RCCL has no "peer closed" - a rank that died (or aborted) would leave this one in the stream forever.
+    // Poll the stream; an asynchronous error of the communicator or the deadline aborts it.
+    const double t0 = now_s();
+    unsigned spins = 0;
+    while (e == hipSuccess) {
+        const hipError_t q = hipStreamQuery(r->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { e = q; break; }
+        int ae = 0;
+        if (g_api.async_err && r->comm && g_api.async_err(r->comm, &ae) == 0 && ae != 0) {
+            r->pending.clear(); r->used = 0;
+            const int rc = RFAIL("asynchronous error of the communicator", ae);
+            rc_abort(r);
+            return rc;
+        }
+        if (now_s() - t0 > r->timeout_s) {
+            r->pending.clear(); r->used = 0;
+            rc_abort(r);
+            return p264fan_set_error("rccl transport: a group did not complete within %.0f s (a peer has gone?): communicator aborted", r->timeout_s);
+        }
+        if (++spins > 2000) usleep(200);                       // (the first polls spin: a round's transfers take well under a millisecond)
+    }
     r->pending.clear(); r->used = 0;
     if (e != hipSuccess) { r->broken = true; return HFAIL("completing a group", e); }
     return 0;
@@ -78,6 +113,7 @@ int finish(Rccl *r)
 int rc_send(void *c, int peer, const void *buf, size_t n)
 {
     Rccl *r = (Rccl *)c;
+    if (!r->comm) return p264fan_set_error("rccl transport: the communicator has been aborted");
     (void)hipSetDevice(r->device);
     void *d = stage_buf(r, n);
     if (!d) return -1;
@@ -89,6 +125,7 @@ int rc_send(void *c, int peer, const void *buf, size_t n)
 int rc_recv(void *c, int peer, void *buf, size_t n)
 {
     Rccl *r = (Rccl *)c;
+    if (!r->comm) return p264fan_set_error("rccl transport: the communicator has been aborted");
     (void)hipSetDevice(r->device);
     void *d = stage_buf(r, n);
     if (!d) return -1;
@@ -139,6 +176,7 @@ extern "C" int p264fan_rccl_transport(p264fan_transport_t *t, int rank, int worl
         rc_close(r);
         return -1;
     }
-    t->ctx = r; t->send = rc_send; t->recv = rc_recv; t->group_begin = rc_begin; t->group_end = rc_end; t->close = rc_close; t->name = "rccl";
+    t->ctx = r; t->send = rc_send; t->recv = rc_recv; t->group_begin = rc_begin; t->group_end = rc_end; t->close = rc_close; t->name = "rccl"; t->abort = rc_abort;
+    if (const char *env = getenv("P264AMD_FAN_TIMEOUT_S")) { const double v = atof(env); if (v > 0) r->timeout_s = v; }
     return 0;
 }

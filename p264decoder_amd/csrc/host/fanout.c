@@ -107,30 +107,59 @@ static int unpack_picture(const uint8_t *src, size_t bytes, p264hip_picture_t *o
 }
 
 /* ---------------------------------------------------------------- default backend ------- */
-/* The MI355X path of this library.  reconstruct() only ENQUEUES (upload, kernels, layout conversion, download into the
- * caller's buffer); sync() waits for everything enqueued - a round's pictures overlap on the device and there is one wait
- * per round.  The picture's arrays and the output buffer must stay untouched until sync() (the fan-out keeps a round's
- * messages and frames alive until then; frames live in pinned memory so that the downloads are real DMA transfers). */
-typedef struct { p264hip_ctx *hip; int mb_w, mb_h; } hipbk_t;
+/* The MI355X path of this library.  reconstruct() only uploads (asynchronously) and NOTES the picture; sync() reconstructs
+ * everything noted since the last sync() as ONE batch - the pictures of a round belong to different local streams, and the
+ * kernels are built for batches: a round of 64 pictures as 64 single-picture batches would run the GPU nearly empty, one
+ * launch latency after the other - then converts and downloads the frames and waits once.  The picture's arrays and the
+ * output buffers must stay untouched until sync() (the fan-out keeps a round's messages and frames alive until then; frames
+ * live in pinned memory so that the downloads are real DMA transfers). */
+typedef struct { p264hip_ctx *hip; int mb_w, mb_h, n_local, n_pend; int *stream, *slot; uint8_t **out; } hipbk_t;
+static void hipbk_close(void *ctx);
 static int hipbk_open(void **ctx, int device, int mb_w, int mb_h, int n_local, int slots)
 {
     hipbk_t *b = (hipbk_t *)calloc(1, sizeof *b);
     if (!b) return fail("out of memory");
-    if (p264hip_create(&b->hip, device, mb_w, mb_h, n_local, slots, n_local) != P264HIP_OK) { fail("%s", p264hip_last_error()); free(b); return -1; }
-    b->mb_w = mb_w; b->mb_h = mb_h;
+    b->stream = (int *)malloc(sizeof(int) * (size_t)n_local); b->slot = (int *)malloc(sizeof(int) * (size_t)n_local);
+    b->out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)n_local);
+    if (!b->stream || !b->slot || !b->out) { hipbk_close(b); return fail("out of memory"); }
+    if (p264hip_create(&b->hip, device, mb_w, mb_h, n_local, slots, n_local) != P264HIP_OK) { fail("%s", p264hip_last_error()); b->hip = NULL; hipbk_close(b); return -1; }
+    b->mb_w = mb_w; b->mb_h = mb_h; b->n_local = n_local;
     *ctx = b;
     return 0;
+}
+static int hipbk_sync(void *ctx)
+{
+    hipbk_t *b = (hipbk_t *)ctx;
+    const int w = b->mb_w * 16, h = b->mb_h * 16, n = b->n_pend;
+    b->n_pend = 0;
+    if (n) {
+        /* input slot = local stream (hipbk_reconstruct); one batch, then the frames */
+        if (p264hip_reconstruct(b->hip, b->stream, b->stream, n) != P264HIP_OK) return fail("%s", p264hip_last_error());
+        for (int i = 0; i < n; i++) {
+            uint8_t *o = b->out[i];
+            if (p264hip_read_frame_async(b->hip, b->stream[i], b->slot[i], o, w, o + (size_t)w * h, o + (size_t)w * h * 5 / 4, w / 2) != P264HIP_OK) return fail("%s", p264hip_last_error());
+        }
+    }
+    return p264hip_sync(b->hip) == P264HIP_OK ? 0 : fail("%s", p264hip_last_error());
 }
 static int hipbk_reconstruct(void *ctx, int s, const p264hip_picture_t *pic, uint8_t *i420)
 {
     hipbk_t *b = (hipbk_t *)ctx;
-    const int w = b->mb_w * 16, h = b->mb_h * 16;
-    if (p264hip_submit_async(b->hip, s, pic) != P264HIP_OK) return fail("%s", p264hip_last_error());
-    if (p264hip_read_frame_async(b->hip, s, pic->dst_slot, i420, w, i420 + (size_t)w * h, i420 + (size_t)w * h * 5 / 4, w / 2) != P264HIP_OK) return fail("%s", p264hip_last_error());
+    if (s < 0 || s >= b->n_local) return fail("local stream %d out of range", s);
+    for (int i = 0; i < b->n_pend; i++)
+        if (b->stream[i] == s) { if (hipbk_sync(b)) return -1; break; }     /* (a second picture of a stream: the first one has to be through) */
+    if (p264hip_upload_async(b->hip, s, pic) != P264HIP_OK) return fail("%s", p264hip_last_error());
+    b->stream[b->n_pend] = s; b->slot[b->n_pend] = pic->dst_slot; b->out[b->n_pend] = i420;
+    b->n_pend++;
     return 0;
 }
-static int hipbk_sync(void *ctx) { hipbk_t *b = (hipbk_t *)ctx; return p264hip_sync(b->hip) == P264HIP_OK ? 0 : fail("%s", p264hip_last_error()); }
-static void hipbk_close(void *ctx) { hipbk_t *b = (hipbk_t *)ctx; if (b) { if (b->hip) p264hip_destroy(b->hip); free(b); } }
+static void hipbk_close(void *ctx)
+{
+    hipbk_t *b = (hipbk_t *)ctx;
+    if (!b) return;
+    if (b->hip) p264hip_destroy(b->hip);
+    free(b->stream); free(b->slot); free(b->out); free(b);
+}
 static const p264fan_backend_t g_hip_backend = { NULL, hipbk_open, hipbk_reconstruct, hipbk_close, hipbk_sync };
 /* frames: pinned when a HIP device is there (downloads and RCCL staging copies become DMA), plain memory otherwise */
 static uint8_t *frames_alloc(size_t bytes, int *pinned)
@@ -157,6 +186,12 @@ static int io_all(int fd, void *buf, size_t n, int wr)
 static int tcp_send(void *c, int peer, const void *buf, size_t n) { tcp_t *t = (tcp_t *)c; return io_all(t->fd[peer], (void *)buf, n, 1); }
 static int tcp_recv(void *c, int peer, void *buf, size_t n) { tcp_t *t = (tcp_t *)c; return io_all(t->fd[peer], buf, n, 0); }
 static int tcp_nop(void *c) { (void)c; return 0; }
+static void tcp_abort(void *c)
+{
+    tcp_t *t = (tcp_t *)c;
+    if (!t) return;
+    for (int i = 0; i < t->world; i++) if (t->fd[i] >= 0) shutdown(t->fd[i], SHUT_RDWR);
+}
 static void tcp_close(void *c)
 {
     tcp_t *t = (tcp_t *)c;
@@ -205,7 +240,7 @@ int p264fan_tcp_transport(p264fan_transport_t *out, int rank, int world, const c
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
         t->fd[0] = fd;
     }
-    out->ctx = t; out->send = tcp_send; out->recv = tcp_recv; out->group_begin = tcp_nop; out->group_end = tcp_nop; out->close = tcp_close; out->name = "tcp";
+    out->ctx = t; out->send = tcp_send; out->recv = tcp_recv; out->group_begin = tcp_nop; out->group_end = tcp_nop; out->close = tcp_close; out->name = "tcp"; out->abort = tcp_abort;
     return 0;
 }
 
@@ -242,20 +277,20 @@ int p264fan_worker_run(p264fan *f)
     if (!f || f->rank == 0) return fail("p264fan_worker_run: not a worker");
     uint8_t *msg[FAN_MAX_PER_ROUND] = { 0 }; size_t cap[FAN_MAX_PER_ROUND] = { 0 };
     uint8_t *out = NULL; size_t frame = 0; int out_pinned = 0;
-    int rc = 0;                                             /* transport failures only: they end the loop */
+    int rc = 0, fatal = 0;                                  /* rc: transport failures only, they end the loop; fatal: this rank cannot stay in step */
     char first_err[248] = "";
     for (;;) {
         fan_ctrl_t c;
         if (gb(f) || f->t.recv(f->t.ctx, 0, &c, sizeof c) || ge(f)) { rc = -1; break; }
         if (c.n == FAN_FINISHED) break;
-        if (c.n < 0 || c.n > FAN_MAX_PER_ROUND) { rc = fail("worker %d: bad control block", f->rank); break; }   /* (out of step: nothing sane left to do) */
+        if (c.n < 0 || c.n > FAN_MAX_PER_ROUND) { rc = fail("worker %d: bad control block", f->rank); fatal = 1; break; }   /* (out of step: nothing sane left to do) */
         fan_status_t st; memset(&st, 0, sizeof st); st.n = c.n;
         /* ---- the round's pictures: always received, whatever state this worker is in */
         for (int k = 0; k < c.n; k++)
             if (c.bytes[k] > cap[k]) {
                 free(msg[k]); cap[k] = 0;
                 msg[k] = (uint8_t *)malloc((size_t)c.bytes[k] + c.bytes[k] / 4);
-                if (!msg[k]) { rc = fail("worker %d: out of memory", f->rank); break; }       /* (cannot even receive: the transport is closed below) */
+                if (!msg[k]) { rc = fail("worker %d: out of memory", f->rank); fatal = 1; break; }       /* (cannot even receive: the transport is aborted below) */
                 cap[k] = (size_t)c.bytes[k] + c.bytes[k] / 4;
             }
         if (rc) break;
@@ -285,6 +320,8 @@ int p264fan_worker_run(p264fan *f)
         for (int k = 0; k < c.n && !rc; k++) if (f->t.send(f->t.ctx, 0, out + frame * (size_t)k, frame)) rc = -1;
         if (ge(f) || rc) { rc = -1; break; }
     }
+    /* leaving out of step: the root must not wait for this rank's status or frames (RCCL has no "peer closed") */
+    if (fatal && f->t.abort) { char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep); f->t.abort(f->t.ctx); memcpy(g_err, keep, sizeof keep); }
     for (int k = 0; k < FAN_MAX_PER_ROUND; k++) free(msg[k]);
     if (out) frames_free(out, out_pinned);
     if (!rc && first_err[0]) rc = fail("%s", first_err);    /* the job failed on this worker, even though it left in step */

@@ -9,7 +9,7 @@ from . import _native as N
 
 class Transport(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("send", C.c_void_p), ("recv", C.c_void_p), ("group_begin", C.c_void_p),
-                ("group_end", C.c_void_p), ("close", C.c_void_p), ("name", C.c_char_p)]
+                ("group_end", C.c_void_p), ("close", C.c_void_p), ("name", C.c_char_p), ("abort", C.c_void_p)]
 
 
 BK_OPEN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)

@@ -97,3 +97,43 @@ def test_fanout_symbols_and_errors(lib):
         assert hasattr(lib, sym)
     with pytest.raises(RuntimeError):
         FanOut(1, 2, ("tcp", "not-an-address", 1), lib=lib)
+
+
+def test_worker_out_of_step_aborts_the_transport(lib):
+    """A worker that cannot stay in step with the root (here: a control block that announces more pictures than a round can
+    hold) gives up ON the transport, not just on its loop: the root's side of the connection is shut down at once, so a root
+    in the middle of a round gets an error instead of waiting for that worker's status (over RCCL, where a peer cannot
+    "close", the same call is ncclCommAbort)."""
+    import socket
+    import struct
+    import threading
+    from p264decoder_amd.fanout import FanOut
+    port = 30700 + (os.getpid() % 300)
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", port))
+    srv.listen(1)
+    result = {}
+
+    def worker():
+        try:
+            fan = FanOut(1, 2, ("tcp", "127.0.0.1", port), device=0, backend=None, lib=lib)
+            try:
+                fan.worker()
+                result["rc"] = "ok"
+            except Exception as e:                              # noqa: BLE001
+                result["rc"] = repr(e)
+            fan.close()
+        except Exception as e:                                  # noqa: BLE001
+            result["rc"] = "open: %r" % (e,)
+    th = threading.Thread(target=worker)
+    th.start()
+    conn, _ = srv.accept()
+    conn.settimeout(20)
+    assert struct.unpack("<i", conn.recv(4))[0] == 1            # the worker introduces itself with its rank
+    conn.sendall(struct.pack("<5i64I", 1000, 22, 18, 2, 1, *([0] * 64)))     # fan_ctrl_t with n = 1000 (> 64 per round)
+    assert conn.recv(16) == b"", "the worker must shut the connection down, not leave the root waiting"
+    th.join(20)
+    assert not th.is_alive() and "bad control block" in result.get("rc", ""), result
+    conn.close()
+    srv.close()

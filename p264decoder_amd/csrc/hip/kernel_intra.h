@@ -408,7 +408,7 @@ struct IntraShared {
     unsigned long long m_intra[INTRA_MASKS], m_walk[INTRA_MASKS];   // per row window: intra macroblocks / those left to the band walk
     int free_n[2];
 };
-__device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__restrict__ pics, const Geom &g, int *status)
+__device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__restrict__ pics, const Geom &g, int *status, const uint8_t *__restrict__ is_intra_all)
 {
     IntraSync &sync = sh.sync;
     int16_t *lut = sh.lut;
@@ -431,6 +431,7 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
     for (int i = threadIdx.x; i <= n_bands; i += blockDim.x) sync.progress[i] = 0;
     const int wins = (g.mb_w + 63) / 64, n_win = g.mb_h * wins;
     const bool use_free = pd->slice_type != P264_SLICE_I && n_win <= INTRA_MASKS && g.n_mb < 65536;     // (scalar)
+    const uint8_t *is_intra = is_intra_all + (size_t)blockIdx.x * g.n_mb;                                 // written by k_mc_sort[_b] for P / B pictures
     if (threadIdx.x < 2) free_n[threadIdx.x] = 0;
     __syncthreads();
     IntraGrp &L = lds[wave].g[grp];
@@ -442,7 +443,9 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int w = w0 + j, row = w / wins, x = (w - row * wins) * 64 + lane;
-                in[j] = w < n_win && x < g.mb_w && P264_MB_IS_INTRA(glob(pd->mb)[row * g.mb_w + x].mb_type);
+                // (one byte per macroblock from the work-list sort, which has seen every record anyway: 64 contiguous bytes per
+                // wavefront here - out of the 16-byte records it was one byte per cache line sector, 130 KB per picture and role)
+                in[j] = w < n_win && x < g.mb_w && glob(is_intra)[row * g.mb_w + x] != 0;
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) { const unsigned long long m = __ballot(in[j]); if (w0 + j < n_win && lane == 0) m_intra[w0 + j] = m; }
@@ -641,17 +644,17 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
 // round trips per workgroup: 64 registers, so that all of the batch's workgroups are resident at once (0.42 -> 0.36 ms per
 // 1024-picture launch).
 __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
-void k_intra(const PicDev *__restrict__ pics, Geom g, int *status)
+void k_intra(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra)
 {
     __shared__ IntraShared sh;
-    intra_picture(sh, pics, g, status);
+    intra_picture(sh, pics, g, status, is_intra);
 }
 #ifndef INTRA_SPARSE_WAVES_PER_EU
 #define INTRA_SPARSE_WAVES_PER_EU 8
 #endif
 __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_SPARSE_WAVES_PER_EU)
-void k_intra_sparse(const PicDev *__restrict__ pics, Geom g, int *status)
+void k_intra_sparse(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra)
 {
     __shared__ IntraShared sh;
-    intra_picture(sh, pics, g, status);
+    intra_picture(sh, pics, g, status, is_intra);
 }

@@ -340,8 +340,10 @@ __device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, in
 // twice - keeping two classifications of eight macroblocks does not fit the register file).
 template <bool BPIC>
 __device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml, uint32_t inv_mbw,
-                                                uint32_t *cnt, uint32_t *pos)
+                                                uint32_t *cnt, uint32_t *pos, uint8_t *__restrict__ is_intra_all)
 {
+    // by-product for the intra stage (k_intra's collect pass): one byte per macroblock, 1 = intra
+    AS1 uint8_t *is_intra = glob(is_intra_all + (size_t)blockIdx.x * g.n_mb);
     constexpr int NP = BPIC ? 2 : 1;
     const PicDev *pd = pics + blockIdx.x;
     uint32_t *out = mc_all + (size_t)blockIdx.x * ml.words;
@@ -365,11 +367,15 @@ __device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics,
         for (int j = 0; j < (BPIC ? 1 : MC_SORT_KEEP); j++) {
             const int mbi = tid + j * MC_SORT_THREADS;
             kept[j].info = 0;
-            if (mbi < g.n_mb) { kept[j] = mc_classify<BPIC>(pd, g, mc_load<BPIC>(pd, mbi), mbi, inv_mbw, (int)ml.band_log2, 0); mc_count(ctx[0], kept[j]); }
+            if (mbi < g.n_mb) {
+                kept[j] = mc_classify<BPIC>(pd, g, mc_load<BPIC>(pd, mbi), mbi, inv_mbw, (int)ml.band_log2, 0); mc_count(ctx[0], kept[j]);
+                is_intra[mbi] = (uint8_t)!(kept[j].info & MCMB_INTER);
+            }
         }
     } else {
         for (int mbi = tid; mbi < g.n_mb; mbi += MC_SORT_THREADS) {
             const McIn in = mc_load<BPIC>(pd, mbi);
+            is_intra[mbi] = (uint8_t)(P264_MB_IS_INTRA(in.rec.x & 255) != 0);
 #pragma unroll
             for (int ps = 0; ps < NP; ps++) if (ps < n_pass) mc_count(ctx[ps], mc_classify<BPIC>(pd, g, in, mbi, inv_mbw, (int)ml.band_log2, ps));
         }
@@ -425,17 +431,17 @@ __device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics,
 }
 // batches without B pictures (the two-list classification costs registers the sort of a P picture does not have to pay for)
 __global__ __launch_bounds__(MC_SORT_THREADS)
-void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
+void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, uint8_t *__restrict__ is_intra)
 {
     __shared__ uint32_t cnt[MC_KEY_SLOTS], pos[MC_KEY_SLOTS];
-    mc_sort_picture<false>(pics, mc_all, g, ml, inv_mbw, cnt, pos);
+    mc_sort_picture<false>(pics, mc_all, g, ml, inv_mbw, cnt, pos, is_intra);
 }
 // batches with B pictures
 __global__ __launch_bounds__(MC_SORT_THREADS)
-void k_mc_sort_b(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw)
+void k_mc_sort_b(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, uint8_t *__restrict__ is_intra)
 {
     __shared__ uint32_t cnt[2 * MC_KEY_SLOTS], pos[2 * MC_KEY_SLOTS];
-    mc_sort_picture<true>(pics, mc_all, g, ml, inv_mbw, cnt, pos);
+    mc_sort_picture<true>(pics, mc_all, g, ml, inv_mbw, cnt, pos, is_intra);
 }
 
 // ------------------------------------------------------------------------------------------

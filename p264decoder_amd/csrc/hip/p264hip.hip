@@ -79,6 +79,7 @@ struct p264hip_ctx {
     int *d_status = nullptr;
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
     uint32_t *d_mc = nullptr;              // [batch_cap][ml.words], motion-compensation work lists (k_mc_sort -> k_mc, k_mc_second)
+    uint8_t *d_is_intra = nullptr;         // [batch_cap][n_mb], 1 = intra macroblock (k_mc_sort -> k_intra's collect pass; P / B pictures)
     McLayout ml;
     std::vector<int> stream_seen;          // p264hip_reconstruct: batch index + 1 that last named a stream in the current call
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
@@ -163,6 +164,7 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     if (c->frames) (void)hipFree(c->frames);
     if (c->d_edge) (void)hipFree(c->d_edge);
     if (c->d_mc) (void)hipFree(c->d_mc);
+    if (c->d_is_intra) (void)hipFree(c->d_is_intra);
     if (c->d_planar) (void)hipFree(c->d_planar);
     for (auto &m : c->markers) if (m) (void)hipEventDestroy(m);
     if (c->d_status) (void)hipFree(c->d_status);
@@ -332,7 +334,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         }
         if (c->d_edge) (void)hipFree(c->d_edge);
         if (c->d_mc) (void)hipFree(c->d_mc);
-        c->d_edge = nullptr; c->d_mc = nullptr;
+        if (c->d_is_intra) (void)hipFree(c->d_is_intra);
+        c->d_edge = nullptr; c->d_mc = nullptr; c->d_is_intra = nullptr;
+        HIPCHK(hipMalloc((void **)&c->d_is_intra, (size_t)n * c->g.n_mb));
         HIPCHK(hipMalloc((void **)&c->d_edge, (size_t)n * c->g.n_mb * sizeof(EdgeInfo)));
         HIPCHK(hipMalloc((void **)&c->d_mc, (size_t)n * c->ml.words * sizeof(uint32_t)));
         c->batch_cap = n;
@@ -391,8 +395,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // interpolation has to do, then the luma and chroma kernels over the sorted lists (kernel_mc.h), side by side
         ScopedStamp t(c, 0);
         const McLayout ml = c->ml;
-        if (any_b) hipLaunchKernelGGL(k_mc_sort_b, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
-        else hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw);
+        if (any_b) hipLaunchKernelGGL(k_mc_sort_b, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw, c->d_is_intra);
+        else hipLaunchKernelGGL(k_mc_sort, dim3(n), dim3(MC_SORT_THREADS), 0, c->stream, c->d_batch[r], c->d_mc, g, ml, inv_mbw, c->d_is_intra);
         // one launch for luma / chroma, macroblock / quadrant items (k_mc): every picture gets the same number of workgroups,
         // which split into the four roles on the device.  Enough workgroups per picture to fill the chip a few times over,
         // no more than there can be chunks (four wavefronts per workgroup, one chunk per wavefront pass).
@@ -418,8 +422,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         if (c->tune_intra_waves >= 1 && c->tune_intra_waves <= INTRA_ROW_WAVES) intra_waves = c->tune_intra_waves;
         // luma and chroma of a picture are independent chains: as two workgroups they run side by side (the kernel is bound by
         // the latency of the macroblock-to-macroblock chain, not by arithmetic)
-        if (any_i) hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status);
-        else hipLaunchKernelGGL(k_intra_sparse, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status);
+        if (any_i) hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status, (const uint8_t *)c->d_is_intra);
+        else hipLaunchKernelGGL(k_intra_sparse, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status, (const uint8_t *)c->d_is_intra);
     }
     {
         ScopedStamp t(c, 2);

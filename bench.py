@@ -358,7 +358,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=1024, help="independent 1080p streams per GPU")
+    # 2048 streams = 8 pictures per CU and launch (round 4: 1024 -> 2048 streams +5 % frames/s, 3072 / 4096 no more; the wavefront
+    # kernels balance their bands better with more pictures per workgroup).  26 pictures x 2048 streams of parsed input = 80 GB.
+    ap.add_argument("--streams", type=int, default=2048, help="independent 1080p streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
     ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0)")

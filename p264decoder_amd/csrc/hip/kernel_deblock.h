@@ -374,7 +374,7 @@ struct OctLds {                    // per octet: 212 dwords
     uint32_t ring[RING_SLOTS][RING_DW];
     uint32_t edge[EDGE_DW];
 };
-#define MAX_PICS_PER_WG 4
+#define MAX_PICS_PER_WG 16             // pictures one workgroup serves (in groups of as many as a wavefront holds)
 #define MAX_BANDS (MAX_MB_ROWS / 2)
 
 __global__ __launch_bounds__(ROW_WAVES * 64)

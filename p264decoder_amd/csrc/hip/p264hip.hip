@@ -430,18 +430,18 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // edge info (boundary strengths, averaged QPs per edge class): everything about an edge that does not depend on samples
         if (any_b) hipLaunchKernelGGL(k_deblock_bs<true>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, inv_mbw);
         else       hipLaunchKernelGGL(k_deblock_bs<false>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, inv_mbw);
-        // pictures per workgroup = as many as it takes to cover the batch with one workgroup per CU (at most 4: a second,
-        // half-empty round of workgroups costs more than sharing a workgroup)
+        // pictures per workgroup = as many as it takes to cover the batch with one workgroup per CU (a second, half-empty round
+        // of workgroups costs more than sharing a workgroup: 1280 pictures as 320 workgroups of 4 took 5.35 ms, as 256 of 5 ...)
         int per_wg = (n + c->n_cu - 1) / c->n_cu;
         if (per_wg < 1) per_wg = 1;
-        if (per_wg > 4) per_wg = 4;
+        if (per_wg > MAX_PICS_PER_WG) per_wg = MAX_PICS_PER_WG;
         // bands of 8 rows of one picture per wavefront while every picture has a CU to itself, else 4 rows of two pictures; a
         // workgroup with more pictures than a wavefront holds (8 >> rb_log2) works on them in groups (units = band x group).
         // (Round 4: 2 rows x 4 pictures ran as fast, 2.70 ms, but every second row's bottom lines cross a band - 0.4 GB more
         // through memory per launch.)
         int rb_log2 = per_wg == 1 ? 3 : 2;
         if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) rb_log2 = c->tune_rb_log2;
-        if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= 4) per_wg = c->tune_pics_per_wg;
+        if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= MAX_PICS_PER_WG) per_wg = c->tune_pics_per_wg;
         const int n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
         const int n_units = n_bands * ((per_wg + (8 >> rb_log2) - 1) / (8 >> rb_log2));
         int waves = n_units < ROW_WAVES ? n_units : ROW_WAVES;

@@ -38,7 +38,7 @@ for k, ctrs in agg.items():
         pmc[k][c] = round(sum(vals) / len(vals))
     pmc[k]["launches_averaged"] = len(vals)
 note = ("per-launch averages over the P-picture launches of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` "
-        "(1024 1080p pictures per launch), separate rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as reported")
+        "(bench.py's default batch of 1080p pictures per launch: see traffic_latest.json), separate rocprofv3 --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as reported")
 for k in ("k_mc", "k_mc_sort"):
     if k in pmc:
         pmc[k]["hbm_bytes_2xFETCH_plus_WRITE"] = int((2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024)
@@ -51,7 +51,7 @@ def hbm_any(prefix):
 # (the bench's P launches run k_intra_sparse; k_intra itself only sees the all-intra IDR launch of the warm-up)
 traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra_sparse" if "k_intra_sparse" in pmc else "k_intra"), "deblock": hbm_any("k_deblock"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
-traffic["pictures_per_launch"] = 1024          # bench.py's default batch, which collect.sh profiles
+traffic["pictures_per_launch"] = int(json.load(open(os.path.join(here, tag + "_bench.json")))["config"]["pictures_per_step"])   # bench.py's default batch, which collect.sh profiles
 json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(traffic))
 print(open(os.path.join(here, tag + "_kernel_stats.csv")).read())

@@ -1,6 +1,6 @@
 """The two row-wavefront kernels pick their workgroup shape from the batch size (pictures vs compute units):
-k_deblock walks bands of 8 / 4 / 2 macroblock rows with 1 / 2 / 4 pictures per workgroup, k_intra uses 16 or 8
-wavefronts per picture.  A test batch is far smaller than an MI355X, so every shape is forced through the
+k_deblock walks bands of 8 / 4 / 2 macroblock rows of 1 / 2 / 4 pictures per wavefront, a workgroup serving up to 16 pictures
+in groups of as many as a wavefront holds (work units = band x group); k_intra uses 16 or 8 wavefronts per picture.  A test batch is far smaller than an MI355X, so every shape is forced through the
 P264AMD_* knobs (read once, when the context is created) and checked against the CPU oracle, picture by picture, on every stream."""
 import os
 
@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [  # (P264AMD_DEBLOCK_RB_LOG2, P264AMD_DEBLOCK_PICS_PER_WG, P264AMD_INTRA_WAVES)
     ("3", "1", "16"), ("2", "2", "8"), ("2", "1", "4"), ("1", "4", "8"), ("1", "3", "1"), ("1", "1", "16"),
+    # more pictures per workgroup than a wavefront holds: groups (the last one partly empty with 7 streams)
+    ("2", "4", "8"), ("3", "4", "8"), ("2", "7", "4"), ("3", "16", "4"), ("1", "13", "2"),
 ]
 
 
@@ -40,14 +42,13 @@ def test_workgroup_shapes(lib, oracle, case, rb, per_wg, intra_waves, monkeypatc
     hip.close()
 
 
-@pytest.mark.parametrize("band_log2,wgs,concurrent", [("0", "4", "1"), ("2", "7", "1"), ("6", "200", "0"), ("1", "16", "0")])
-def test_mc_launch_knobs(lib, oracle, band_log2, wgs, concurrent, monkeypatch):
+@pytest.mark.parametrize("band_log2,wgs", [("0", "4"), ("2", "7"), ("6", "200"), ("1", "16")])
+def test_mc_launch_knobs(lib, oracle, band_log2, wgs, monkeypatch):
     """The other launch paths no default run takes: locality bands of the motion-compensation lists of 1 / 4 / 64 macroblock
     rows (more or fewer keys and chunks), few or many workgroups per picture in the fused launch (down to one workgroup per
-    role), and the side-stream fork / join of k_deblock_bs (P264AMD_CONCURRENT)."""
+    role)."""
     monkeypatch.setenv("P264AMD_MC_BAND_LOG2", band_log2)
     monkeypatch.setenv("P264AMD_MC_WGS_PER_PIC", wgs)
-    monkeypatch.setenv("P264AMD_CONCURRENT", concurrent)
     parser = Parser(quiet=True, lib=lib)
     pics = parser.parse_stream(synth_cases.stream_bytes("cif_ip"))[:10]
     mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
@@ -61,7 +62,7 @@ def test_mc_launch_knobs(lib, oracle, band_log2, wgs, concurrent, monkeypatch):
         for s in (0, S - 1):
             got = hip.read_frame(s, p.desc.dst_slot)
             for plane, (a, b) in enumerate(zip(got, want)):
-                assert np.array_equal(a, b), "band %s wgs %s concurrent %s: picture %d stream %d plane %d differs" % (band_log2, wgs, concurrent, i, s, plane)
+                assert np.array_equal(a, b), "band %s wgs %s: picture %d stream %d plane %d differs" % (band_log2, wgs, i, s, plane)
     hip.close()
 
 

@@ -73,10 +73,10 @@ static inline int p264cabac_bypass(p264cabac_t *c)
 {
     c->n -= 1;
     const uint64_t scaled = (uint64_t)c->range << c->n;
-    const int bin = c->low >= scaled;
-    if (bin) c->low -= scaled;
+    const uint64_t one = (uint64_t)0 - (uint64_t)(c->low >= scaled);               /* (a mask, not a branch: bypass bins are coin flips) */
+    c->low -= scaled & one;
     if (c->n < 8) p264cabac_refill(c);
-    return bin;
+    return (int)(one & 1u);
 }
 /* 9.3.3.2.2.x: end_of_slice_flag / the bin in front of I_PCM samples */
 static inline int p264cabac_terminate(p264cabac_t *c)

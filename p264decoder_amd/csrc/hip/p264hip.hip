@@ -401,7 +401,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // which split into the four roles on the device.  Enough workgroups per picture to fill the chip a few times over,
         // no more than there can be chunks (four wavefronts per workgroup, one chunk per wavefront pass).
         int wgs = (c->n_cu * 192 + n - 1) / n;
-        if (wgs < 16) wgs = 16;
+        if (wgs < 48) wgs = 48;            // (2048 pictures: 24 / 32 / 48 / 64 / 96 per picture -> 5.34 / 5.31 / 5.24 / 5.31 / 5.34 ms; with 24 the stage's reads grew by half:
+                                           //  a picture's roles drift apart and stop sharing reference lines in L2)
         int max_wgs = 0;
         for (int l = 0; l < ML_LISTS; l++) max_wgs += (int)(ml.max_chunks[l] + 3) / 4;
         if (wgs > max_wgs) wgs = max_wgs;

@@ -20,7 +20,7 @@ for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
   echo "[collect] pmc pass $i: $ctr" | tee -a $out/progress.log
-  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $out/pmc$i -- python3 $BENCH --no-cpu-baseline > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; grep -m2 "Missing\|error" $out/pmc$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex "^(void )?k_" --output-format csv -d $out/pmc$i -- python3 $BENCH --no-cpu-baseline > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; grep -m2 "Missing\|error" $out/pmc$i.log; exit 1; }
 done
 find $out -name "*agent_info.csv" -delete
 echo "[collect] done" | tee -a $out/progress.log

@@ -45,8 +45,10 @@ __device__ __forceinline__ int f2(int a, int b) { return (a + b + 1) >> 1; }
 // column bottom-up, corner, top and top-right row; the ends replicated).  Every directional mode is then one of
 //   copy S[c],  (S[c] + S[c+1] + 1) >> 1,  (S[c-1] + 2 S[c] + S[c+1] + 2) >> 2
 // with an index c that is linear in (x,y) per mode (checked against the per-mode formulas for all modes and positions).
-// The four macroblocks of a wavefront have four different modes: (c, kind) per (mode, sample) comes out of a 144-byte
-// table in LDS, filled from this function when the kernel starts.
+// The four macroblocks of a wavefront have four different modes: per (mode, sample) the places of S[c-1], S[c], S[c+1] come
+// out of a 576-byte table in LDS, filled from this function when the kernel starts.  All three kinds are ONE formula over
+// three places: (A + 2 B + D + 2) >> 2 is B for A = D = B and (B + D + 1) >> 1 for A = D - the table repeats a place
+// instead of naming a kind, and the sixteen steps have no branch on it.
 enum { P4_COPY = 0, P4_F2 = 1, P4_F3 = 2, P4_DC = 3 };
 __device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, int &kind)
 {
@@ -65,8 +67,17 @@ __device__ __forceinline__ void pred4x4_where(int mode, int x, int y, int &c, in
               c = z >= 5 ? 1 : 3 - y - (x >> 1); kind = z > 5 ? P4_COPY : (z == 5 || (z & 1)) ? P4_F3 : P4_F2; break; }
     }
 }
-#define INTRA_LUT_ENTRIES (9 * 16)         // int16: offset of S[c] from the block origin << 8 | kind << 4 | c
+#define INTRA_LUT_ENTRIES (9 * 16)         // uint32: place of A | place of B << 8 | place of D << 16 | DC << 24 (lut_entry)
+#define INTRA_LUT_BIAS (IT_STRIDE + 1)     // places are offsets from the block origin + this: 0 (the corner) .. 4 IT_STRIDE
 __device__ __forceinline__ int edge_offset(int k) { return k <= 4 ? (4 - max(k, 1)) * IT_STRIDE - 1 : -IT_STRIDE + min(k, 13) - 6; }
+__device__ __forceinline__ uint32_t lut_entry(int mode, int x, int y)
+{
+    int c, kind;
+    pred4x4_where(mode, x, y, c, kind);
+    const int pb = edge_offset(c) + INTRA_LUT_BIAS, pd = edge_offset(c + 1) + INTRA_LUT_BIAS;
+    const int pa = kind == P4_F3 ? edge_offset(c - 1) + INTRA_LUT_BIAS : kind == P4_F2 ? pd : pb;
+    return (uint32_t)pa | (uint32_t)pb << 8 | (uint32_t)(kind == P4_COPY ? pb : pd) << 16 | (uint32_t)(kind == P4_DC) << 24;
+}
 
 // sum over the sixteen lanes of a group / over aligned groups of 2^k lanes (xor butterflies stay inside the group)
 __device__ __forceinline__ int sum_lanes(int v, int n)
@@ -116,7 +127,7 @@ __device__ __forceinline__ uint32_t add_res4(uint32_t px, uint32_t r01, uint32_t
 // needs is issued at the top, before anything waits: one memory round trip per iteration, everything after that runs out
 // of registers and LDS.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, IntraGrp &L, const int16_t *lut, int mbx, int mby, const uint4 rec, int l)
+__device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, IntraGrp &L, const uint32_t *lut, int mbx, int mby, const uint4 rec, int l)
 {
     // Everything below that depends on the lane number alone (roles, tile offsets, edge slots) would otherwise be hoisted
     // out of the caller's loops and kept - or spilled - across them: recomputing it per macroblock is a few dozen
@@ -188,11 +199,18 @@ __device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, Int
             if (dcflag) dcv = L.dc[blk_y(l) * 4 + blk_x(l)];
         }
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
-        uint32_t c4[4][2], c16[4][2], col[4][2], r[4][2];
-        unscan_cols<false>(lv, c4);                        // Intra4x4: 16 levels
-        unscan_cols<true>(lv, c16);                        // Intra16x16: 15 AC levels at scan positions 1..15 (:787-794)
+        uint32_t col[4][2], r[4][2];
+        // Intra4x4: 16 levels; Intra16x16: 15 AC levels at scan positions 1..15 (:787-794).  The macroblocks of a wavefront are
+        // mostly of one type (the lists of P / B pictures are): both orders only where they are mixed
+        if (!__ballot(is16)) unscan_cols<false>(lv, col);
+        else if (!__ballot(!is16)) unscan_cols<true>(lv, col);
+        else {
+            uint32_t c4[4][2], c16[4][2];
+            unscan_cols<false>(lv, c4);
+            unscan_cols<true>(lv, c16);
 #pragma unroll
-        for (int x = 0; x < 4; x++) { col[x][0] = is16 ? c16[x][0] : c4[x][0]; col[x][1] = is16 ? c16[x][1] : c4[x][1]; }
+            for (int x = 0; x < 4; x++) { col[x][0] = is16 ? c16[x][0] : c4[x][0]; col[x][1] = is16 ? c16[x][1] : c4[x][1]; }
+        }
         dequant_cols(col, qp);
         if (is16) col[0][0] = (col[0][0] & 0xffff0000u) | ((uint32_t)dcv & 0xffffu);
         idct_res(col, r);
@@ -254,23 +272,22 @@ __device__ __forceinline__ void intra_luma4(const PicDev *pd, const Geom &g, Int
             // which of the 16 blocks (decode order) have their left / top neighbour (for the DC fall-backs): one bit per block
             const unsigned left_m = 0xFAFAu | (aL ? 0x0505u : 0u), top_m = 0xFFCCu | (aT ? 0x0033u : 0u);
             const int grp_base = (int)(threadIdx.x & 48);
-            const int16_t *lut16 = (const int16_t *)lut;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int bx = blk_x(i), by = blk_y(i);
                 const bool left = (left_m >> i) & 1, top = (top_m >> i) & 1;
                 const int mode = __shfl(modebyte, grp_base + i);
                 uint8_t *o = L.tile + (by * 4 + 1) * IT_STRIDE + 4 + bx * 4;           // block origin inside the tile
-                // where the lane's three edge samples sit: offset of S[c] from the origin, c and the filter kind out of the table;
-                // S[c-1] / S[c+1] one step back / on along the edge (down the left column, across the corner, along the top row)
-                const int wk = lut16[min(mode, 8) * 16 + l], ob = wk >> 8, c = wk & 15, kind = (wk >> 4) & 3;
-                const int oa = c == 1 ? ob : c <= 5 ? ob + IT_STRIDE : ob - 1, od = c >= 13 ? ob : c <= 4 ? ob - IT_STRIDE : ob + 1;
-                const int a = o[oa], b = o[ob], d = o[od];
-                int v = kind == P4_COPY ? b : kind == P4_F2 ? (b + d + 1) >> 1 : (a + 2 * b + d + 2) >> 2;
-                if (__ballot(kind == P4_DC)) {                                          // DC and its fall-backs, :677-695
+                // the lane's three edge samples: their places come out of the table (pred4x4_where / lut_entry)
+                const uint32_t wk = lut[min(mode, 8) * 16 + l];
+                const uint8_t *e = o - INTRA_LUT_BIAS;
+                const int a = e[wk & 255u], b = e[(wk >> 8) & 255u], d = e[(wk >> 16) & 255u];
+                int v = (a + 2 * b + d + 2) >> 2;
+                const bool is_dc = (wk >> 24) != 0;
+                if (__ballot(is_dc)) {                                                  // DC and its fall-backs, :677-695
                     const int sl = o[-1] + o[IT_STRIDE - 1] + o[2 * IT_STRIDE - 1] + o[3 * IT_STRIDE - 1], st = byte_sum(*(const uint32_t *)(o - IT_STRIDE));
                     const int dcv = (left && top) ? (sl + st + 4) >> 3 : left ? (sl + 2) >> 2 : top ? (st + 2) >> 2 : 128;
-                    v = kind == P4_DC ? dcv : v;
+                    v = is_dc ? dcv : v;
                 }
                 if ((mask >> i) & 1) v = clip255(v + (int)L.res[i * 16 + l]);
                 o[y * IT_STRIDE + x] = (uint8_t)v;
@@ -403,7 +420,7 @@ __device__ __forceinline__ void intra_chroma4(const PicDev *pd, const Geom &g, I
 struct IntraSync { int progress[MAX_MB_ROWS / INTRA_BAND + 1]; };            // per band: columns of its last row that are final
 struct IntraShared {
     IntraSync sync;
-    int16_t lut[INTRA_LUT_ENTRIES];
+    uint32_t lut[INTRA_LUT_ENTRIES];
     uint16_t free_list[2][INTRA_FREE_CAP];
     unsigned long long m_intra[INTRA_MASKS], m_walk[INTRA_MASKS];   // per row window: intra macroblocks / those left to the band walk
     int free_n[2];
@@ -411,7 +428,7 @@ struct IntraShared {
 __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__restrict__ pics, const Geom &g, int *status, const uint8_t *__restrict__ is_intra_all)
 {
     IntraSync &sync = sh.sync;
-    int16_t *lut = sh.lut;
+    uint32_t *lut = sh.lut;
     uint16_t (*free_list)[INTRA_FREE_CAP] = sh.free_list;
     unsigned long long *m_intra = sh.m_intra, *m_walk = sh.m_walk;
     int *free_n = sh.free_n;
@@ -423,11 +440,7 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
     const int n_waves = blockDim.x >> 6;                       // 16 per picture, or fewer when pictures share a CU (host's choice)
     const int n_bands = (g.mb_h + INTRA_BAND - 1) / INTRA_BAND;
-    for (int i = threadIdx.x; i < INTRA_LUT_ENTRIES; i += blockDim.x) {
-        int c, kind;
-        pred4x4_where(i >> 4, i & 3, (i >> 2) & 3, c, kind);
-        lut[i] = (int16_t)(edge_offset(c) * 256 + (kind << 4 | c));
-    }
+    for (int i = threadIdx.x; i < INTRA_LUT_ENTRIES; i += blockDim.x) lut[i] = lut_entry(i >> 4, i & 3, (i >> 2) & 3);
     for (int i = threadIdx.x; i <= n_bands; i += blockDim.x) sync.progress[i] = 0;
     const int wins = (g.mb_w + 63) / 64, n_win = g.mb_h * wins;
     const bool use_free = pd->slice_type != P264_SLICE_I && n_win <= INTRA_MASKS && g.n_mb < 65536;     // (scalar)

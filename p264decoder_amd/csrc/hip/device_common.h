@@ -99,6 +99,10 @@ __device__ __forceinline__ void wave_lds_fence()
 // v_perm_b32: result byte i = byte sel[i] of {hi (4..7), lo (0..3)}; 0x0c = zero
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long rfl64(unsigned long long v)
+{
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
+}
 
 // ---- tables (H.264 standard data; the reference holds them at the cited places) --------
 // zig-zag scan -> raster position, decoder/macroblock.c:602-603

@@ -437,7 +437,9 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
     IntraLds *lds = (IntraLds *)intra_dyn_lds;
     const PicDev *pd = pics + blockIdx.x;
     const bool chroma_role = blockIdx.y != 0;               // grid.y = 2: luma and chroma of a picture in separate workgroups
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
+    // (the wavefront's number through readfirstlane: everything the band walk derives from it - rows, windows, masks, the
+    // progress it waits for - is then scalar work for the compiler instead of vector instructions on uniform values)
+    const int wave = rfl((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
     const int n_waves = blockDim.x >> 6;                       // 16 per picture, or fewer when pictures share a CU (host's choice)
     const int n_bands = (g.mb_h + INTRA_BAND - 1) / INTRA_BAND;
     for (int i = threadIdx.x; i < INTRA_LUT_ENTRIES; i += blockDim.x) lut[i] = lut_entry(i >> 4, i & 3, (i >> 2) & 3);
@@ -553,6 +555,10 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
         for (int r = 0; r < INTRA_BAND; r++) { base[r] = -64; todo[r] = deps[r] = 0; fin[r] = R0 + r >= g.mb_h; }
         int spins = 0, published = -1;
         for (;;) {
+            // (uniform by construction; said here so that the compiler keeps the walk's state in scalar registers)
+#pragma unroll
+            for (int r = 0; r < INTRA_BAND; r++) { todo[r] = rfl64(todo[r]); deps[r] = rfl64(deps[r]); base[r] = rfl(base[r]); fin[r] = rfl((int)fin[r]) != 0; }
+            spins = rfl(spins); published = rfl(published); ok = rfl((int)ok) != 0;
             // ---- rows whose window is used up take the next one (all of them in one batch of loads) ----
             for (;;) {
                 bool need[INTRA_BAND], any_need = false;
@@ -569,13 +575,13 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
                     for (int r = 0; r < INTRA_BAND; r++) {
                         if (!need[r]) continue;
                         const int row = R0 + r, win = base[r] >> 6, w = row * wins + win;
-                        todo[r] = m_walk[w];
+                        todo[r] = rfl64(m_walk[w]);                    // (LDS reads land in vector registers: back to scalars)
                         unsigned long long d = 0;
                         if (row > 0) {
-                            const unsigned long long u = m_walk[w - wins];
+                            const unsigned long long u = rfl64(m_walk[w - wins]);
                             d = u | u << 1 | u >> 1;
-                            if (win > 0) d |= m_walk[w - wins - 1] >> 63;
-                            if (win + 1 < wins) d |= m_walk[w - wins + 1] << 63;
+                            if (win > 0) d |= rfl64(m_walk[w - wins - 1]) >> 63;
+                            if (win + 1 < wins) d |= rfl64(m_walk[w - wins + 1]) << 63;
                         }
                         deps[r] = d;
                     }

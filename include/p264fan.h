@@ -16,8 +16,10 @@
  * (p264hip_create / p264hip_submit / p264hip_read_frame on the rank's device).  A rank without a HIP device fails
  * loudly: there is no CPU reconstruction in the product (tests plug the CPU oracle in through the backend interface).
  *
- * Per round the root sends every worker ONE control block (how many pictures, their sizes, or "finished") and then the
- * pictures; the worker reconstructs them and answers with ONE fixed-size status block (0 or its error text) followed, when
+ * Per round the root sends every worker ONE control block (how many pictures, their sizes, or "finished"), then ONE message
+ * with the pictures' descriptors (host memory on both sides: the worker needs them to lay its input slots out) and then
+ * the pictures' arrays, each packed as ONE block in the layout of an input slot (p264hip_input_layout_t, include/p264hip.h);
+ * the worker reconstructs them and answers with ONE fixed-size status block (0 or its error text) followed, when
  * the status is 0, by the planes.  A worker that fails keeps answering (with its error) until the root says "finished",
  * which it only does where a worker expects a control block: no failure on either side leaves the other one waiting
  * inside a round.  A rank that cannot even stay in step (no memory to receive a message into, a control block out of range)
@@ -51,6 +53,13 @@ typedef struct p264fan_transport {
      * sockets are shut down, the peers see "peer closed").  A rank that cannot go on inside a round (out of memory for a
      * message, a control block that makes no sense) calls it before it leaves, so that nobody waits for it. */
     void (*abort)(void *ctx);
+    /* optional: the same for buffers in DEVICE memory of the rank's GPU, no staging (RCCL: ncclSend / ncclRecv straight from /
+     * into the buffer).  Where both the transport and the backend offer their device entry points a worker receives a
+     * picture's arrays straight into the input slot it is reconstructed from and sends the reconstructed planes straight
+     * out of the conversion buffer: nothing of a round's data touches the worker's host memory.  The buffers must be
+     * complete (send) / unused (recv) on the device when the call is made; they are done with when the group ends. */
+    int (*send_dev)(void *ctx, int peer, const void *dev, size_t bytes);
+    int (*recv_dev)(void *ctx, int peer, void *dev, size_t bytes);
 } p264fan_transport_t;
 
 /* Reconstruction of one picture of one local stream; i420 receives the MB-aligned planes Y, U, V back to back. */
@@ -63,6 +72,14 @@ typedef struct p264fan_backend {
      * picture handed over since the last sync() is in its i420 buffer.  The picture's arrays and the buffers stay valid
      * until then. */
     int (*sync)(void *ctx);
+    /* optional, all three or none - the device road of a worker (see p264fan_transport_t.send_dev):
+     * reserve: where the packed arrays (p264hip_input_layout_t) of local stream's next picture are to be written, in device
+     *          memory; reconstruct_reserved: they are there - note the picture like reconstruct() does (no i420 buffer: the
+     *          planes stay on the device); planes: after sync(), the device address of the planar I420 frame of the k-th
+     *          picture noted since the sync() before. */
+    int (*reserve)(void *ctx, int local_stream, const p264hip_picture_t *desc, void **dev, size_t *bytes);
+    int (*reconstruct_reserved)(void *ctx, int local_stream, const p264hip_picture_t *desc);
+    int (*planes)(void *ctx, int k, void **dev, size_t *bytes);
 } p264fan_backend_t;
 
 typedef struct {
@@ -74,13 +91,16 @@ typedef struct {
      * r is exchanged and reconstructed; parse_wait_seconds is the part of the parse the exchange side had to wait for (the
      * rest was hidden), reconstruct_seconds the root's own reconstruction */
     double  parse_wait_seconds, reconstruct_seconds;
-    int     parse_threads, reserved;
+    int     parse_threads;
+    int     device_road_rounds;          /* (worker, round) pairs served the device road: pictures into their input slots, planes out of the conversion buffers */
 } p264fan_stats_t;
 
 /* called on the root for every reconstructed picture, in decode order per stream */
 typedef void (*p264fan_frame_cb)(void *user, int stream, int64_t picture, int width, int height, const uint8_t *i420);
 
-/* transports */
+/* transports.  (P264AMD_FAN_TCP_DEVICE=1 makes the TCP transport offer send_dev / recv_dev too, through a host bounce buffer
+ * and p264hip_copy_*: the device road of the protocol can then be exercised by ranks that share one GPU, where RCCL cannot
+ * form a communicator.) */
 int  p264fan_tcp_transport(p264fan_transport_t *t, int rank, int world, const char *root_host, int port);
 int  p264fan_rccl_unique_id(uint8_t id[128]);                                      /* on one rank; hand the bytes to all */
 int  p264fan_rccl_transport(p264fan_transport_t *t, int rank, int world, const uint8_t id[128], int device);

@@ -143,6 +143,41 @@ int  p264hip_marker_wait(p264hip_ctx *ctx, int marker);
 /* Device-side copy of resident picture `src` into slot `dst` (private HBM copy; bench set-up). */
 int  p264hip_clone_picture(p264hip_ctx *ctx, int dst, int src);
 
+/* ---- the layout of a picture's arrays inside its input slot, and ways into the slot that do not pass through
+ * p264hip_upload's five copies.  An input slot is ONE block of device memory with the arrays at 256-byte aligned offsets
+ * (a pure function of mb_w, mb_h, n_coef_blocks and slice_type).  A host buffer packed in this layout goes into a slot
+ * with one copy (p264hip_upload_packed); a producer that can write device memory itself - the RCCL transport of the
+ * stream fan-out receiving a picture from another rank (include/p264fan.h) - asks for the slot's address
+ * (p264hip_input_reserve), fills it and commits it.  Nothing of this has a counterpart in the reference. */
+typedef struct p264hip_input_layout {
+    size_t off_mb, off_mv, off_ref, off_i4, off_coef;      /* p264hip_mb_t[n], int16[n][16][2], int8[n][4], uint8[n][16], int16[n_coef_blocks][16] */
+    size_t off_mv_l1, off_ref_l1, off_weights;             /* B pictures only (0 otherwise): list-1 vectors, indices, bipred_weight[] */
+    size_t bytes;                                          /* of the whole block */
+} p264hip_input_layout_t;
+int  p264hip_input_layout(const p264hip_picture_t *desc, p264hip_input_layout_t *out);
+/* host side, no device involved: the picture's arrays copied into `dst` (cap >= layout.bytes) in that layout; the
+ * macroblock records are checked as p264hip_upload checks them (coefficient ranges inside coefs[]).  Returns the bytes used
+ * or a negative P264HIP_E* code. */
+int64_t p264hip_pack_input(const p264hip_picture_t *pic, void *dst, size_t cap);
+/* the inverse view: *pic = *desc with its array pointers set into `packed` (nothing is copied) */
+int  p264hip_unpack_input(const p264hip_picture_t *desc, const void *packed, size_t bytes, p264hip_picture_t *pic);
+/* packed host buffer -> slot, one asynchronous copy (the buffer stays untouched until a marker / p264hip_sync; the records are
+ * trusted to have been checked by p264hip_pack_input) */
+int  p264hip_upload_packed(p264hip_ctx *ctx, int slot, const p264hip_picture_t *desc, const void *packed, size_t bytes);
+/* device producers: reserve makes room in `slot` for a picture described by desc (scalar fields; its pointers are ignored)
+ * and returns where its packed arrays are to be written; the slot becomes usable with commit, which the caller issues once
+ * its writes have completed (the context's stream does not wait for anybody else's). */
+int  p264hip_input_reserve(p264hip_ctx *ctx, int slot, const p264hip_picture_t *desc, void **dev, size_t *bytes);
+int  p264hip_input_commit(p264hip_ctx *ctx, int slot);
+/* frame `slot` of `stream` converted to planar I420 (Y, U, V back to back, MB-aligned) in device buffer number `index` of
+ * the context (buffers are created on demand and live as long as the context); enqueued on the context's stream - *dev is
+ * readable by other streams / RCCL after p264hip_sync or a marker. */
+int  p264hip_frame_planar_device(p264hip_ctx *ctx, int stream, int slot, int index, void **dev, size_t *bytes);
+/* plain synchronous copies between host and device memory (the fan-out's TCP transport uses them where it stands in for a
+ * device-to-device transport in tests) */
+int  p264hip_copy_to_device(void *dev, const void *host, size_t bytes);
+int  p264hip_copy_from_device(void *host, const void *dev, size_t bytes);
+
 /* Reconstruct a batch: picture input slot pic_ids[i] is decoded into stream streams[i].
  * All pictures of one call are mutually independent (different streams).  Asynchronous. */
 int  p264hip_reconstruct(p264hip_ctx *ctx, const int *pic_ids, const int *streams, int n);

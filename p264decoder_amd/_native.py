@@ -49,6 +49,11 @@ class Picture(C.Structure):
 assert C.sizeof(MbInfo) == 16
 
 
+class InputLayout(C.Structure):
+    """p264hip_input_layout_t"""
+    _fields_ = [(n, C.c_size_t) for n in ("off_mb", "off_mv", "off_ref", "off_i4", "off_coef", "off_mv_l1", "off_ref_l1", "off_weights", "bytes")]
+
+
 class PipeStats(C.Structure):
     """p264pipe_stats_t"""
     _fields_ = [("pictures", C.c_int64), ("bytes", C.c_int64), ("seconds", C.c_double), ("parse_seconds", C.c_double),
@@ -109,6 +114,16 @@ def load(path=None):
         lib.p264hip_host_alloc.argtypes = [C.c_size_t]
         lib.p264hip_host_free.argtypes = [C.c_void_p]
         lib.p264hip_marker.restype = C.c_int
+        lib.p264hip_input_layout.argtypes = [C.POINTER(Picture), C.POINTER(InputLayout)]
+        lib.p264hip_pack_input.restype = C.c_int64
+        lib.p264hip_pack_input.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t]
+        lib.p264hip_unpack_input.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t, C.POINTER(Picture)]
+        lib.p264hip_upload_packed.argtypes = [C.c_void_p, C.c_int, C.POINTER(Picture), C.c_void_p, C.c_size_t]
+        lib.p264hip_input_reserve.argtypes = [C.c_void_p, C.c_int, C.POINTER(Picture), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        lib.p264hip_input_commit.argtypes = [C.c_void_p, C.c_int]
+        lib.p264hip_frame_planar_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        lib.p264hip_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.p264hip_copy_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.p264hip_marker.argtypes = [C.c_void_p]
         lib.p264hip_marker_wait.restype = C.c_int
         lib.p264hip_marker_wait.argtypes = [C.c_void_p, C.c_int]

@@ -1,7 +1,8 @@
 // fan_rccl.hip - the RCCL transport of the stream fan-out (include/p264fan.h): grouped ncclSend / ncclRecv over xGMI,
 // one process per GPU.  librccl is loaded on demand (dlopen), so the library itself does not depend on it.  The
-// interface hands over host buffers; they are staged through device memory on both ends (a send copies host -> device
-// and posts ncclSend, a receive posts ncclRecv and copies device -> host when the group ends).
+// interface's send / recv hand over host buffers; they are staged through device memory (a send copies host -> device
+// and posts ncclSend, a receive posts ncclRecv and copies device -> host when the group ends).  send_dev / recv_dev take
+// device buffers as they are: a worker's pictures and planes never touch its host memory.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdio.h>
@@ -133,6 +134,24 @@ int rc_recv(void *c, int peer, void *buf, size_t n)
     r->pending.push_back({ buf, d, n });
     return r->in_group ? 0 : finish(r);
 }
+// device buffers: no staging on this side (the caller's buffer is complete / free on the device when it calls: ordering
+// against the streams that produce or consume it is the caller's - the fan-out waits for its reconstruction stream first)
+int rc_send_dev(void *c, int peer, const void *dev, size_t n)
+{
+    Rccl *r = (Rccl *)c;
+    if (!r->comm) return p264fan_set_error("rccl transport: the communicator has been aborted");
+    (void)hipSetDevice(r->device);
+    if (int ne = g_api.send((void *)dev, n, 1 /* ncclUint8 */, peer, r->comm, r->stream)) { r->broken = true; return RFAIL("ncclSend", ne); }
+    return r->in_group ? 0 : finish(r);
+}
+int rc_recv_dev(void *c, int peer, void *dev, size_t n)
+{
+    Rccl *r = (Rccl *)c;
+    if (!r->comm) return p264fan_set_error("rccl transport: the communicator has been aborted");
+    (void)hipSetDevice(r->device);
+    if (int ne = g_api.recv(dev, n, 1, peer, r->comm, r->stream)) { r->broken = true; return RFAIL("ncclRecv", ne); }
+    return r->in_group ? 0 : finish(r);
+}
 int rc_begin(void *c) { Rccl *r = (Rccl *)c; r->in_group = true; if (int ne = g_api.gstart()) { r->broken = true; return RFAIL("ncclGroupStart", ne); } return 0; }
 int rc_end(void *c) { Rccl *r = (Rccl *)c; r->in_group = false; if (int ne = g_api.gend()) { r->broken = true; r->pending.clear(); r->used = 0; return RFAIL("ncclGroupEnd", ne); } return finish(r); }
 void rc_close(void *c)
@@ -176,7 +195,7 @@ extern "C" int p264fan_rccl_transport(p264fan_transport_t *t, int rank, int worl
         rc_close(r);
         return -1;
     }
-    t->ctx = r; t->send = rc_send; t->recv = rc_recv; t->group_begin = rc_begin; t->group_end = rc_end; t->close = rc_close; t->name = "rccl"; t->abort = rc_abort;
+    t->ctx = r; t->send = rc_send; t->recv = rc_recv; t->group_begin = rc_begin; t->group_end = rc_end; t->close = rc_close; t->name = "rccl"; t->abort = rc_abort; t->send_dev = rc_send_dev; t->recv_dev = rc_recv_dev;
     if (const char *env = getenv("P264AMD_FAN_TIMEOUT_S")) { const double v = atof(env); if (v > 0) r->timeout_s = v; }
     return 0;
 }

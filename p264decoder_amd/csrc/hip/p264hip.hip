@@ -37,10 +37,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct PicSlot {                       // one device-resident parsed picture
     uint8_t *dev = nullptr;
     size_t   cap = 0;                  // bytes allocated
-    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_coef = 0, off_l1 = 0;   // off_l1: list-1 vectors, indices, weight table (B pictures)
+    size_t   off_mv = 0, off_ref = 0, off_i4 = 0, off_coef = 0, off_mv_l1 = 0, off_ref_l1 = 0, off_weights = 0;   // p264hip_input_layout_t (the last three: B pictures)
     size_t   bytes = 0;                // bytes in use
     p264hip_picture_t meta;            // scalar fields only; pointers unused
-    bool     valid = false;
+    bool     valid = false, reserved = false;   // reserved: p264hip_input_reserve handed the block out, commit is pending
 };
 
 #define BATCH_RING 4
@@ -83,6 +83,7 @@ struct p264hip_ctx {
     McLayout ml;
     std::vector<int> stream_seen;          // p264hip_reconstruct: batch index + 1 that last named a stream in the current call
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
+    std::vector<uint8_t *> planar_pool;    // p264hip_frame_planar_device: planar I420 frames that stay on the device
     // tuning knobs, read from the environment ONCE (p264hip_create); 0 = built-in choice
     int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0;
     hipEvent_t markers[P264HIP_MARKERS] = {};
@@ -166,13 +167,15 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     if (c->d_mc) (void)hipFree(c->d_mc);
     if (c->d_is_intra) (void)hipFree(c->d_is_intra);
     if (c->d_planar) (void)hipFree(c->d_planar);
+    for (uint8_t *p : c->planar_pool) if (p) (void)hipFree(p);
     for (auto &m : c->markers) if (m) (void)hipEventDestroy(m);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
-static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
+// arrays: the picture's host arrays are there to be checked too (false: only the descriptor - the arrays are already packed)
+static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p, bool arrays)
 {
     if (p->mb_w != c->g.mb_w || p->mb_h != c->g.mb_h)
         return fail(P264HIP_EINVAL, "picture is %dx%d MBs, context is %dx%d", p->mb_w, p->mb_h, c->g.mb_w, c->g.mb_h);
@@ -184,7 +187,7 @@ static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
     if (p->slice_type == P264_SLICE_P && p->n_ref < 1) return fail(P264HIP_EINVAL, "P picture without reference");
     if (p->slice_type == P264_SLICE_B) {
         if (p->n_ref < 1 || p->n_ref_l1 < 1 || p->n_ref_l1 > P264HIP_MAX_REFS) return fail(P264HIP_EINVAL, "B picture: list lengths %d / %d", p->n_ref, p->n_ref_l1);
-        if (!p->mv_l1 || !p->ref_idx_l1) return fail(P264HIP_EINVAL, "B picture without list-1 arrays");
+        if (arrays && (!p->mv_l1 || !p->ref_idx_l1)) return fail(P264HIP_EINVAL, "B picture without list-1 arrays");
         if (p->n_coef_blocks >= (1u << MCE_W_SHIFT)) return fail(P264HIP_EINVAL, "B picture with %u coefficient blocks (limit %u: the second pass packs the weight beside the index)", p->n_coef_blocks, 1u << MCE_W_SHIFT);
         for (int i = 0; i < p->n_ref_l1; i++)
             if (p->ref_slot_l1[i] < 0 || p->ref_slot_l1[i] >= c->slots) return fail(P264HIP_EINVAL, "ref_slot_l1[%d]=%d out of range", i, p->ref_slot_l1[i]);
@@ -192,6 +195,7 @@ static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
             for (int i = 0; i < P264HIP_MAX_REFS * P264HIP_MAX_REFS; i++)
                 if (p->bipred_weight[i] < -64 || p->bipred_weight[i] > 128) return fail(P264HIP_EINVAL, "bipred_weight[%d]=%d out of range (-64 .. 128)", i, p->bipred_weight[i]);
     }
+    if (!arrays) return 0;
     if (!p->mb || !p->mv || !p->ref_idx || !p->i4modes || (p->n_coef_blocks && !p->coefs)) return fail(P264HIP_EINVAL, "null picture array");
     // every macroblock's packed blocks must lie inside coefs[] (the kernels index it without further checks)
     const int n_mb = c->g.n_mb;
@@ -204,42 +208,125 @@ static int check_pic(p264hip_ctx *c, const p264hip_picture_t *p)
     return 0;
 }
 
-static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
+// room for a picture of this layout in slot `id`; the slot's offsets follow the layout (include/p264hip.h)
+static int slot_prepare(p264hip_ctx *c, PicSlot &s, const p264hip_input_layout_t &L)
 {
-    int rc = check_pic(c, p);
-    if (rc) return rc;
-    PicSlot &s = c->pics[(size_t)id];
-    const size_t n = (size_t)c->g.n_mb;
-    size_t off_mv = align_up(n * sizeof(p264hip_mb_t), 256);
-    size_t off_ref = off_mv + align_up(n * 64, 256);
-    size_t off_i4 = off_ref + align_up(n * 4, 256);
-    size_t off_coef = off_i4 + align_up(n * 16, 256);
-    const bool isB = p->slice_type == P264_SLICE_B;
-    size_t off_l1 = off_coef + align_up((size_t)p->n_coef_blocks * 32, 256) + 256;
-    size_t need = off_l1 + (isB ? align_up(n * 64, 256) + align_up(n * 4, 256) + 512 : 0);
-    if (need > s.cap) {
+    if (L.bytes > s.cap) {
         if (s.dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(s.dev)); s.dev = nullptr; s.cap = 0; }
-        size_t cap = need + need / 4;
+        size_t cap = L.bytes + L.bytes / 4;
         hipError_t e = hipMalloc((void **)&s.dev, cap);
         if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for picture input: %s", cap, hipGetErrorString(e));
         s.cap = cap;
     }
-    s.off_mv = off_mv; s.off_ref = off_ref; s.off_i4 = off_i4; s.off_coef = off_coef; s.off_l1 = off_l1; s.bytes = need;
-    if (isB) {
-        HIPCHK(hipMemcpyAsync(s.dev + off_l1, p->mv_l1, n * 64, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(s.dev + off_l1 + align_up(n * 64, 256), p->ref_idx_l1, n * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(s.dev + off_l1 + align_up(n * 64, 256) + align_up(n * 4, 256), p->bipred_weight, sizeof p->bipred_weight, hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(s.dev + off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(s.dev + off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(s.dev + off_i4, p->i4modes, n * 16, hipMemcpyHostToDevice, c->stream));
-    if (p->n_coef_blocks)
-        HIPCHK(hipMemcpyAsync(s.dev + off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
+    s.off_mv = L.off_mv; s.off_ref = L.off_ref; s.off_i4 = L.off_i4; s.off_coef = L.off_coef;
+    s.off_mv_l1 = L.off_mv_l1; s.off_ref_l1 = L.off_ref_l1; s.off_weights = L.off_weights; s.bytes = L.bytes;
+    return 0;
+}
+static void slot_meta(PicSlot &s, const p264hip_picture_t *p)
+{
     s.meta = *p;
     s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr; s.meta.mv_l1 = nullptr; s.meta.ref_idx_l1 = nullptr;
+}
+
+static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
+{
+    int rc = check_pic(c, p, true);
+    if (rc) return rc;
+    PicSlot &s = c->pics[(size_t)id];
+    const size_t n = (size_t)c->g.n_mb;
+    p264hip_input_layout_t L;
+    if (p264hip_input_layout(p, &L)) return fail(P264HIP_EINVAL, "picture layout");
+    if ((rc = slot_prepare(c, s, L))) return rc;
+    if (p->slice_type == P264_SLICE_B) {
+        HIPCHK(hipMemcpyAsync(s.dev + L.off_mv_l1, p->mv_l1, n * 64, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.dev + L.off_ref_l1, p->ref_idx_l1, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.dev + L.off_weights, p->bipred_weight, sizeof p->bipred_weight, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(s.dev + L.off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(s.dev + L.off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(s.dev + L.off_i4, p->i4modes, n * 16, hipMemcpyHostToDevice, c->stream));
+    if (p->n_coef_blocks)
+        HIPCHK(hipMemcpyAsync(s.dev + L.off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
+    slot_meta(s, p);
     s.valid = true;
     return 0;
+}
+
+// ---- other ways into a slot (include/p264hip.h): a packed host block in one copy; a device producer (reserve / commit) ----
+extern "C" int p264hip_upload_packed(p264hip_ctx *c, int slot, const p264hip_picture_t *desc, const void *packed, size_t bytes)
+{
+    if (!c || !desc || !packed || slot < 0 || slot >= c->max_pictures) return fail(P264HIP_EINVAL, "p264hip_upload_packed: bad argument (slot %d)", slot);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = check_pic(c, desc, false);
+    if (rc) return rc;
+    p264hip_input_layout_t L;
+    if (p264hip_input_layout(desc, &L) || bytes != L.bytes) return fail(P264HIP_EINVAL, "p264hip_upload_packed: %zu bytes, the layout has %zu", bytes, L.bytes);
+    PicSlot &s = c->pics[(size_t)slot];
+    if ((rc = slot_prepare(c, s, L))) return rc;
+    HIPCHK(hipMemcpyAsync(s.dev, packed, L.bytes, hipMemcpyHostToDevice, c->stream));
+    slot_meta(s, desc);
+    s.valid = true;
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_input_reserve(p264hip_ctx *c, int slot, const p264hip_picture_t *desc, void **dev, size_t *bytes)
+{
+    if (!c || !desc || !dev || !bytes || slot < 0 || slot >= c->max_pictures) return fail(P264HIP_EINVAL, "p264hip_input_reserve: bad argument (slot %d)", slot);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = check_pic(c, desc, false);
+    if (rc) return rc;
+    p264hip_input_layout_t L;
+    if (p264hip_input_layout(desc, &L)) return fail(P264HIP_EINVAL, "picture layout");
+    PicSlot &s = c->pics[(size_t)slot];
+    s.valid = false;
+    // (whatever still reads the slot's previous picture on the context's stream must be through before somebody else writes it)
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = slot_prepare(c, s, L))) return rc;
+    slot_meta(s, desc);
+    s.reserved = true;
+    *dev = s.dev; *bytes = L.bytes;
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_input_commit(p264hip_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= c->max_pictures || !c->pics[(size_t)slot].reserved) return fail(P264HIP_EINVAL, "p264hip_input_commit: slot %d is not reserved", slot);
+    PicSlot &s = c->pics[(size_t)slot];
+    s.reserved = false; s.valid = true;
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_frame_planar_device(p264hip_ctx *c, int stream, int slot, int index, void **dev, size_t *bytes)
+{
+    if (!c || !dev || !bytes || stream < 0 || stream >= c->n_streams || slot < 0 || slot >= c->slots || index < 0 || index >= 4096)
+        return fail(P264HIP_EINVAL, "p264hip_frame_planar_device: bad argument (stream %d slot %d buffer %d)", stream, slot, index);
+    HIPCHK(hipSetDevice(c->device));
+    const Geom &g = c->g;
+    const size_t sz = (size_t)g.w * g.h + 2 * (size_t)g.cw * g.ch;
+    if ((size_t)index >= c->planar_pool.size()) c->planar_pool.resize((size_t)index + 1, nullptr);
+    if (!c->planar_pool[(size_t)index]) {
+        hipError_t e = hipMalloc((void **)&c->planar_pool[(size_t)index], sz);
+        if (e != hipSuccess) { c->planar_pool[(size_t)index] = nullptr; return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for a planar frame: %s", sz, hipGetErrorString(e)); }
+    }
+    const int n_dw = g.n_mb * 96;
+    hipLaunchKernelGGL(k_tile_convert, dim3((n_dw + 255) / 256), dim3(256), 0, c->stream, frame_ptr(c, stream, slot), c->planar_pool[(size_t)index], g, 1);
+    HIPCHK(hipGetLastError());
+    *dev = c->planar_pool[(size_t)index]; *bytes = sz;
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_copy_to_device(void *dev, const void *host, size_t bytes)
+{
+    if (!dev || !host) return fail(P264HIP_EINVAL, "p264hip_copy_to_device: null argument");
+    HIPCHK(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    return P264HIP_OK;
+}
+extern "C" int p264hip_copy_from_device(void *host, const void *dev, size_t bytes)
+{
+    if (!dev || !host) return fail(P264HIP_EINVAL, "p264hip_copy_from_device: null argument");
+    HIPCHK(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return P264HIP_OK;
 }
 
 extern "C" int p264hip_upload(p264hip_ctx *c, int first, const p264hip_picture_t *pics, int n)
@@ -300,7 +387,7 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
         d.cap = need;
     }
     HIPCHK(hipMemcpyAsync(d.dev, s.dev, need, hipMemcpyDeviceToDevice, c->stream));
-    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef; d.off_l1 = s.off_l1; d.bytes = s.bytes;
+    d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef; d.off_mv_l1 = s.off_mv_l1; d.off_ref_l1 = s.off_ref_l1; d.off_weights = s.off_weights; d.bytes = s.bytes;
     d.meta = s.meta; d.valid = true;
     return P264HIP_OK;
 }
@@ -373,10 +460,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         d.chroma_qp_offset = s.meta.chroma_qp_offset; d.deblock = s.meta.deblock;
         d.alpha_off = s.meta.alpha_c0_offset; d.beta_off = s.meta.beta_offset;
         if (s.meta.slice_type == P264_SLICE_B) {
-            const size_t n_mb = (size_t)c->g.n_mb;
-            d.mv_l1 = (const int *)(s.dev + s.off_l1);
-            d.ref_idx_l1 = (const int8_t *)(s.dev + s.off_l1 + align_up(n_mb * 64, 256));
-            d.bipred_w = (const int16_t *)(s.dev + s.off_l1 + align_up(n_mb * 64, 256) + align_up(n_mb * 4, 256));
+            d.mv_l1 = (const int *)(s.dev + s.off_mv_l1);
+            d.ref_idx_l1 = (const int8_t *)(s.dev + s.off_ref_l1);
+            d.bipred_w = (const int16_t *)(s.dev + s.off_weights);
             d.n_ref_l1 = s.meta.n_ref_l1; d.weighted = s.meta.weighted_bipred;
             for (int k = 0; k < P264HIP_MAX_REFS; k++)
                 d.ref_off_l1[k] = (uint32_t)(c->frame_bytes * (size_t)(k < s.meta.n_ref_l1 ? s.meta.ref_slot_l1[k] : s.meta.ref_slot_l1[0]));

@@ -36,7 +36,11 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 /* Per round and worker, always in this order and always of these sizes (a fixed-size exchange keeps both sides in step
  * whatever fails):
  *   root -> worker   fan_ctrl_t                      how many pictures follow and their sizes, or FAN_FINISHED
- *   root -> worker   n packed pictures
+ *   root -> worker   n fan_head_t in one message     the pictures' descriptors (host memory: the worker lays its input slots out
+ *                                                    from them)
+ *   root -> worker   n packed pictures               each ONE block in the layout of an input slot (p264hip_input_layout_t); a worker
+ *                                                    whose transport and backend have the device road receives it straight into the
+ *                                                    slot (recv_dev), otherwise into host memory
  *   worker -> root   fan_status_t                    0, or what failed on the worker (it keeps serving: the root ends the job
  *                                                    with FAN_FINISHED at the next round boundary)
  *   worker -> root   n frames of MB-aligned I420     only when the status is 0
@@ -54,56 +58,41 @@ typedef struct {                        /* root -> worker, once per round, fixed
 } fan_ctrl_t;
 typedef struct {                        /* worker -> root, once per round, fixed size */
     int32_t rc, n;
-    char msg[248];
+    int32_t device_road;                /* this round's pictures and planes never touched the worker's host memory */
+    char msg[244];
 } fan_status_t;
-typedef struct {                        /* head of a packed picture; the arrays follow, each padded to 16 bytes */
+typedef struct {                        /* descriptor of a packed picture (travels apart from the arrays) */
     uint32_t magic;
     int32_t  local_stream;
     p264hip_picture_t desc;             /* pointers are meaningless on the wire */
     uint32_t n_mb;
 } fan_head_t;
-#define FAN_MAGIC 0x70464e32u
-static size_t pad16(size_t v) { return (v + 15) & ~(size_t)15; }
+#define FAN_MAGIC 0x70464e33u
+/* the arrays of a picture as one block in the layout of an input slot; the head beside it */
 static size_t packed_size(const p264hip_picture_t *p)
 {
-    const size_t n = (size_t)p->mb_w * p->mb_h;
-    const size_t l1 = p->slice_type == P264_SLICE_B ? pad16(n * 64) + pad16(n * 4) : 0;          /* list-1 vectors and indices of a B picture */
-    return pad16(sizeof(fan_head_t)) + pad16(n * sizeof(p264hip_mb_t)) + pad16(n * 64) + pad16(n * 4) + pad16(n * 16) + pad16((size_t)p->n_coef_blocks * 32) + l1;
+    p264hip_input_layout_t L;
+    return p264hip_input_layout(p, &L) ? 0 : L.bytes;
 }
-static void pack_picture(uint8_t *dst, int local_stream, const p264hip_picture_t *p)
+static int pack_picture(fan_head_t *h, uint8_t *dst, size_t cap, int local_stream, const p264hip_picture_t *p)
 {
-    const size_t n = (size_t)p->mb_w * p->mb_h;
-    fan_head_t h; memset(&h, 0, sizeof h);
-    h.magic = FAN_MAGIC; h.local_stream = local_stream; h.desc = *p; h.n_mb = (uint32_t)n;
-    h.desc.mb = NULL; h.desc.mv = NULL; h.desc.ref_idx = NULL; h.desc.i4modes = NULL; h.desc.coefs = NULL; h.desc.mv_l1 = NULL; h.desc.ref_idx_l1 = NULL;
-    memcpy(dst, &h, sizeof h); dst += pad16(sizeof h);
-    memcpy(dst, p->mb, n * sizeof(p264hip_mb_t)); dst += pad16(n * sizeof(p264hip_mb_t));
-    memcpy(dst, p->mv, n * 64); dst += pad16(n * 64);
-    memcpy(dst, p->ref_idx, n * 4); dst += pad16(n * 4);
-    memcpy(dst, p->i4modes, n * 16); dst += pad16(n * 16);
-    if (p->n_coef_blocks) memcpy(dst, p->coefs, (size_t)p->n_coef_blocks * 32);
-    dst += pad16((size_t)p->n_coef_blocks * 32);
-    if (p->slice_type == P264_SLICE_B) { memcpy(dst, p->mv_l1, n * 64); dst += pad16(n * 64); memcpy(dst, p->ref_idx_l1, n * 4); }
+    memset(h, 0, sizeof *h);
+    h->magic = FAN_MAGIC; h->local_stream = local_stream; h->desc = *p; h->n_mb = (uint32_t)((size_t)p->mb_w * p->mb_h);
+    h->desc.mb = NULL; h->desc.mv = NULL; h->desc.ref_idx = NULL; h->desc.i4modes = NULL; h->desc.coefs = NULL; h->desc.mv_l1 = NULL; h->desc.ref_idx_l1 = NULL;
+    return p264hip_pack_input(p, dst, cap) < 0 ? fail("a parsed picture does not pack (inconsistent macroblock records)") : 0;
 }
-/* the picture described by a packed message, its arrays pointing into the message */
-static int unpack_picture(const uint8_t *src, size_t bytes, p264hip_picture_t *out, int *local_stream)
+static int check_head(const fan_head_t *h, size_t bytes)
 {
-    fan_head_t h;
-    if (bytes < sizeof h) return fail("packed picture too short");
-    memcpy(&h, src, sizeof h);
-    if (h.magic != FAN_MAGIC || h.n_mb != (uint32_t)(h.desc.mb_w * h.desc.mb_h)) return fail("packed picture: bad header");
-    *out = h.desc; *local_stream = h.local_stream;
-    if (packed_size(out) != bytes) return fail("packed picture: %zu bytes, header says %zu", bytes, packed_size(out));
-    const size_t n = h.n_mb;
-    src += pad16(sizeof h);
-    out->mb = (const p264hip_mb_t *)src; src += pad16(n * sizeof(p264hip_mb_t));
-    out->mv = (const int16_t *)src; src += pad16(n * 64);
-    out->ref_idx = (const int8_t *)src; src += pad16(n * 4);
-    out->i4modes = src; src += pad16(n * 16);
-    out->coefs = (const int16_t *)src; src += pad16((size_t)out->n_coef_blocks * 32);
-    out->mv_l1 = NULL; out->ref_idx_l1 = NULL;
-    if (out->slice_type == P264_SLICE_B) { out->mv_l1 = (const int16_t *)src; src += pad16(n * 64); out->ref_idx_l1 = (const int8_t *)src; }
+    if (h->magic != FAN_MAGIC || h->desc.mb_w < 1 || h->desc.mb_h < 1 || h->n_mb != (uint32_t)(h->desc.mb_w * h->desc.mb_h)) return fail("packed picture: bad header");
+    if (packed_size(&h->desc) != bytes) return fail("packed picture: %zu bytes, its header says %zu", bytes, packed_size(&h->desc));
     return 0;
+}
+/* the picture described by a head and its block, the arrays pointing into the block */
+static int unpack_picture(const fan_head_t *h, const uint8_t *body, size_t bytes, p264hip_picture_t *out, int *local_stream)
+{
+    if (check_head(h, bytes)) return -1;
+    *local_stream = h->local_stream;
+    return p264hip_unpack_input(&h->desc, body, bytes, out) ? fail("packed picture: bad layout") : 0;
 }
 
 /* ---------------------------------------------------------------- default backend ------- */
@@ -113,15 +102,15 @@ static int unpack_picture(const uint8_t *src, size_t bytes, p264hip_picture_t *o
  * launch latency after the other - then converts and downloads the frames and waits once.  The picture's arrays and the
  * output buffers must stay untouched until sync() (the fan-out keeps a round's messages and frames alive until then; frames
  * live in pinned memory so that the downloads are real DMA transfers). */
-typedef struct { p264hip_ctx *hip; int mb_w, mb_h, n_local, n_pend; int *stream, *slot; uint8_t **out; } hipbk_t;
+typedef struct { p264hip_ctx *hip; int mb_w, mb_h, n_local, n_pend, n_last; int *stream, *slot; uint8_t **out; void **planes; size_t plane_bytes; } hipbk_t;
 static void hipbk_close(void *ctx);
 static int hipbk_open(void **ctx, int device, int mb_w, int mb_h, int n_local, int slots)
 {
     hipbk_t *b = (hipbk_t *)calloc(1, sizeof *b);
     if (!b) return fail("out of memory");
     b->stream = (int *)malloc(sizeof(int) * (size_t)n_local); b->slot = (int *)malloc(sizeof(int) * (size_t)n_local);
-    b->out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)n_local);
-    if (!b->stream || !b->slot || !b->out) { hipbk_close(b); return fail("out of memory"); }
+    b->out = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)n_local); b->planes = (void **)calloc((size_t)n_local, sizeof(void *));
+    if (!b->stream || !b->slot || !b->out || !b->planes) { hipbk_close(b); return fail("out of memory"); }
     if (p264hip_create(&b->hip, device, mb_w, mb_h, n_local, slots, n_local) != P264HIP_OK) { fail("%s", p264hip_last_error()); b->hip = NULL; hipbk_close(b); return -1; }
     b->mb_w = mb_w; b->mb_h = mb_h; b->n_local = n_local;
     *ctx = b;
@@ -131,14 +120,18 @@ static int hipbk_sync(void *ctx)
 {
     hipbk_t *b = (hipbk_t *)ctx;
     const int w = b->mb_w * 16, h = b->mb_h * 16, n = b->n_pend;
-    b->n_pend = 0;
+    b->n_pend = 0; b->n_last = 0;
     if (n) {
-        /* input slot = local stream (hipbk_reconstruct); one batch, then the frames */
+        /* input slot = local stream (hipbk_reconstruct); one batch, then the frames: downloaded, or - pictures that came the
+         * device road - converted to planes that stay on the device (hipbk_planes) */
         if (p264hip_reconstruct(b->hip, b->stream, b->stream, n) != P264HIP_OK) return fail("%s", p264hip_last_error());
         for (int i = 0; i < n; i++) {
             uint8_t *o = b->out[i];
-            if (p264hip_read_frame_async(b->hip, b->stream[i], b->slot[i], o, w, o + (size_t)w * h, o + (size_t)w * h * 5 / 4, w / 2) != P264HIP_OK) return fail("%s", p264hip_last_error());
+            b->planes[i] = NULL;
+            if (o) { if (p264hip_read_frame_async(b->hip, b->stream[i], b->slot[i], o, w, o + (size_t)w * h, o + (size_t)w * h * 5 / 4, w / 2) != P264HIP_OK) return fail("%s", p264hip_last_error()); }
+            else if (p264hip_frame_planar_device(b->hip, b->stream[i], b->slot[i], i, &b->planes[i], &b->plane_bytes) != P264HIP_OK) return fail("%s", p264hip_last_error());
         }
+        b->n_last = n;
     }
     return p264hip_sync(b->hip) == P264HIP_OK ? 0 : fail("%s", p264hip_last_error());
 }
@@ -153,14 +146,40 @@ static int hipbk_reconstruct(void *ctx, int s, const p264hip_picture_t *pic, uin
     b->n_pend++;
     return 0;
 }
+/* the device road: the picture's arrays are written into the stream's input slot by the transport */
+static int hipbk_reserve(void *ctx, int s, const p264hip_picture_t *desc, void **dev, size_t *bytes)
+{
+    hipbk_t *b = (hipbk_t *)ctx;
+    if (s < 0 || s >= b->n_local) return fail("local stream %d out of range", s);
+    for (int i = 0; i < b->n_pend; i++)
+        if (b->stream[i] == s) return fail("two pictures of local stream %d in one round", s);     /* (its slot is still to be read) */
+    if (p264hip_input_reserve(b->hip, s, desc, dev, bytes) != P264HIP_OK) return fail("%s", p264hip_last_error());
+    return 0;
+}
+static int hipbk_reconstruct_reserved(void *ctx, int s, const p264hip_picture_t *desc)
+{
+    hipbk_t *b = (hipbk_t *)ctx;
+    if (s < 0 || s >= b->n_local || b->n_pend >= b->n_local) return fail("local stream %d out of range", s);
+    if (p264hip_input_commit(b->hip, s) != P264HIP_OK) return fail("%s", p264hip_last_error());
+    b->stream[b->n_pend] = s; b->slot[b->n_pend] = desc->dst_slot; b->out[b->n_pend] = NULL;
+    b->n_pend++;
+    return 0;
+}
+static int hipbk_planes(void *ctx, int k, void **dev, size_t *bytes)
+{
+    hipbk_t *b = (hipbk_t *)ctx;
+    if (k < 0 || k >= b->n_last || !b->planes[k]) return fail("no device planes for picture %d of the round", k);
+    *dev = b->planes[k]; *bytes = b->plane_bytes;
+    return 0;
+}
 static void hipbk_close(void *ctx)
 {
     hipbk_t *b = (hipbk_t *)ctx;
     if (!b) return;
     if (b->hip) p264hip_destroy(b->hip);
-    free(b->stream); free(b->slot); free(b->out); free(b);
+    free(b->stream); free(b->slot); free(b->out); free(b->planes); free(b);
 }
-static const p264fan_backend_t g_hip_backend = { NULL, hipbk_open, hipbk_reconstruct, hipbk_close, hipbk_sync };
+static const p264fan_backend_t g_hip_backend = { NULL, hipbk_open, hipbk_reconstruct, hipbk_close, hipbk_sync, hipbk_reserve, hipbk_reconstruct_reserved, hipbk_planes };
 /* frames: pinned when a HIP device is there (downloads and RCCL staging copies become DMA), plain memory otherwise */
 static uint8_t *frames_alloc(size_t bytes, int *pinned)
 {
@@ -171,7 +190,7 @@ static uint8_t *frames_alloc(size_t bytes, int *pinned)
 static void frames_free(uint8_t *p, int pinned) { if (pinned) p264hip_host_free(p); else free(p); }
 
 /* ---------------------------------------------------------------- TCP transport --------- */
-typedef struct { int rank, world; int *fd; } tcp_t;        /* fd[peer]; root: one per worker, worker: fd[0] */
+typedef struct { int rank, world; int *fd; uint8_t *bounce; size_t bounce_cap; } tcp_t;        /* fd[peer]; root: one per worker, worker: fd[0] */
 static int io_all(int fd, void *buf, size_t n, int wr)
 {
     uint8_t *p = (uint8_t *)buf;
@@ -186,6 +205,30 @@ static int io_all(int fd, void *buf, size_t n, int wr)
 static int tcp_send(void *c, int peer, const void *buf, size_t n) { tcp_t *t = (tcp_t *)c; return io_all(t->fd[peer], (void *)buf, n, 1); }
 static int tcp_recv(void *c, int peer, void *buf, size_t n) { tcp_t *t = (tcp_t *)c; return io_all(t->fd[peer], buf, n, 0); }
 static int tcp_nop(void *c) { (void)c; return 0; }
+/* P264AMD_FAN_TCP_DEVICE=1: device buffers through a host bounce buffer - stands in for a device-to-device transport where
+ * ranks share one GPU (tests of the device road; RCCL needs one GPU per rank) */
+static uint8_t *tcp_bounce(tcp_t *t, size_t n)
+{
+    if (n > t->bounce_cap) { free(t->bounce); t->bounce = (uint8_t *)malloc(n + n / 4); t->bounce_cap = t->bounce ? n + n / 4 : 0; }
+    if (!t->bounce) fail("out of memory");
+    return t->bounce;
+}
+static int tcp_send_dev(void *c, int peer, const void *dev, size_t n)
+{
+    tcp_t *t = (tcp_t *)c;
+    uint8_t *b = tcp_bounce(t, n);
+    if (!b) return -1;
+    if (p264hip_copy_from_device(b, dev, n) != P264HIP_OK) return fail("%s", p264hip_last_error());
+    return io_all(t->fd[peer], b, n, 1);
+}
+static int tcp_recv_dev(void *c, int peer, void *dev, size_t n)
+{
+    tcp_t *t = (tcp_t *)c;
+    uint8_t *b = tcp_bounce(t, n);
+    if (!b) return -1;
+    if (io_all(t->fd[peer], b, n, 0)) return -1;
+    return p264hip_copy_to_device(dev, b, n) != P264HIP_OK ? fail("%s", p264hip_last_error()) : 0;
+}
 static void tcp_abort(void *c)
 {
     tcp_t *t = (tcp_t *)c;
@@ -197,7 +240,7 @@ static void tcp_close(void *c)
     tcp_t *t = (tcp_t *)c;
     if (!t) return;
     for (int i = 0; i < t->world; i++) if (t->fd[i] >= 0) close(t->fd[i]);
-    free(t->fd); free(t);
+    free(t->fd); free(t->bounce); free(t);
 }
 int p264fan_tcp_transport(p264fan_transport_t *out, int rank, int world, const char *host, int port)
 {
@@ -241,6 +284,8 @@ int p264fan_tcp_transport(p264fan_transport_t *out, int rank, int world, const c
         t->fd[0] = fd;
     }
     out->ctx = t; out->send = tcp_send; out->recv = tcp_recv; out->group_begin = tcp_nop; out->group_end = tcp_nop; out->close = tcp_close; out->name = "tcp"; out->abort = tcp_abort;
+    out->send_dev = NULL; out->recv_dev = NULL;
+    { const char *e = getenv("P264AMD_FAN_TCP_DEVICE"); if (e && atoi(e) > 0) { out->send_dev = tcp_send_dev; out->recv_dev = tcp_recv_dev; } }
     return 0;
 }
 
@@ -276,53 +321,78 @@ int p264fan_worker_run(p264fan *f)
 {
     if (!f || f->rank == 0) return fail("p264fan_worker_run: not a worker");
     uint8_t *msg[FAN_MAX_PER_ROUND] = { 0 }; size_t cap[FAN_MAX_PER_ROUND] = { 0 };
+    fan_head_t *heads = (fan_head_t *)malloc(sizeof(fan_head_t) * FAN_MAX_PER_ROUND);
     uint8_t *out = NULL; size_t frame = 0; int out_pinned = 0;
-    int rc = 0, fatal = 0;                                  /* rc: transport failures only, they end the loop; fatal: this rank cannot stay in step */
+    int rc = heads ? 0 : fail("out of memory"), fatal = heads ? 0 : 1;  /* rc: transport failures only, they end the loop; fatal: this rank cannot stay in step */
     char first_err[248] = "";
-    for (;;) {
+    /* the device road: pictures straight into their input slots, planes straight out of the conversion buffers */
+    const int dev_road = f->t.recv_dev && f->t.send_dev && f->bk.reserve && f->bk.reconstruct_reserved && f->bk.planes;
+    while (!rc) {
         fan_ctrl_t c;
         if (gb(f) || f->t.recv(f->t.ctx, 0, &c, sizeof c) || ge(f)) { rc = -1; break; }
         if (c.n == FAN_FINISHED) break;
         if (c.n < 0 || c.n > FAN_MAX_PER_ROUND) { rc = fail("worker %d: bad control block", f->rank); fatal = 1; break; }   /* (out of step: nothing sane left to do) */
         fan_status_t st; memset(&st, 0, sizeof st); st.n = c.n;
-        /* ---- the round's pictures: always received, whatever state this worker is in */
-        for (int k = 0; k < c.n; k++)
-            if (c.bytes[k] > cap[k]) {
-                free(msg[k]); cap[k] = 0;
-                msg[k] = (uint8_t *)malloc((size_t)c.bytes[k] + c.bytes[k] / 4);
-                if (!msg[k]) { rc = fail("worker %d: out of memory", f->rank); fatal = 1; break; }       /* (cannot even receive: the transport is aborted below) */
-                cap[k] = (size_t)c.bytes[k] + c.bytes[k] / 4;
-            }
-        if (rc) break;
-        if (gb(f)) { rc = -1; break; }
-        for (int k = 0; k < c.n && !rc; k++) if (f->t.recv(f->t.ctx, 0, msg[k], c.bytes[k])) rc = -1;
-        if (ge(f) || rc) { rc = -1; break; }
-        /* ---- reconstruct; a failure becomes the round's status and the worker keeps serving */
-        if (!f->bk_ctx && !first_err[0]) {
+        /* ---- the round's descriptors */
+        if (c.n && (gb(f) || f->t.recv(f->t.ctx, 0, heads, sizeof(fan_head_t) * (size_t)c.n) || ge(f))) { rc = -1; break; }
+        for (int k = 0; k < c.n && !st.rc; k++) if (check_head(&heads[k], c.bytes[k])) st.rc = -1;
+        /* ---- the backend, once */
+        if (!st.rc && !f->bk_ctx && !first_err[0]) {
             if (f->bk.open(&f->bk_ctx, f->device, c.mb_w, c.mb_h, c.n_local_streams, c.slots)) { st.rc = -1; f->bk_ctx = NULL; }
             else {
                 frame = (size_t)c.mb_w * c.mb_h * 384;
-                out = frames_alloc(frame * FAN_MAX_PER_ROUND, &out_pinned);
-                if (!out) { st.rc = -1; fail("worker %d: out of memory", f->rank); }
+                if (!dev_road) { out = frames_alloc(frame * FAN_MAX_PER_ROUND, &out_pinned); if (!out) { st.rc = -1; fail("worker %d: out of memory", f->rank); } }
             }
         }
         if (first_err[0]) { st.rc = -1; fail("%s", first_err); }      /* an earlier round failed: this worker's frame stores are stale */
+        /* ---- the round's pictures: always received, whatever state this worker is in.  Device road: every picture's slot is
+         *      reserved first; if that fails for one of them the whole round goes to host buffers and is answered with the error */
+        void *slot_dev[FAN_MAX_PER_ROUND]; int on_device = dev_road && !st.rc;
+        for (int k = 0; k < c.n && on_device; k++) {
+            size_t bytes = 0;
+            if (f->bk.reserve(f->bk_ctx, heads[k].local_stream, &heads[k].desc, &slot_dev[k], &bytes) || bytes != c.bytes[k]) { if (bytes && bytes != c.bytes[k]) fail("worker %d: slot of %zu bytes for a picture of %u", f->rank, bytes, c.bytes[k]); st.rc = -1; on_device = 0; }
+        }
+        if (!on_device)
+            for (int k = 0; k < c.n; k++)
+                if (c.bytes[k] > cap[k]) {
+                    free(msg[k]); cap[k] = 0;
+                    msg[k] = (uint8_t *)malloc((size_t)c.bytes[k] + c.bytes[k] / 4);
+                    if (!msg[k]) { rc = fail("worker %d: out of memory", f->rank); fatal = 1; break; }       /* (cannot even receive: the transport is aborted below) */
+                    cap[k] = (size_t)c.bytes[k] + c.bytes[k] / 4;
+                }
+        if (rc) break;
+        char keep_err[sizeof g_err]; memcpy(keep_err, g_err, sizeof keep_err);
+        if (gb(f)) { rc = -1; break; }
+        for (int k = 0; k < c.n && !rc; k++)
+            if (on_device ? f->t.recv_dev(f->t.ctx, 0, slot_dev[k], c.bytes[k]) : f->t.recv(f->t.ctx, 0, msg[k], c.bytes[k])) rc = -1;
+        if (ge(f) || rc) { rc = -1; break; }
+        if (st.rc) memcpy(g_err, keep_err, sizeof keep_err);
+        /* ---- reconstruct; a failure becomes the round's status and the worker keeps serving */
         for (int k = 0; k < c.n && !st.rc; k++) {
+            if (on_device) { if (f->bk.reconstruct_reserved(f->bk_ctx, heads[k].local_stream, &heads[k].desc)) st.rc = -1; continue; }
             p264hip_picture_t pic; int ls = 0;
-            if (unpack_picture(msg[k], c.bytes[k], &pic, &ls) || f->bk.reconstruct(f->bk_ctx, ls, &pic, out + frame * (size_t)k)) st.rc = -1;
+            if (unpack_picture(&heads[k], msg[k], c.bytes[k], &pic, &ls) || f->bk.reconstruct(f->bk_ctx, ls, &pic, out + frame * (size_t)k)) st.rc = -1;
         }
         if (!st.rc && bk_sync(f)) st.rc = -1;
-        if (st.rc) { snprintf(st.msg, sizeof st.msg, "%.240s", g_err[0] ? g_err : "reconstruction failed"); if (!first_err[0]) snprintf(first_err, sizeof first_err, "%.240s", st.msg); }
+        void *plane_dev[FAN_MAX_PER_ROUND];
+        for (int k = 0; k < c.n && !st.rc && on_device; k++) {
+            size_t bytes = 0;
+            if (f->bk.planes(f->bk_ctx, k, &plane_dev[k], &bytes) || bytes != frame) { if (bytes && bytes != frame) fail("worker %d: planes of %zu bytes, a frame has %zu", f->rank, bytes, frame); st.rc = -1; }
+        }
+        if (st.rc) { snprintf(st.msg, sizeof st.msg, "%.236s", g_err[0] ? g_err : "reconstruction failed"); if (!first_err[0]) snprintf(first_err, sizeof first_err, "%.236s", st.msg); }
         /* ---- status, then the frames */
+        st.device_road = on_device && !st.rc && c.n > 0;
         if (gb(f) || f->t.send(f->t.ctx, 0, &st, sizeof st) || ge(f)) { rc = -1; break; }
         if (st.rc) continue;
         if (gb(f)) { rc = -1; break; }
-        for (int k = 0; k < c.n && !rc; k++) if (f->t.send(f->t.ctx, 0, out + frame * (size_t)k, frame)) rc = -1;
+        for (int k = 0; k < c.n && !rc; k++)
+            if (on_device ? f->t.send_dev(f->t.ctx, 0, plane_dev[k], frame) : f->t.send(f->t.ctx, 0, out + frame * (size_t)k, frame)) rc = -1;
         if (ge(f) || rc) { rc = -1; break; }
     }
     /* leaving out of step: the root must not wait for this rank's status or frames (RCCL has no "peer closed") */
     if (fatal && f->t.abort) { char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep); f->t.abort(f->t.ctx); memcpy(g_err, keep, sizeof keep); }
     for (int k = 0; k < FAN_MAX_PER_ROUND; k++) free(msg[k]);
+    free(heads);
     if (out) frames_free(out, out_pinned);
     if (!rc && first_err[0]) rc = fail("%s", first_err);    /* the job failed on this worker, even though it left in step */
     return rc;
@@ -353,6 +423,7 @@ static const p264hip_picture_t *next_picture(fstream_t *s, int max_pictures, int
  * this one travels and is reconstructed - for the root's own streams too). */
 typedef struct {
     uint8_t **msg; size_t *cap, *len;   /* [n_streams]; len 0 = the stream has no picture in this round */
+    fan_head_t *head;                   /* [n_streams] the descriptors of the packed pictures */
     int64_t *index;                     /* picture number inside its stream */
     int n, failed, slots, mb_w, mb_h;
     char err[200];
@@ -382,7 +453,7 @@ static void *parse_worker(void *arg)
             if (!R->msg[s]) { j->failed = 1; continue; }
             R->cap[s] = need + need / 4;
         }
-        pack_picture(R->msg[s], s / P->world, pic);
+        if (!need || pack_picture(&R->head[s], R->msg[s], R->cap[s], s / P->world, pic)) { j->failed = 1; continue; }
         R->len[s] = need;
         R->index[s] = P->st[s].pictures - 1;
     }
@@ -407,7 +478,7 @@ static void fill_round(fan_producer_t *P, fan_round_t *R)
     for (int t = 0; t < threads; t++) if (jobs[t].failed) { R->failed = 1; snprintf(R->err, sizeof R->err, "a stream failed to parse (or the host ran out of memory)"); }
     for (int s = 0; s < P->n_streams && !R->failed; s++) {
         if (!R->len[s]) continue;
-        fan_head_t h; memcpy(&h, R->msg[s], sizeof h);
+        const fan_head_t h = R->head[s];
         if (!R->n) { R->mb_w = h.desc.mb_w; R->mb_h = h.desc.mb_h; }
         else if (h.desc.mb_w != R->mb_w || h.desc.mb_h != R->mb_h) { R->failed = 1; snprintf(R->err, sizeof R->err, "stream %d has a different picture size (%dx%d macroblocks, the job runs at %dx%d)", s, h.desc.mb_w, h.desc.mb_h, R->mb_w, R->mb_h); }
         const int sl = p264parse_slots(P->st[s].parser);       /* every rank's frame stores are sized for the stream that needs most */
@@ -447,13 +518,16 @@ int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, co
     P.st = (fstream_t *)calloc((size_t)n_streams, sizeof *P.st);
     fan_ctrl_t *ctrl = (fan_ctrl_t *)calloc((size_t)W, sizeof *ctrl);
     fan_status_t *status = (fan_status_t *)calloc((size_t)W, sizeof *status);
+    fan_head_t *heads = (fan_head_t *)malloc(sizeof(fan_head_t) * (size_t)n_streams);     /* a round's descriptors, grouped by worker */
+    int *head_at = (int *)calloc((size_t)W + 1, sizeof(int));
     uint8_t *frames = NULL; size_t frame = 0; int frames_pinned = 0;
-    int rc = (P.st && ctrl && status) ? 0 : fail("out of memory");
+    int rc = (P.st && ctrl && status && heads && head_at) ? 0 : fail("out of memory");
     for (int k = 0; k < 2 && !rc; k++) {
         fan_round_t *R = &P.rounds[k];
         R->msg = (uint8_t **)calloc((size_t)n_streams, sizeof *R->msg); R->cap = (size_t *)calloc((size_t)n_streams, sizeof *R->cap);
         R->len = (size_t *)calloc((size_t)n_streams, sizeof *R->len); R->index = (int64_t *)calloc((size_t)n_streams, sizeof *R->index);
-        if (!R->msg || !R->cap || !R->len || !R->index) rc = fail("out of memory");
+        R->head = (fan_head_t *)calloc((size_t)n_streams, sizeof *R->head);
+        if (!R->msg || !R->cap || !R->len || !R->index || !R->head) rc = fail("out of memory");
     }
     for (int s = 0; s < n_streams && !rc; s++) {
         P.st[s].parser = p264parse_open(P264PARSE_OPT_QUIET);
@@ -504,8 +578,17 @@ int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, co
             ctrl[r].bytes[ctrl[r].n++] = (uint32_t)R->len[s];
             S.bytes_scattered += (int64_t)R->len[s]; S.pictures_remote++;
         }
+        /* (the descriptors of worker r's pictures, in the order of its control block: heads[head_at[r] .. head_at[r + 1])) */
+        head_at[0] = head_at[1] = 0;
+        for (int r = 1; r < W; r++) {
+            int at = head_at[r];
+            for (int s = r; s < n_streams; s += W) if (R->len[s]) heads[at++] = R->head[s];
+            head_at[r + 1] = at;
+        }
         if (gb(f)) { rc = -1; break; }
         for (int r = 1; r < W && !rc; r++) if (f->t.send(f->t.ctx, r, &ctrl[r], sizeof ctrl[r])) rc = -1;
+        if (ge(f) || rc || gb(f)) { rc = -1; break; }
+        for (int r = 1; r < W && !rc; r++) if (ctrl[r].n && f->t.send(f->t.ctx, r, heads + head_at[r], sizeof(fan_head_t) * (size_t)ctrl[r].n)) rc = -1;
         if (ge(f) || rc || gb(f)) { rc = -1; break; }
         for (int s = 0; s < n_streams && !rc; s++) if (R->len[s] && s % W) if (f->t.send(f->t.ctx, s % W, R->msg[s], R->len[s])) rc = -1;
         if (ge(f) || rc) { rc = -1; break; }
@@ -515,7 +598,7 @@ int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, co
         for (int s = 0; s < n_streams && !rc_local; s += W) {
             if (!R->len[s]) continue;
             p264hip_picture_t pic; int ls = 0;
-            if (unpack_picture(R->msg[s], R->len[s], &pic, &ls) || f->bk.reconstruct(f->bk_ctx, ls, &pic, frames + frame * (size_t)s)) rc_local = -1;
+            if (unpack_picture(&R->head[s], R->msg[s], R->len[s], &pic, &ls) || f->bk.reconstruct(f->bk_ctx, ls, &pic, frames + frame * (size_t)s)) rc_local = -1;
         }
         if (!rc_local && bk_sync(f)) rc_local = -1;
         if (rc_local) snprintf(err_local, sizeof err_local, "root: %.240s", g_err);
@@ -529,6 +612,7 @@ int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, co
             if (R->len[s] && s % W && status[s % W].rc == 0) { if (f->t.recv(f->t.ctx, s % W, frames + frame * (size_t)s, frame)) rc = -1; S.bytes_gathered += (int64_t)frame; }
         if (ge(f) || rc) { rc = -1; break; }
         S.exchange_seconds += now_s() - g0;
+        for (int r = 1; r < W; r++) if (!status[r].rc && status[r].device_road) S.device_road_rounds++;
         for (int r = 1; r < W && !rc; r++)
             if (status[r].rc) { status[r].msg[sizeof status[r].msg - 1] = 0; rc = fail("worker %d: %s", r, status[r].msg); }
         if (!rc && rc_local) rc = fail("%s", err_local);
@@ -557,9 +641,9 @@ int p264fan_root_run(p264fan *f, int n_streams, const uint8_t *const *annexb, co
     for (int k = 0; k < 2; k++) {
         fan_round_t *R = &P.rounds[k];
         if (R->msg) for (int s = 0; s < n_streams; s++) free(R->msg[s]);
-        free(R->msg); free(R->cap); free(R->len); free(R->index);
+        free(R->msg); free(R->cap); free(R->len); free(R->index); free(R->head);
     }
     if (frames) frames_free(frames, frames_pinned);
-    free(P.st); free(ctrl); free(status);
+    free(P.st); free(ctrl); free(status); free(heads); free(head_at);
     return rc;
 }

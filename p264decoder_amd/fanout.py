@@ -9,7 +9,8 @@ from . import _native as N
 
 class Transport(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("send", C.c_void_p), ("recv", C.c_void_p), ("group_begin", C.c_void_p),
-                ("group_end", C.c_void_p), ("close", C.c_void_p), ("name", C.c_char_p), ("abort", C.c_void_p)]
+                ("group_end", C.c_void_p), ("close", C.c_void_p), ("name", C.c_char_p), ("abort", C.c_void_p),
+                ("send_dev", C.c_void_p), ("recv_dev", C.c_void_p)]
 
 
 BK_OPEN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
@@ -18,13 +19,14 @@ BK_CLOSE = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class Backend(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("open", BK_OPEN), ("reconstruct", BK_RECON), ("close", BK_CLOSE), ("sync", C.c_void_p)]
+    _fields_ = [("ctx", C.c_void_p), ("open", BK_OPEN), ("reconstruct", BK_RECON), ("close", BK_CLOSE), ("sync", C.c_void_p),
+                ("reserve", C.c_void_p), ("reconstruct_reserved", C.c_void_p), ("planes", C.c_void_p)]      # (the device road: NULL in test backends)
 
 
 class FanStats(C.Structure):
     _fields_ = [("pictures", C.c_int64), ("pictures_remote", C.c_int64), ("bytes_scattered", C.c_int64), ("bytes_gathered", C.c_int64),
                 ("seconds", C.c_double), ("parse_seconds", C.c_double), ("exchange_seconds", C.c_double), ("rounds", C.c_int), ("world", C.c_int),
-                ("parse_wait_seconds", C.c_double), ("reconstruct_seconds", C.c_double), ("parse_threads", C.c_int), ("reserved", C.c_int)]
+                ("parse_wait_seconds", C.c_double), ("reconstruct_seconds", C.c_double), ("parse_threads", C.c_int), ("device_road_rounds", C.c_int)]
 
 
 FRAME_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_uint8))

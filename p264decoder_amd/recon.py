@@ -137,6 +137,37 @@ class HipReconstructor:
         arr = (N.Picture * len(pictures))(*[p.desc for p in pictures])
         self._chk(self.lib.p264hip_upload(self.h, first, arr, len(pictures)), "p264hip_upload")
 
+    # ---- the packed form of a picture's arrays (p264hip_input_layout_t) and the roads into a slot that use it ----
+    @staticmethod
+    def pack(picture, lib=None):
+        """The picture's arrays as one block in the layout of an input slot (numpy uint8; host side only)."""
+        lib = lib or N.load()
+        lay = N.InputLayout()
+        if lib.p264hip_input_layout(C.byref(picture.desc), C.byref(lay)) != 0:
+            raise P264Error("p264hip_input_layout failed")
+        buf = np.zeros(lay.bytes, np.uint8)
+        n = lib.p264hip_pack_input(C.byref(picture.desc), buf.ctypes.data, buf.size)
+        if n != lay.bytes:
+            raise P264Error("p264hip_pack_input: %d" % n)
+        return buf
+
+    def upload_packed(self, slot, picture, packed):
+        self._chk(self.lib.p264hip_upload_packed(self.h, slot, C.byref(picture.desc), packed.ctypes.data, packed.size), "p264hip_upload_packed")
+
+    def input_reserve(self, slot, picture):
+        """(device address, bytes) of the block slot `slot` expects for this picture; fill it, then input_commit(slot)."""
+        dev, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.p264hip_input_reserve(self.h, slot, C.byref(picture.desc), C.byref(dev), C.byref(n)), "p264hip_input_reserve")
+        return dev.value, n.value
+
+    def input_commit(self, slot):
+        self._chk(self.lib.p264hip_input_commit(self.h, slot), "p264hip_input_commit")
+
+    def frame_planar_device(self, stream, slot, index=0):
+        dev, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.p264hip_frame_planar_device(self.h, stream, slot, index, C.byref(dev), C.byref(n)), "p264hip_frame_planar_device")
+        return dev.value, n.value
+
     def clone_picture(self, dst, src):
         self._chk(self.lib.p264hip_clone_picture(self.h, dst, src), "p264hip_clone_picture")
 

@@ -76,6 +76,7 @@ def main():
            "parse_wait_seconds": round(st["parse_wait_seconds"], 3), "exchange_seconds": round(st["exchange_seconds"], 3),
            "root_reconstruct_seconds": round(st["reconstruct_seconds"], 3),
            "scattered_MB": round(st["bytes_scattered"] / 1e6, 2), "gathered_MB": round(st["bytes_gathered"] / 1e6, 2),
+           "worker_rounds_on_the_device_road": st["device_road_rounds"],      # pictures into their input slots, planes out of the conversion buffers: no host bounce on the workers
            "workload": a.workload, "all_pictures_match_%s" % pinned_by: not bad,
            "what": "rank 0 parses every stream (one host thread per stream, the next round while the current one is exchanged), "
                    "scatters parsed pictures, gathers I420; parse_wait_seconds is the part of the parse that was not hidden"}

@@ -33,6 +33,89 @@ def test_fanout_1080p(lib):
             assert got[(s, i)] == hashes[i]
 
 
+def test_fanout_device_road_two_ranks_one_gpu(lib, f26, f26_hashes, monkeypatch):
+    """The DEVICE ROAD of the protocol (p264fan_transport_t.send_dev / recv_dev + the backend's reserve / reconstruct_reserved /
+    planes): the worker receives every picture straight into the input slot it is reconstructed from and sends the planes out
+    of the device conversion buffer.  Two ranks share the box's GPU, so the transport is TCP with its device entry points
+    switched on (P264AMD_FAN_TCP_DEVICE: a host bounce inside the transport stands in for xGMI); between two GPUs the RCCL
+    transport offers the same entry points (test_rccl_transport_self_exchange covers its calls, test_rccl_two_ranks the job)."""
+    monkeypatch.setenv("P264AMD_FAN_TCP_DEVICE", "1")
+    cif = synth_cases.stream_bytes("cif_ip")
+    cif_h = synth_cases.golden("cif_ip")[1]
+    got, st = fan_helpers.run_job(2, [f26, cif, cif, f26], 30, False, 30100 + (os.getpid() % 200))
+    assert st["pictures"] == 30 + 24 + 24 + 30 and st["pictures_remote"] == 24 + 30
+    assert st["device_road_rounds"] == 30, st                     # every round of the one worker (its two streams end after 24 and 30 pictures)
+    for i in range(30):
+        assert got[(0, i)] == f26_hashes[i] and got[(3, i)] == f26_hashes[i]
+    for i in range(24):
+        assert got[(1, i)] == cif_h[i] and got[(2, i)] == cif_h[i]
+    # B pictures (list-1 arrays and the weight table are part of the block) and 1080p
+    from tests.test_input_layout import B_CIF
+    from tests import oracle_bind
+    from p264decoder_amd import Parser
+    b = synth_cases.stream_bytes(B_CIF)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(b)
+    ora = oracle_bind.load()
+    store = oracle_bind.FrameStore(pics[0].mb_w, pics[0].mb_h, parser.slots)
+    import hashlib
+    want = []
+    for p in pics:
+        h = hashlib.sha256()
+        for plane in oracle_bind.reconstruct(ora, store, p):
+            h.update(plane.tobytes())
+        want.append(h.hexdigest())
+    data = synth_cases.stream_bytes("cfg3_1080p_allp")
+    hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    for streams, n, ref in (([b, b, b], len(pics), want), ([data, data], 3, hashes)):
+        got, st = fan_helpers.run_job(2, streams, n, False, 30400 + (os.getpid() % 200))
+        assert st["device_road_rounds"] == n
+        for s in range(len(streams)):
+            for i in range(n):
+                assert got[(s, i)] == ref[i], (s, i)
+
+
+def test_default_road_is_the_host_one_without_device_entry_points(lib, f26, f26_hashes, monkeypatch):
+    monkeypatch.delenv("P264AMD_FAN_TCP_DEVICE", raising=False)
+    got, st = fan_helpers.run_job(2, [f26, f26], 5, False, 30700 + (os.getpid() % 200))
+    assert st["device_road_rounds"] == 0 and all(got[(1, i)] == f26_hashes[i] for i in range(5))
+
+
+def test_packed_upload_and_reserved_slots_match_the_plain_upload(lib):
+    """p264hip_upload_packed (one copy of the packed block) and p264hip_input_reserve / commit (somebody else writes the
+    block into the slot: here p264hip_copy_to_device) against p264hip_upload, picture by picture; the device-resident planar
+    frame (p264hip_frame_planar_device) against p264hip_read_frame."""
+    import ctypes as C
+    import numpy as np
+    from p264decoder_amd import HipReconstructor, Parser
+    from tests.test_input_layout import B_CIF
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes(B_CIF))
+    hip = HipReconstructor(pics[0].mb_w, pics[0].mb_h, n_streams=3, slots=parser.slots, max_pictures=3, lib=lib)
+    for p in pics:
+        blk = HipReconstructor.pack(p, lib)
+        hip.upload(0, [p])
+        hip.upload_packed(1, p, blk)
+        dev, n = hip.input_reserve(2, p)
+        assert n == blk.size
+        with pytest.raises(Exception):
+            hip.reconstruct([2], [2])                             # reserved, not committed: the slot is not usable yet
+        assert lib.p264hip_copy_to_device(dev, blk.ctypes.data, n) == 0
+        hip.input_commit(2)
+        hip.reconstruct([0, 1, 2], [0, 1, 2])
+        hip.sync()
+        f0 = hip.read_frame(0, p.desc.dst_slot)
+        for s in (1, 2):
+            for a, b in zip(f0, hip.read_frame(s, p.desc.dst_slot)):
+                assert np.array_equal(a, b)
+        pdev, pn = hip.frame_planar_device(2, p.desc.dst_slot, index=1)
+        hip.sync()
+        flat = np.empty(pn, np.uint8)
+        assert lib.p264hip_copy_from_device(flat.ctypes.data, pdev, pn) == 0
+        assert np.array_equal(flat, np.concatenate([a.reshape(-1) for a in f0]))
+    hip.close()
+
+
 def test_rccl_transport_self_exchange(lib):
     """The RCCL transport on one GPU: a communicator of one rank, a grouped ncclSend / ncclRecv to itself through the
     transport's staging buffers (host -> device -> RCCL -> device -> host).  The multi-GPU exchange uses exactly these calls."""
@@ -57,6 +140,26 @@ def test_rccl_transport_self_exchange(lib):
         assert recv(t.ctx, 0, ra.ctypes.data, ra.size) == 0 and recv(t.ctx, 0, rb.ctypes.data, rb.size) == 0
         assert end(t.ctx) == 0
         assert np.array_equal(a, ra) and np.array_equal(b, rb)
+    # device buffers: ncclSend / ncclRecv straight from / into them (send_dev / recv_dev), mixed with staged host messages.
+    # (Two planar frame buffers of a 1080p context serve as the device memory: what a worker sends out of.)
+    from p264decoder_amd import HipReconstructor
+    assert t.send_dev and t.recv_dev
+    send_dev, recv_dev = SEND(t.send_dev), SEND(t.recv_dev)
+    hip = HipReconstructor(120, 68, n_streams=1, slots=2, max_pictures=1, lib=lib)
+    (src, n), (dst, _) = hip.frame_planar_device(0, 0, index=0), hip.frame_planar_device(0, 1, index=1)
+    hip.sync()
+    assert n == 3133440
+    data = rng.integers(0, 256, size=n, dtype=np.uint8)
+    back = np.zeros(n, np.uint8)
+    assert lib.p264hip_copy_to_device(src, data.ctypes.data, n) == 0 and lib.p264hip_copy_to_device(dst, back.ctypes.data, n) == 0
+    ctrl, rctrl = rng.integers(0, 256, size=272, dtype=np.uint8), np.zeros(272, np.uint8)
+    assert begin(t.ctx) == 0
+    assert send(t.ctx, 0, ctrl.ctypes.data, ctrl.size) == 0 and send_dev(t.ctx, 0, src, n) == 0
+    assert recv(t.ctx, 0, rctrl.ctypes.data, rctrl.size) == 0 and recv_dev(t.ctx, 0, dst, n) == 0
+    assert end(t.ctx) == 0
+    assert lib.p264hip_copy_from_device(back.ctypes.data, dst, n) == 0
+    assert np.array_equal(ctrl, rctrl) and np.array_equal(data, back)
+    hip.close()
     close(t.ctx)
 
 

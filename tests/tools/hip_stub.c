@@ -22,6 +22,12 @@ int p264hip_timing_read(p264hip_ctx *c, double *a, int64_t *b) { (void)c;(void)a
 int p264hip_timing_reset(p264hip_ctx *c) { (void)c; return -1; }
 int p264hip_submit_async(p264hip_ctx *c, int s, const p264hip_picture_t *p) { (void)c;(void)s;(void)p; return -1; }
 int p264hip_read_frame_async(p264hip_ctx *c, int s, int sl, uint8_t *y, int ys, uint8_t *u, uint8_t *v, int cs) { (void)c;(void)s;(void)sl;(void)y;(void)ys;(void)u;(void)v;(void)cs; return -1; }
+int p264hip_upload_packed(p264hip_ctx *c, int s, const p264hip_picture_t *d, const void *p, size_t n) { (void)c;(void)s;(void)d;(void)p;(void)n; return -1; }
+int p264hip_input_reserve(p264hip_ctx *c, int s, const p264hip_picture_t *d, void **dev, size_t *n) { (void)c;(void)s;(void)d;(void)dev;(void)n; return -1; }
+int p264hip_input_commit(p264hip_ctx *c, int s) { (void)c;(void)s; return -1; }
+int p264hip_frame_planar_device(p264hip_ctx *c, int s, int sl, int i, void **dev, size_t *n) { (void)c;(void)s;(void)sl;(void)i;(void)dev;(void)n; return -1; }
+int p264hip_copy_to_device(void *d, const void *h, size_t n) { (void)d;(void)h;(void)n; return -1; }
+int p264hip_copy_from_device(void *h, const void *d, size_t n) { (void)h;(void)d;(void)n; return -1; }
 /* the RCCL transport lives with the HIP code: not part of the host-only build */
 #include "p264fan.h"
 int p264fan_rccl_unique_id(uint8_t id[128]) { (void)id; return -1; }

@@ -81,3 +81,24 @@ for frame_bits, poc_bits, w_mb, h_mb, refs in [(60, 4, 6, 5, 1), (4, 70, 6, 5, 1
 print("crafted SPS ok")
 pipe = Pipeline([data, synth_cases.stream_bytes("cif_ip")]*3, threads=4, device=-1, lib=lib)
 print(pipe.run()); pipe.close()
+# the fan-out's root loop, producer threads, packing (p264hip_pack_input) and the unpacked views, one rank, the CPU oracle
+# plugged in as the backend (TEST INFRASTRUCTURE); then two ranks over TCP in threads of this process
+import threading
+from p264decoder_amd.fanout import FanOut
+from tests import fan_helpers
+cif = synth_cases.stream_bytes("cif_ip")
+bst = open(synth_cases.generate("--mbw 22 --mbh 18 --frames 7 --seed 5 --refs 2 --bframes 2 --implicit --d8inf --coded 8 --maxlevel 8"), "rb").read()
+fan = FanOut(0, 1, None, backend=fan_helpers.oracle_backend(), lib=lib)
+print("fan-out, one rank:", fan.root([cif, bst, cif], max_pictures=7)["pictures"])
+fan.close()
+res = {}
+def rank(r):
+    f = FanOut(r, 2, ("tcp", "127.0.0.1", 29871), backend=fan_helpers.oracle_backend(), lib=lib)
+    if r == 0:
+        res["st"] = f.root([cif, bst, bst, cif], max_pictures=7)
+    else:
+        f.worker()
+    f.close()
+ts = [threading.Thread(target=rank, args=(r,)) for r in (0, 1)]
+[t.start() for t in ts]; [t.join(120) for t in ts]
+print("fan-out, two ranks:", res["st"]["pictures"], res["st"]["pictures_remote"])

@@ -39,10 +39,18 @@ N_MB = MB_W * MB_H
 DISTINCT = 4                   # distinct synthetic streams per rank; the S streams cycle through private copies of them
 STAGE_KERNELS = {"inter": "k_mc_sort + k_mc", "intra": "k_intra_sparse",      # (the timed launches hold P pictures only: the sparse build of k_intra)
                  "deblock": "k_deblock_bs + k_deblock"}
+if os.environ.get("P264AMD_BS_FUSED", "1") != "0":
+    STAGE_KERNELS.update(intra="k_intra_sparse (intra macroblocks + the loop filter's edge-info pass as extra workgroups)", deblock="k_deblock")
 
 
 def synth_args(frames, seed):
     return "--mbw %d --mbh %d --frames %d --gop 0 --seed %d --coded 12 --maxlevel 12 --crop-bottom 4" % (MB_W, MB_H, frames, seed)
+
+
+# Round 4: in batches of P pictures the loop filter's edge-info pass (the boundary strengths: 84 B of records and vectors per
+# macroblock in) runs as extra workgroups of the k_intra_sparse launch, where it overlaps the intra work (kernel_intra.h);
+# P264AMD_BS_FUSED=0 gives it its own launch (k_deblock_bs) back.  Its bytes are booked on the stage whose launch does the work.
+EDGE_INFO_FUSED = os.environ.get("P264AMD_BS_FUSED", "1") != "0"
 
 
 def algorithmic_bytes(pics):
@@ -63,8 +71,12 @@ def algorithmic_bytes(pics):
         inter_resid += n_inter * (836 + 16) + int(blocks[~is_intra].sum()) * 32
         # intra: 384 B written + modes (16 B) + MB record (16 B) + coded blocks
         intra += n_intra * (384 + 32) + int(blocks[is_intra].sum()) * 32
-        # deblock: 384 B read + 384 B written + side tables (16 B record, 64 B motion, 4 B refs)
-        deblock += len(rec) * (768 + 84)
+        # deblock: 384 B read + 384 B written + side tables (16 B record, 64 B motion, 4 B refs).  With the edge-info pass inside the
+        # intra launch the side tables are read there; what crosses HBM for them here is then the 16 B of edge info per macroblock
+        # written by that pass and read by k_deblock (not algorithmic: left out on both sides)
+        deblock += len(rec) * (768 + (0 if EDGE_INFO_FUSED else 84))
+        if EDGE_INFO_FUSED:
+            intra += len(rec) * 84
     return {"inter": inter, "intra": intra, "deblock": deblock, "inter_read": inter_read, "inter_with_residual": inter_resid}
 
 

@@ -25,6 +25,7 @@
 #include <stddef.h>
 #include "device_common.h"
 #include "wavefront_sync.h"
+#include "kernel_deblock.h"             // (edge_info_of: the edge-info role of k_intra_sparse)
 
 #define IT_STRIDE 24               // luma tile: row -1..15, byte 3 = left column, 4..19 = MB, 20..23 = top-right
 #define CT_STRIDE 12               // chroma tile (one per plane): byte 3 = left column, 4..11 = MB
@@ -425,7 +426,8 @@ struct IntraShared {
     unsigned long long m_intra[INTRA_MASKS], m_walk[INTRA_MASKS];   // per row window: intra macroblocks / those left to the band walk
     int free_n[2];
 };
-__device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__restrict__ pics, const Geom &g, int *status, const uint8_t *__restrict__ is_intra_all)
+__device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__restrict__ pics, const Geom &g, int *status, const uint8_t *__restrict__ is_intra_all,
+                                              const int pic_index, const bool chroma_role)
 {
     IntraSync &sync = sh.sync;
     uint32_t *lut = sh.lut;
@@ -435,8 +437,7 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
     // one tile set per wavefront, sized by the launch (dynamic shared memory = wavefronts x sizeof(IntraLds))
     extern __shared__ __attribute__((aligned(16))) uint8_t intra_dyn_lds[];
     IntraLds *lds = (IntraLds *)intra_dyn_lds;
-    const PicDev *pd = pics + blockIdx.x;
-    const bool chroma_role = blockIdx.y != 0;               // grid.y = 2: luma and chroma of a picture in separate workgroups
+    const PicDev *pd = pics + pic_index;                    // (luma and chroma of a picture in separate workgroups)
     // (the wavefront's number through readfirstlane: everything the band walk derives from it - rows, windows, masks, the
     // progress it waits for - is then scalar work for the compiler instead of vector instructions on uniform values)
     const int wave = rfl((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
@@ -446,7 +447,7 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
     for (int i = threadIdx.x; i <= n_bands; i += blockDim.x) sync.progress[i] = 0;
     const int wins = (g.mb_w + 63) / 64, n_win = g.mb_h * wins;
     const bool use_free = pd->slice_type != P264_SLICE_I && n_win <= INTRA_MASKS && g.n_mb < 65536;     // (scalar)
-    const uint8_t *is_intra = is_intra_all + (size_t)blockIdx.x * g.n_mb;                                 // written by k_mc_sort[_b] for P / B pictures
+    const uint8_t *is_intra = is_intra_all + (size_t)pic_index * g.n_mb;                                 // written by k_mc_sort[_b] for P / B pictures
     if (threadIdx.x < 2) free_n[threadIdx.x] = 0;
     __syncthreads();
     IntraGrp &L = lds[wave].g[grp];
@@ -666,14 +667,41 @@ __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra)
 {
     __shared__ IntraShared sh;
-    intra_picture(sh, pics, g, status, is_intra);
+    intra_picture(sh, pics, g, status, is_intra, (int)blockIdx.x, blockIdx.y != 0);
 }
 #ifndef INTRA_SPARSE_WAVES_PER_EU
 #define INTRA_SPARSE_WAVES_PER_EU 8
 #endif
+// The sparse build also carries the loop filter's EDGE INFO pass (kernel_deblock.h, K4a) as a third role: that pass is bound
+// by memory (84 bytes of records and vectors per macroblock in, 16 out) and depends on nothing but the parsed input, this
+// kernel is bound by vector-instruction issue and leaves the memory pipes idle - side by side in ONE launch they overlap
+// (two streams did not: the events between them cost more than the overlap).  Workgroup w of the
+// launch: picture w / roles, role w % roles = luma, chroma, then INTRA_BS_WGS edge-info workgroups - a picture's
+// workgroups are neighbours in the dispatch order, so the roles are in flight together all through the launch.
+// Measured at 2048 pictures per launch (scratch/r4_bsfused2.sh, three runs each): own launch 0.59 + (0.37 + 4.78) ms for
+// k_intra_sparse + (k_deblock_bs + k_deblock), fused 0.87 + 4.72 ms - 186.1 k -> 189.1 k frames/s; 2 / 4 / 8 edge-info
+// workgroups per picture: 5.76 / 5.57 / 5.56 ms for the pair against 5.46 with one.
+#define INTRA_BS_WGS 1
 __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_SPARSE_WAVES_PER_EU)
-void k_intra_sparse(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra)
+void k_intra_sparse(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra, EdgeInfo *__restrict__ info, uint32_t inv_mbw, int bs_wgs)
 {
+    const int roles = 2 + bs_wgs;
+    const int pic = (int)(blockIdx.x / (unsigned)roles), role = (int)blockIdx.x - pic * roles;
+    if (role >= 2) {
+        const PicDev *pd = pics + pic;
+        if (!pd->deblock) return;
+        for (int mbi = (role - 2) * (int)blockDim.x + (int)threadIdx.x; mbi < g.n_mb; mbi += bs_wgs * (int)blockDim.x) {
+            int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
+            if (mbi - mby * g.mb_w >= g.mb_w) mby++;
+            const int mbx = mbi - mby * g.mb_w;
+            const uint4 rec = gload4((const uint4 *)pd->mb + mbi);
+            const int *mvs = pd->mv;
+            const uint4 m0 = gload4(mvs + mbi * 16), m1 = gload4(mvs + mbi * 16 + 4), m2 = gload4(mvs + mbi * 16 + 8), m3 = gload4(mvs + mbi * 16 + 12);
+            const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
+            gstore4(info + (size_t)pic * g.n_mb + mbi, edge_info_of<false>(pd, g, mbi, mbx, mby, rec, m0, m1, m2, m3, refs, nullptr));
+        }
+        return;
+    }
     __shared__ IntraShared sh;
-    intra_picture(sh, pics, g, status, is_intra);
+    intra_picture(sh, pics, g, status, is_intra, pic, role != 0);
 }

@@ -85,7 +85,7 @@ struct p264hip_ctx {
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
     std::vector<uint8_t *> planar_pool;    // p264hip_frame_planar_device: planar I420 frames that stay on the device
     // tuning knobs, read from the environment ONCE (p264hip_create); 0 = built-in choice
-    int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0;
+    int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0, tune_bs_fused = -1;
     hipEvent_t markers[P264HIP_MARKERS] = {};
     int next_marker = 0;
     bool timing = false;
@@ -135,6 +135,7 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     if (const char *env = getenv("P264AMD_DEBLOCK_RB_LOG2")) c->tune_rb_log2 = atoi(env);
     if (const char *env = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) c->tune_pics_per_wg = atoi(env);
     if (const char *env = getenv("P264AMD_DEBLOCK_WAVES")) c->tune_db_waves = atoi(env);
+    if (const char *env = getenv("P264AMD_BS_FUSED")) { c->tune_bs_fused = atoi(env); if (c->tune_bs_fused > 16) c->tune_bs_fused = 16; }   // 0: own launch; n: n edge-info workgroups per picture in the k_intra_sparse launch
     if (e == hipSuccess) e = hipMalloc((void **)&c->frames, c->frame_bytes * (size_t)n_streams * slots);
     if (e == hipSuccess) e = hipMemsetAsync(c->frames, 0, c->frame_bytes * (size_t)n_streams * slots, c->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int));
@@ -476,6 +477,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     HIPCHK(hipEventRecord(c->batch_free[r], c->stream));
     const Geom g = c->g;
     const uint32_t inv_mbw = (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w);
+    bool bs_fused = false;
     if (any_p) {
         // motion compensation + residual of all inter macroblocks: device-side counting sort of the work items by what the
         // interpolation has to do, then the luma and chroma kernels over the sorted lists (kernel_mc.h), side by side
@@ -510,13 +512,20 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // luma and chroma of a picture are independent chains: as two workgroups they run side by side (the kernel is bound by
         // the latency of the macroblock-to-macroblock chain, not by arithmetic)
         if (any_i) hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status, (const uint8_t *)c->d_is_intra);
-        else hipLaunchKernelGGL(k_intra_sparse, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status, (const uint8_t *)c->d_is_intra);
+        else {
+            // (P / B pictures only.  Batches without B pictures: the loop filter's edge info is computed by extra workgroups of this
+            // launch, kernel_intra.h)
+            bs_fused = !any_b && c->tune_bs_fused != 0;
+            const int bs_wgs = bs_fused ? (c->tune_bs_fused > 0 ? c->tune_bs_fused : INTRA_BS_WGS) : 0;
+            hipLaunchKernelGGL(k_intra_sparse, dim3((unsigned)n * (2 + bs_wgs)), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status,
+                               (const uint8_t *)c->d_is_intra, c->d_edge, inv_mbw, bs_wgs);
+        }
     }
     {
         ScopedStamp t(c, 2);
         // edge info (boundary strengths, averaged QPs per edge class): everything about an edge that does not depend on samples
         if (any_b) hipLaunchKernelGGL(k_deblock_bs<true>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, inv_mbw);
-        else       hipLaunchKernelGGL(k_deblock_bs<false>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, inv_mbw);
+        else if (!bs_fused) hipLaunchKernelGGL(k_deblock_bs<false>, dim3((g.n_mb + 255) / 256, n), dim3(256), 0, c->stream, c->d_batch[r], g, c->d_edge, inv_mbw);
         // pictures per workgroup = as many as it takes to cover the batch with one workgroup per CU (a second, half-empty round
         // of workgroups costs more than sharing a workgroup: 1280 pictures as 320 workgroups of 4 took 5.35 ms, as 256 of 5 ...)
         int per_wg = (n + c->n_cu - 1) / c->n_cu;

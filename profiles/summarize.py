@@ -49,7 +49,10 @@ def hbm(k):
 def hbm_any(prefix):
     return sum(hbm(k) for k in pmc if k == prefix or k.startswith(prefix + "<") or k.startswith(prefix + "_"))
 # (the bench's P launches run k_intra_sparse; k_intra itself only sees the all-intra IDR launch of the warm-up)
-traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra_sparse" if "k_intra_sparse" in pmc else "k_intra"), "deblock": hbm_any("k_deblock"),
+# (round 4: in P batches the edge-info pass runs inside the k_intra_sparse launch - k_deblock_bs then only appears for the IDR launch
+# of the warm-up and is no part of the deblocking stage's launches)
+bs_own_launch = any(k.startswith("k_deblock_bs") and pmc[k].get("launches_averaged", 0) + 1 >= pmc.get("k_deblock", {}).get("launches_averaged", 0) for k in pmc)
+traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra_sparse" if "k_intra_sparse" in pmc else "k_intra"), "deblock": hbm_any("k_deblock") if bs_own_launch else hbm("k_deblock"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
 traffic["pictures_per_launch"] = int(json.load(open(os.path.join(here, tag + "_bench.json")))["config"]["pictures_per_step"])   # bench.py's default batch, which collect.sh profiles
 json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)

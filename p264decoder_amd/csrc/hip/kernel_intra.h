@@ -659,10 +659,9 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
         }
     }
 }
-// Two builds of the same code.  A batch with I pictures is bound by vector-instruction issue: 96 registers, nothing spilled
-// (config 2: 204 k frames/s against 175 k with 64 registers).  A batch of P / B pictures only is bound by the chain of memory
-// round trips per workgroup: 64 registers, so that all of the batch's workgroups are resident at once (0.42 -> 0.36 ms per
-// 1024-picture launch).
+// Two builds of the same code.  A batch with I pictures gets 96 registers (config 2: 204 k frames/s against 175 k with 64 in round 3;
+// since the band walk's state lives in scalar registers it needs 75).  A batch of P / B pictures only gets 64, so that more of the
+// batch's workgroups are resident at once (0.42 -> 0.36 ms per 1024-picture launch in round 3; no scratch since round 4).
 __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra)
 {

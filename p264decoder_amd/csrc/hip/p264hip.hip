@@ -505,12 +505,11 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     }
     {
         ScopedStamp t(c, 1);
-        // one workgroup per picture: 16 wavefronts while every picture can have a CU to itself, else 8 or 4 so that two or
-        // four pictures share a CU (the kernel is dependency/latency bound: measured +19 % at 512 and +9 % at 1024 pictures)
+        // one workgroup per picture and role: 16 wavefronts while every picture can have a CU to itself, else 8 or 4 so that two or
+        // four pictures share a CU (measured +19 % at 512 and +9 % at 1024 pictures; 2048: 2 / 4 / 8 / 16 -> 1.02 / 0.87 / 0.90 / 1.10 ms)
         int intra_waves = n > 2 * c->n_cu ? INTRA_ROW_WAVES / 4 : n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
         if (c->tune_intra_waves >= 1 && c->tune_intra_waves <= INTRA_ROW_WAVES) intra_waves = c->tune_intra_waves;
-        // luma and chroma of a picture are independent chains: as two workgroups they run side by side (the kernel is bound by
-        // the latency of the macroblock-to-macroblock chain, not by arithmetic)
+        // luma and chroma of a picture are independent chains: as two workgroups they run side by side
         if (any_i) hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status, (const uint8_t *)c->d_is_intra);
         else {
             // (P / B pictures only.  Batches without B pictures: the loop filter's edge info is computed by extra workgroups of this

@@ -288,6 +288,10 @@ __device__ __forceinline__ pk16 pk_clamp(pk16 v, pk16 lo, pk16 hi) { return pk_m
 __device__ __forceinline__ pk16 pk_absd(pk16 a, pk16 b) { pk16 d = a - b; return pk_max(d, -d); }
 __device__ __forceinline__ pk16 pk_lt(pk16 a, pk16 b) { return (a - b) >> (pk16)15; }                  // a < b ? 0xffff : 0
 __device__ __forceinline__ pk16 pk_sel(pk16 m, pk16 a, pk16 b) { return (a & m) | (b & ~m); }            // v_bfi_b32
+// a + b where both halves of both operands are non-negative and the sums stay below 65536 (samples and sums of a few samples):
+// one 32-bit add - nothing carries from the low half into the high one.  v_add_u32 issues in 2.4 cycles per wavefront on
+// gfx950, v_pk_add_u16 in 4.3 (scratch/r4_rates/).
+__device__ __forceinline__ pk16 pk_addu(pk16 a, pk16 b) { return as_pk(as_u(a) + as_u(b)); }
 
 // the three "filterSamplesFlag" conditions, core/frame.c:311,357,398,444
 __device__ __forceinline__ pk16 pk_edge_flag(pk16 p1, pk16 p0, pk16 q0, pk16 q1, pk16 A, pk16 B)
@@ -299,9 +303,9 @@ __device__ __forceinline__ pk16 pk_edge_flag(pk16 p1, pk16 p0, pk16 q0, pk16 q1,
 __device__ __forceinline__ void pk_luma_normal(pk16 p2, pk16 &p1, pk16 &p0, pk16 &q0, pk16 &q1, pk16 q2,
                                                pk16 f, pk16 ap, pk16 aq, pk16 T0)
 {
-    const pk16 avg = (p0 + q0 + (pk16)1) >> (pk16)1;
-    const pk16 dp = pk_clamp(((p2 + avg) >> (pk16)1) - p1, -T0, T0) & (f & ap);
-    const pk16 dq = pk_clamp(((q2 + avg) >> (pk16)1) - q1, -T0, T0) & (f & aq);
+    const pk16 avg = pk_addu(pk_addu(p0, q0), (pk16)1) >> (pk16)1;
+    const pk16 dp = pk_clamp((pk_addu(p2, avg) >> (pk16)1) - p1, -T0, T0) & (f & ap);
+    const pk16 dq = pk_clamp((pk_addu(q2, avg) >> (pk16)1) - q1, -T0, T0) & (f & aq);
     const pk16 tc = T0 - ap - aq;                                   // the masks are -1 where true
     const pk16 delta = pk_clamp((((q0 - p0) << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -tc, tc) & f;
     p1 += dp; q1 += dq;
@@ -314,11 +318,15 @@ __device__ __forceinline__ void pk_luma_strong(pk16 p3, pk16 &p2, pk16 &p1, pk16
 {
     const pk16 small = pk_lt(pk_absd(p0, q0), (A >> (pk16)2) + (pk16)2);
     const pk16 sp = small & ap, sq = small & aq;
-    const pk16 pq = p0 + q0;
-    const pk16 p0w = (p1 + p1 + p0 + q1 + (pk16)2) >> (pk16)2, q0w = (q1 + q1 + q0 + p1 + (pk16)2) >> (pk16)2;
-    const pk16 p0s = (p2 + p1 + p1 + pq + pq + q1 + (pk16)4) >> (pk16)3, q0s = (p1 + pq + pq + q1 + q1 + q2 + (pk16)4) >> (pk16)3;
-    const pk16 p1s = (p2 + p1 + pq + (pk16)2) >> (pk16)2, q1s = (pq + q1 + q2 + (pk16)2) >> (pk16)2;
-    const pk16 p2s = (p3 + p3 + p2 + p2 + p2 + p1 + pq + (pk16)4) >> (pk16)3, q2s = (q3 + q3 + q2 + q2 + q2 + q1 + pq + (pk16)4) >> (pk16)3;
+    // (sums of samples: 32-bit adds, pk_addu; the largest, eight samples + 4, stays below 2048)
+    const pk16 pq = pk_addu(p0, q0), p11 = pk_addu(p1, p1), q11 = pk_addu(q1, q1), pq2 = pk_addu(pk_addu(pq, pq), (pk16)4);
+    const pk16 c2 = (pk16)2;
+    const pk16 p0w = pk_addu(pk_addu(p11, p0), pk_addu(q1, c2)) >> (pk16)2, q0w = pk_addu(pk_addu(q11, q0), pk_addu(p1, c2)) >> (pk16)2;
+    const pk16 p0s = pk_addu(pk_addu(p2, p11), pk_addu(pq2, q1)) >> (pk16)3, q0s = pk_addu(pk_addu(p1, pq2), pk_addu(q11, q2)) >> (pk16)3;
+    const pk16 p1s = pk_addu(pk_addu(p2, p1), pk_addu(pq, c2)) >> (pk16)2, q1s = pk_addu(pk_addu(pq, q1), pk_addu(q2, c2)) >> (pk16)2;
+    const pk16 p22 = pk_addu(p2, p2), q22 = pk_addu(q2, q2);
+    const pk16 p2s = pk_addu(pk_addu(pk_addu(p3, p3), pk_addu(p22, p2)), pk_addu(pk_addu(p1, pq), (pk16)4)) >> (pk16)3;
+    const pk16 q2s = pk_addu(pk_addu(pk_addu(q3, q3), pk_addu(q22, q2)), pk_addu(pk_addu(q1, pq), (pk16)4)) >> (pk16)3;
     p0 = pk_sel(s, pk_sel(sp, p0s, p0w), p0); q0 = pk_sel(s, pk_sel(sq, q0s, q0w), q0);
     p1 = pk_sel(s & sp, p1s, p1); q1 = pk_sel(s & sq, q1s, q1);
     p2 = pk_sel(s & sp, p2s, p2); q2 = pk_sel(s & sq, q2s, q2);
@@ -332,7 +340,7 @@ __device__ __forceinline__ void pk_chroma(pk16 p1, pk16 &p0, pk16 &q0, pk16 q1, 
     p0 = pk_clamp(p0 + delta, (pk16)0, (pk16)255);
     q0 = pk_clamp(q0 - delta, (pk16)0, (pk16)255);
     if (any_strong) {
-        const pk16 p0w = (p1 + p1 + op0 + q1 + (pk16)2) >> (pk16)2, q0w = (q1 + q1 + oq0 + p1 + (pk16)2) >> (pk16)2;
+        const pk16 p0w = pk_addu(pk_addu(pk_addu(p1, p1), op0), pk_addu(q1, (pk16)2)) >> (pk16)2, q0w = pk_addu(pk_addu(pk_addu(q1, q1), oq0), pk_addu(p1, (pk16)2)) >> (pk16)2;
         const pk16 s = f & str;
         p0 = pk_sel(s, p0w, p0);
         q0 = pk_sel(s, q0w, q0);

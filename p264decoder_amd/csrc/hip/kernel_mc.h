@@ -621,12 +621,16 @@ __device__ __forceinline__ void align_row(const uint32_t (&w)[3], uint32_t s, ui
 // vertical 6-tap of four columns over six rows of samples (mc_hv, core/mc.c:186-199), packed 16-bit
 __device__ __forceinline__ uint32_t tap_v4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4, uint32_t r5)
 {
+    // The pair sums of samples are 32-bit adds of two non-negative 16-bit halves (nothing carries across; v_add_u32 issues in 2.4
+    // cycles per wavefront on gfx950, the packed add in 4.3 - scratch/r4_rates/), the rounding term rides on the first of them;
+    // the taps are two packed multiply-adds.
     const uint32_t M = 0x00ff00ffu;
-    const s16x2 c20 = { 20, 20 }, c5 = { 5, 5 }, c16 = { 16, 16 }, z = { 0, 0 }, m = { 255, 255 };
-    s16x2 a = (as_s16x2(r0 & M) + as_s16x2(r5 & M)) + c20 * (as_s16x2(r2 & M) + as_s16x2(r3 & M)) - c5 * (as_s16x2(r1 & M) + as_s16x2(r4 & M));
-    s16x2 b = (as_s16x2((r0 >> 8) & M) + as_s16x2((r5 >> 8) & M)) + c20 * (as_s16x2((r2 >> 8) & M) + as_s16x2((r3 >> 8) & M))
-              - c5 * (as_s16x2((r1 >> 8) & M) + as_s16x2((r4 >> 8) & M));
-    a = (a + c16) >> 5; b = (b + c16) >> 5;
+    const s16x2 c20 = { 20, 20 }, cm5 = { -5, -5 }, z = { 0, 0 }, m = { 255, 255 };
+    const uint32_t a05 = (r0 & M) + (r5 & M) + 0x00100010u, a23 = (r2 & M) + (r3 & M), a14 = (r1 & M) + (r4 & M);
+    const uint32_t b05 = ((r0 >> 8) & M) + ((r5 >> 8) & M) + 0x00100010u, b23 = ((r2 >> 8) & M) + ((r3 >> 8) & M), b14 = ((r1 >> 8) & M) + ((r4 >> 8) & M);
+    s16x2 a = cm5 * as_s16x2(a14) + (c20 * as_s16x2(a23) + as_s16x2(a05));
+    s16x2 b = cm5 * as_s16x2(b14) + (c20 * as_s16x2(b23) + as_s16x2(b05));
+    a = a >> 5; b = b >> 5;
     a = __builtin_elementwise_min(__builtin_elementwise_max(a, z), m);
     b = __builtin_elementwise_min(__builtin_elementwise_max(b, z), m);
     return as_u32(a) | (as_u32(b) << 8);

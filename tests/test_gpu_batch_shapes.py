@@ -42,6 +42,29 @@ def test_workgroup_shapes(lib, oracle, case, rb, per_wg, intra_waves, monkeypatc
     hip.close()
 
 
+@pytest.mark.parametrize("fused", ["0", "1", "3", "16"])
+@pytest.mark.parametrize("case", ["cif_ip", "qpdelta", "wide_70"])
+def test_edge_info_inside_the_intra_launch_or_on_its_own(lib, oracle, case, fused, monkeypatch):
+    """The loop filter's edge-info pass: its own launch (P264AMD_BS_FUSED=0: k_deblock_bs, as batches with I or B pictures always
+    take it) or 1 / 3 / 16 extra workgroups per picture of the k_intra_sparse launch (batches of P pictures; the default is 1)."""
+    monkeypatch.setenv("P264AMD_BS_FUSED", fused)
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes(case))[:8]
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    S = 5
+    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=parser.slots, max_pictures=len(pics), lib=lib)
+    hip.upload(0, pics)
+    for i, p in enumerate(pics):
+        want = oracle_bind.reconstruct(oracle, store, p)
+        hip.reconstruct([i] * S, list(range(S)))
+        for s in (0, S - 1):
+            got = hip.read_frame(s, p.desc.dst_slot)
+            for plane, (a, b) in enumerate(zip(got, want)):
+                assert np.array_equal(a, b), "%s, P264AMD_BS_FUSED=%s: picture %d stream %d plane %d differs" % (case, fused, i, s, plane)
+    hip.close()
+
+
 @pytest.mark.parametrize("band_log2,wgs", [("0", "4"), ("2", "7"), ("6", "200"), ("1", "16")])
 def test_mc_launch_knobs(lib, oracle, band_log2, wgs, monkeypatch):
     """The other launch paths no default run takes: locality bands of the motion-compensation lists of 1 / 4 / 64 macroblock

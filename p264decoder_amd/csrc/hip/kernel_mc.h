@@ -1314,7 +1314,10 @@ __device__ __forceinline__ void mc_roles(uint8_t *images, const PicDev *__restri
 }
 #define MC_IMAGE_BYTES (YItem<false>::LEAD + 4 * 16 * YItem<false>::BYTES)        // the largest of the four roles' images
 static_assert(MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 8 * CItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 32 * CItem<false>::BYTES, "image space");
-__global__ __launch_bounds__(256, 4)
+#ifndef MC_WAVES_PER_EU
+#define MC_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(256, MC_WAVES_PER_EU)
 void k_mc(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
     __shared__ __attribute__((aligned(16))) uint8_t images[MC_IMAGE_BYTES];

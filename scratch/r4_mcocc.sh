@@ -4,7 +4,6 @@
 #   scratch/variant.sh sk4 -DEXPM_LUMA_COPY=1 -DEXPM_RESID=0; scratch/variant.sh sk6 ... -DMC_WAVES_PER_EU=6; scratch/variant.sh sk8 ... =8
 #   scratch/variant.sh full4; scratch/variant.sh full5 -DMC_WAVES_PER_EU=5
 # MC stage per 2048 pictures: full kernel 5.24 ms (five wavefronts: 6.07), skeleton 4.68 / 4.70 / 4.69 ms - occupancy changes nothing:
-# the skeleton's 4.07 TB/s are what HBM gives for 336-byte segments at random places (the synthetic stream's vectors are random)
-# mixed with the stores; the box's linear copy runs at 5.2 TB/s.
+# (nor does the range of the vectors: r4_mvrange.sh)
 cd $GRAFT_REPO_ROOT
 NOGOLD=1 STEPS=20 bash scratch/variants_run.sh "full4 full5 sk4 sk6 sk8" 2048

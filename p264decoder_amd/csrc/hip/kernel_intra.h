@@ -406,7 +406,9 @@ __device__ __forceinline__ void intra_chroma4(const PicDev *pd, const Geom &g, I
 #define INTRA_ROW_WAVES 16          // most wavefronts per picture workgroup
 #endif
 #ifndef INTRA_WAVES_PER_EU
-#define INTRA_WAVES_PER_EU 5
+#define INTRA_WAVES_PER_EU 8        // (64 registers.  Round 3's kernel spilled at that and was built for 5 wavefronts per SIMD - 96 registers; since
+                                    //  the band walk's state is scalar it needs 75 and fits 64 without scratch: config 2 at 5 / 6 / 7 / 8 wavefronts
+                                    //  per SIMD 235 / 234 / 242 / 254 k frames/s, scratch/r4_intraocc.sh)
 #endif
 #define INTRA_BAND 4                // macroblock rows per wavefront = groups of sixteen lanes
 // P / B pictures: intra macroblocks without an intra neighbour to the left or above depend on nothing this kernel writes.
@@ -659,9 +661,8 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
         }
     }
 }
-// Two builds of the same code.  A batch with I pictures gets 96 registers (config 2: 204 k frames/s against 175 k with 64 in round 3;
-// since the band walk's state lives in scalar registers it needs 75).  A batch of P / B pictures only gets 64, so that more of the
-// batch's workgroups are resident at once (0.42 -> 0.36 ms per 1024-picture launch in round 3; no scratch since round 4).
+// Two kernels of the same code, both at 64 registers (8 wavefronts per SIMD) since round 4: k_intra for batches with I pictures,
+// k_intra_sparse - with the edge-info role below - for batches of P / B pictures only.
 __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_WAVES_PER_EU)
 void k_intra(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra)
 {

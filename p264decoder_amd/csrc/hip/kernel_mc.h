@@ -437,7 +437,10 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
     mc_sort_picture<false>(pics, mc_all, g, ml, inv_mbw, cnt, pos, is_intra);
 }
 // batches with B pictures
-__global__ __launch_bounds__(MC_SORT_THREADS)
+#ifndef MC_SORT_B_WAVES_PER_EU
+#define MC_SORT_B_WAVES_PER_EU 8       // 64 registers (9 spilled): two workgroups per CU instead of one - the MC stage of a B launch 5.44 -> 5.37 ms (scratch/r4_sortb_occ.sh)
+#endif
+__global__ __launch_bounds__(MC_SORT_THREADS, MC_SORT_B_WAVES_PER_EU)
 void k_mc_sort_b(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, uint8_t *__restrict__ is_intra)
 {
     __shared__ uint32_t cnt[2 * MC_KEY_SLOTS], pos[2 * MC_KEY_SLOTS];

@@ -511,6 +511,24 @@ def main():
             except Exception:
                 return None, None
 
+        def valu_of(stage):
+            """Vector-instruction issue of the stage's kernels: instructions per launch from the committed counter summary (like the
+            traffic: counters cannot be read inside this run), against this run's stage time - wave instructions x 4 cycles on every
+            SIMD of the device.  The kernels of this path are bound by instruction issue as much as by HBM."""
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+                if S != int(tj.get("pictures_per_launch", 1024)):
+                    return None
+                pmc = json.load(open(os.path.join(ROOT, "profiles", tj["source"])))
+                names = {"inter": ("k_mc_sort", "k_mc"), "intra": ("k_intra_sparse",), "deblock": ("k_deblock",) if EDGE_INFO_FUSED else ("k_deblock", "k_deblock_bs<false>")}[stage]
+                insts = sum(int(pmc[k]["SQ_INSTS_VALU"]) for k in names)
+                prop = torch.cuda.get_device_properties(local_rank)
+                simds, hz = prop.multi_processor_count * 4, 2.4e9          # (hipDeviceProp_t.clockRate of the MI355X: 2400 MHz)
+                return {"wave_instructions_per_launch": insts, "issue_cycles_frac": round(insts * 4.0 / (kernels[stage]["avg_ms"] * 1e-3 * hz * simds), 3),
+                        "simds": simds, "clock_MHz": round(hz / 1e6), "source": "static: profiles/%s (SQ_INSTS_VALU), 4 cycles per wave instruction" % tj["source"]}
+            except Exception:
+                return None
+
         def roofline_of(stage):
             traffic, traffic_source = traffic_of(stage)
             r = {"kernel": STAGE_KERNELS[stage], "stage": stage, "bound": "hbm", "achieved": kernels[stage]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -518,6 +536,7 @@ def main():
                  "algorithmic_bytes_per_launch": kernels[stage]["algorithmic_bytes"], "avg_ms": kernels[stage]["avg_ms"], "measured_copy_GBps": copy_gbps}
             if traffic:
                 r["traffic_over_algorithmic"] = round(traffic / kernels[stage]["algorithmic_bytes"], 3)
+            r["valu"] = valu_of(stage)
             if stage == "inter":
                 r["bytes_per_inter_mb"] = 836
                 r["frac_read"] = kernels[stage]["frac_read"]

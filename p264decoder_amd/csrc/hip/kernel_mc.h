@@ -44,6 +44,15 @@
 #ifndef EXPM_LUMA_COPY
 #define EXPM_LUMA_COPY 0
 #endif
+#ifndef EXPM_NO_STORE
+#define EXPM_NO_STORE 0            // 1: the sample stores are left out (their operands are still computed)
+#endif
+#ifndef EXPM_NO_WINDOW
+#define EXPM_NO_WINDOW 0           // 1: the reference-window loads are left out (the staging stores and everything behind them stay)
+#endif
+#ifndef EXPM_ONLY
+#define EXPM_ONLY 0                // 1: only the luma roles work, 2: only the chroma roles
+#endif
 #ifndef EXPM_RESID
 #define EXPM_RESID 1
 #endif
@@ -476,7 +485,17 @@ __device__ __forceinline__ u32x2 bload2(rsrc_t r, uint32_t off) { return __built
 // (the 8-byte stores of quadrant items fill half a 16-byte row each: left to L2 to merge - non-temporal they cost 0.27 GB of
 // extra HBM writes per launch)
 #define MC_ST2_AUX 0
-__device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b) { const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, MC_ST2_AUX); }
+__device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b)
+{
+    if (EXPM_NO_STORE) { asm volatile("" :: "v"(a), "v"(b), "v"(off)); return; }
+    const u32x2 v = { a, b }; __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, MC_ST2_AUX);
+}
+// a reference-window load (timing switch EXPM_NO_WINDOW: no load, the offset stands in for the data)
+__device__ __forceinline__ u32x4 wload4(rsrc_t r, uint32_t off)
+{
+    if (EXPM_NO_WINDOW) { u32x4 v = { off, off, off, off }; asm volatile("" : "+v"(v)); return v; }
+    return bload4(r, off);
+}
 // the value of lane ^ 1 / lane ^ 2 (inside a group of four lanes: DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t lane_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }
@@ -496,7 +515,11 @@ __device__ __forceinline__ void quad_transpose(uint32_t (&t)[4], const uint32_t 
         t[j] = b1 ? r : a[j]; t[2 + j] = b1 ? a[2 + j] : r;
     }
 }
-__device__ __forceinline__ void bstore4(rsrc_t r, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const u32x4 v = { a, b, c, d }; __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, MC_ST_AUX); }
+__device__ __forceinline__ void bstore4(rsrc_t r, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    if (EXPM_NO_STORE) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(off)); return; }
+    const u32x4 v = { a, b, c, d }; __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, MC_ST_AUX);
+}
 
 // ------------------------------------------------------------------------------------------
 // reference windows in registers
@@ -546,10 +569,10 @@ __device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t rof
         on[j] = !MB || s < 2 || third;
         v[j] = u32x4{ 0, 0, 0, 0 };
         if (on[j]) {
-            if (!CLAMP) v[j] = bload4(rs, roff + strip_mul(sA + s, g.ystrip) + (uint32_t)((wy + row) * 16));
+            if (!CLAMP) v[j] = wload4(rs, roff + strip_mul(sA + s, g.ystrip) + (uint32_t)((wy + row) * 16));
             else {
                 const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
-                u32x4 t = bload4(rs, roff + strip_mul(sc, g.ystrip) + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
+                u32x4 t = wload4(rs, roff + strip_mul(sc, g.ystrip) + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
                 if (st < 0) { const uint32_t e = perm(t.x, t.x, 0x00000000u); t.x = t.y = t.z = t.w = e; }
                 if (st >= g.mb_w) { const uint32_t e = perm(t.w, t.w, 0x03030303u); t.x = t.y = t.z = t.w = e; }
                 v[j] = t;
@@ -1073,9 +1096,9 @@ template <bool MB> struct CItem {
 // replicated first / last sample of each plane's 8 bytes)
 template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece(rsrc_t rs, uint32_t roff, const Geom &g, int strip, int y)
 {
-    if (!CLAMP) return bload4(rs, roff + g.coff + strip_mul(strip, g.cstrip) + (uint32_t)(y * 16));
+    if (!CLAMP) return wload4(rs, roff + g.coff + strip_mul(strip, g.cstrip) + (uint32_t)(y * 16));
     const int sc = clip3i(strip, 0, g.mb_w - 1);             // (a chroma strip is 8 samples wide: one per macroblock column)
-    u32x4 t = bload4(rs, roff + g.coff + strip_mul(sc, g.cstrip) + (uint32_t)(clip3i(y, 0, g.ch - 1) * 16));
+    u32x4 t = wload4(rs, roff + g.coff + strip_mul(sc, g.cstrip) + (uint32_t)(clip3i(y, 0, g.ch - 1) * 16));
     if (strip < 0) { const uint32_t u = perm(t.x, t.x, 0x00000000u), v = perm(t.z, t.z, 0x00000000u); t.x = t.y = u; t.z = t.w = v; }
     if (strip >= g.mb_w) { const uint32_t u = perm(t.y, t.y, 0x03030303u), v = perm(t.w, t.w, 0x03030303u); t.x = t.y = u; t.z = t.w = v; }
     return t;
@@ -1158,8 +1181,8 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
             uint8_t *pimg = images + (wave * I::PER_WAVE + (lane >> 2) * 2) * I::BYTES;
             u32x4 v[5];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = bload4(rs, (((j >> 1) == (i >> 1)) ? own : other) + (uint32_t)(j & 1) * g.cstrip + (uint32_t)(i * 16));
-            v[4] = bload4(rs, own + (uint32_t)(i & 1) * g.cstrip + 64u);
+            for (int j = 0; j < 4; j++) v[j] = wload4(rs, (((j >> 1) == (i >> 1)) ? own : other) + (uint32_t)(j & 1) * g.cstrip + (uint32_t)(i * 16));
+            v[4] = wload4(rs, own + (uint32_t)(i & 1) * g.cstrip + 64u);
 #pragma unroll
             for (int j = 0; j < 4; j++) lds_put16(pimg + (j >> 1) * I::BYTES + i * I::PITCH + (j & 1) * 16, v[j]);
             lds_put16(pimg + (i >> 1) * I::BYTES + 4 * I::PITCH + (i & 1) * 16, v[4]);
@@ -1310,13 +1333,19 @@ __device__ __forceinline__ void mc_roles(uint8_t *images, const PicDev *__restri
     const float inv = (float)spare / (float)tt;
     const int w1 = (n1 != 0) + (int)((float)t1 * inv), w2 = (n2 != 0) + (int)((float)t2 * inv), w3 = (n3 != 0) + (int)((float)t3 * inv);
     const int w0 = wgs_per_pic - w1 - w2 - w3;             // (luma macroblock items take the rounding remainder)
+    if (EXPM_ONLY == 1 && s >= w0 + w1) return;                                 // (timing switches)
+    if (EXPM_ONLY == 2 && s < w0 + w1) return;
+    if (EXPM_ONLY == 3 && !(s < w0 || (s >= w0 + w1 && s < w0 + w1 + w2))) return;   // macroblock items only
     if (s < w0) mc_luma_body<true, PB>(images, pd, mc, g, ml, s, w0);
     else if (s < w0 + w1) mc_luma_body<false, PB>(images, pd, mc, g, ml, s - w0, w1);
     else if (s < w0 + w1 + w2) mc_chroma_body<true, PB>(images, pd, mc, g, ml, s - w0 - w1, w2);
     else mc_chroma_body<false, PB>(images, pd, mc, g, ml, s - w0 - w1 - w2, w3);
 }
+#ifndef MC_IMAGE_BYTES
 #define MC_IMAGE_BYTES (YItem<false>::LEAD + 4 * 16 * YItem<false>::BYTES)        // the largest of the four roles' images
-static_assert(MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 8 * CItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 32 * CItem<false>::BYTES, "image space");
+#endif
+static_assert(EXPM_ONLY == 3 || (MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 8 * CItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 32 * CItem<false>::BYTES), "image space");
+static_assert(MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 8 * CItem<true>::BYTES, "image space of the macroblock roles");
 #ifndef MC_WAVES_PER_EU
 #define MC_WAVES_PER_EU 4
 #endif

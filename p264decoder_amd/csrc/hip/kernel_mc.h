@@ -480,11 +480,15 @@ __device__ __forceinline__ void bstore(rsrc_t r, uint32_t off, uint32_t v) { __b
 __device__ __forceinline__ u32x4 bload4(rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); }
 // reconstructed samples are written once and not read again by this stage: non-temporal stores keep them from pushing
 // reference lines out of L2 (measured: -3 % on the stage)
+#ifndef MC_ST_AUX
 #define MC_ST_AUX 2
+#endif
 __device__ __forceinline__ u32x2 bload2(rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); }
 // (the 8-byte stores of quadrant items fill half a 16-byte row each: left to L2 to merge - non-temporal they cost 0.27 GB of
 // extra HBM writes per launch)
+#ifndef MC_ST2_AUX
 #define MC_ST2_AUX 0
+#endif
 __device__ __forceinline__ void bstore2(rsrc_t r, uint32_t off, uint32_t a, uint32_t b)
 {
     if (EXPM_NO_STORE) { asm volatile("" :: "v"(a), "v"(b), "v"(off)); return; }

@@ -37,24 +37,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 MB_W, MB_H = 120, 68
 N_MB = MB_W * MB_H
 DISTINCT = 4                   # distinct synthetic streams per rank; the S streams cycle through private copies of them
-STAGE_KERNELS = {"inter": "k_mc_sort + k_mc", "intra": "k_intra_sparse",      # (the timed launches hold P pictures only: the sparse build of k_intra)
-                 "deblock": "k_deblock_bs + k_deblock"}
-if os.environ.get("P264AMD_BS_FUSED", "1") != "0":
-    STAGE_KERNELS.update(intra="k_intra_sparse (intra macroblocks + the loop filter's edge-info pass as extra workgroups)", deblock="k_deblock")
+def stage_kernels(edge_info_fused):
+    """Which kernels a stage's time covers.  Round 4: in batches of P pictures the loop filter's edge-info pass (the boundary
+    strengths: 84 B of records and vectors per macroblock in) runs as extra workgroups of the k_intra_sparse launch, where it
+    overlaps the intra work (kernel_intra.h); P264AMD_BS_FUSED=0 gives it its own launch (k_deblock_bs) back.  Which of the two
+    ran is asked of the library (p264hip_last_launch), not guessed from the environment."""
+    k = {"inter": "k_mc_sort + k_mc", "intra": "k_intra_sparse",      # (the timed launches hold P pictures only: the sparse build of k_intra)
+         "deblock": "k_deblock_bs + k_deblock"}
+    if edge_info_fused:
+        k.update(intra="k_intra_sparse (intra macroblocks + the loop filter's edge-info pass as extra workgroups)", deblock="k_deblock")
+    return k
 
 
 def synth_args(frames, seed):
     return "--mbw %d --mbh %d --frames %d --gop 0 --seed %d --coded 12 --maxlevel 12 --crop-bottom 4" % (MB_W, MB_H, frames, seed)
 
 
-# Round 4: in batches of P pictures the loop filter's edge-info pass (the boundary strengths: 84 B of records and vectors per
-# macroblock in) runs as extra workgroups of the k_intra_sparse launch, where it overlaps the intra work (kernel_intra.h);
-# P264AMD_BS_FUSED=0 gives it its own launch (k_deblock_bs) back.  Its bytes are booked on the stage whose launch does the work.
-EDGE_INFO_FUSED = os.environ.get("P264AMD_BS_FUSED", "1") != "0"
-
-
-def algorithmic_bytes(pics):
-    """Bytes that must cross HBM once per launch, per stage (DESIGN.md 'Roofline').  The MC figure is SURVEY 8d's
+def algorithmic_bytes(pics, edge_info_fused=True):
+    """Bytes that must cross HBM once per launch, per stage (DESIGN.md 'Roofline').  The edge-info pass's input is
+    booked on the stage whose launch does the work (edge_info_fused: inside the intra launch).  The MC figure is SURVEY 8d's
     836 B per inter macroblock (384 B reference + 64 B motion + 4 B type read, 384 B written), its read part 452 B; the residual
     input the MC kernels also consume (16 B record + 32 B per coded block, the seam's dense block format) is reported
     separately as `inter_with_residual` and never enters `roofline.frac`."""
@@ -74,8 +75,8 @@ def algorithmic_bytes(pics):
         # deblock: 384 B read + 384 B written + side tables (16 B record, 64 B motion, 4 B refs).  With the edge-info pass inside the
         # intra launch the side tables are read there; what crosses HBM for them here is then the 16 B of edge info per macroblock
         # written by that pass and read by k_deblock (not algorithmic: left out on both sides)
-        deblock += len(rec) * (768 + (0 if EDGE_INFO_FUSED else 84))
-        if EDGE_INFO_FUSED:
+        deblock += len(rec) * (768 + (0 if edge_info_fused else 84))
+        if edge_info_fused:
             intra += len(rec) * 84
     return {"inter": inter, "intra": intra, "deblock": deblock, "inter_read": inter_read, "inter_with_residual": inter_resid}
 
@@ -170,6 +171,56 @@ def bipred_bytes(pics):
     return (total // max(nb, 1), n_inter // max(nb, 1), bi / max(quads, 1))
 
 
+def small_batch_leg(lib, S=256, K=20, Wm=3):
+    """The metric's workload at SURVEY 8d's own batch: S = 256 independent 1080p pictures per launch (the headline runs 2048).
+    Same stream, same step, same stage timing; stream 0 is the golden stream and its last picture is hashed against the real
+    reference decoder's.  Reported under extras.batch_256 - never `value`."""
+    from p264decoder_amd import HipReconstructor, Parser
+    from tests import synth_cases
+    from tests.conftest import frame_sha256
+    T = 1 + Wm + K
+    golden_hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    parsed = []
+    for g in range(DISTINCT):
+        path = synth_cases.generate("cfg3_1080p_allp") if g == 0 else synth_cases.generate(synth_args(T, 1000 + g))
+        parsed.append(Parser(quiet=True, lib=lib).parse_stream(open(path, "rb").read(), limit=T))
+    hip = HipReconstructor(MB_W, MB_H, n_streams=S, slots=2, max_pictures=S * T, lib=lib)
+    for s in range(min(S, DISTINCT)):
+        hip.upload(s * T, parsed[s])
+    for s in range(DISTINCT, S):
+        for t in range(T):
+            hip.clone_picture(s * T + t, (s % DISTINCT) * T + t)
+    streams = list(range(S))
+    for t in range(1 + Wm):
+        hip.reconstruct([s * T + t for s in streams], streams)
+    hip.sync()
+    hip.timing_enable(True)
+    hip.timing_reset()
+    t0 = time.perf_counter()
+    for t in range(1 + Wm, T):
+        hip.reconstruct([s * T + t for s in streams], streams)
+    hip.sync()
+    elapsed = time.perf_counter() - t0
+    timing = hip.timing_read()
+    hip.timing_enable(False)
+    launch = hip.last_launch()
+    fused = launch["edge_info_fused"] > 0
+    ok = frame_sha256(*hip.read_frame(0, parsed[0][-1].desc.dst_slot)) == golden_hashes[T - 1]
+    hip.close()
+    alg = algorithmic_bytes([parsed[s % DISTINCT][T - 1] for s in streams], fused)
+    stages = {}
+    for name in ("inter", "intra", "deblock"):
+        ms, cnt = timing[name]
+        if cnt:
+            avg = ms / cnt
+            stages[name] = {"kernels": stage_kernels(fused)[name], "avg_ms": round(avg, 4), "algorithmic_bytes": alg[name],
+                            "frac_of_hbm_peak": round(alg[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return {"value": round(S * K / elapsed, 1), "unit": "frames/s", "streams": S, "pictures_per_launch": S, "steps": K, "ms_per_step": round(elapsed / K * 1e3, 4),
+            "stages": stages, "launch": launch, "last_picture_matches_reference": ok,
+            "what": "the metric's all-P workload at SURVEY 8d's batch of 256 pictures per launch (one picture per compute unit): stage times and their "
+                    "fractions of the 8 TB/s roofline at the same algorithmic bytes per macroblock as the headline (MC: 836 B per inter macroblock)"}
+
+
 def extras(lib):
     """Figures that are NOT the metric (never `value`): the other single-GPU configurations of BASELINE.json and the
     end-to-end rates, each on a bounded run."""
@@ -177,6 +228,10 @@ def extras(lib):
     from tests import synth_cases
     from tests.conftest import frame_sha256
     out = {}
+    try:
+        out["batch_256"] = small_batch_leg(lib)
+    except Exception as e:                                    # never let an extra take the metric down
+        out["batch_256"] = {"error": str(e)}
     # config 2: 1280x720 Baseline CAVLC, I slices only (intra + IDCT path), 10 pictures x 1024 streams (as many streams as
     # the metric's run: with 256 the two row-wavefront kernels leave most of the chip idle - 97 k against 144 k frames/s)
     pics = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes("cfg2_720p_intra"))[:10]
@@ -395,6 +450,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
     ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0)")
+    ap.add_argument("--only-batch-256", action="store_true", help="print extras.batch_256 (the metric's workload at 256 pictures per launch) and nothing else")
     args = ap.parse_args()
 
     import torch
@@ -414,6 +470,10 @@ def main():
     from tests import synth_cases
     lib = _native.load()
 
+    if args.only_batch_256:                               # (profiles/collect.sh: the kernel trace and the counters of this leg alone)
+        if rank == 0:
+            print(json.dumps({"extras": {"batch_256": small_batch_leg(lib, K=args.steps, Wm=args.warmup)}}), flush=True)
+        return
     S, K, Wm = args.streams, args.steps, args.warmup
     T = 1 + Wm + K                                        # pictures per stream: IDR + warm-up + timed
     # ---- set-up (untimed): write + parse DISTINCT streams, make every stream's inputs resident ----
@@ -462,6 +522,9 @@ def main():
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
     timing = hip.timing_read()
     hip.timing_enable(False)
+    launch = hip.last_launch()                             # the shapes the timed launches had; which launch ran the edge-info pass
+    EDGE_INFO_FUSED = launch["edge_info_fused"] > 0
+    STAGE_KERNELS = stage_kernels(EDGE_INFO_FUSED)
 
     # ---- the timed output against the real reference decoder: the last picture of stream 0 and of its last clone must
     #      hash to what the reference produced for that picture of the golden stream (committed fixture) ----
@@ -481,7 +544,7 @@ def main():
     if rank == 0:
         frames = S * K * world
         fps = frames / elapsed
-        alg = algorithmic_bytes([parsed[s % DISTINCT][t] for s in streams for t in (T - 1,)])   # one representative step
+        alg = algorithmic_bytes([parsed[s % DISTINCT][t] for s in streams for t in (T - 1,)], EDGE_INFO_FUSED)   # one representative step
         kernels = {}
         for name in ("inter", "intra", "deblock"):
             ms, cnt = timing[name]
@@ -559,6 +622,8 @@ def main():
             "kernels": kernels,
             "reconstruct_call_ms": round(timing["reconstruct"][0] / max(timing["reconstruct"][1], 1), 4),
             "golden_check": golden_check,
+            "launch": launch,
+            "build": {"timing_build": bool(lib.p264hip_build_info() & 1)},
         }
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: a reported baseline, not part of the scaling runs
             out["cpu_baseline"] = cpu_baseline(paths[0], T)

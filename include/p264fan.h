@@ -23,9 +23,12 @@
  * the status is 0, by the planes.  A worker that fails keeps answering (with its error) until the root says "finished",
  * which it only does where a worker expects a control block: no failure on either side leaves the other one waiting
  * inside a round.  A rank that cannot even stay in step (no memory to receive a message into, a control block out of range)
- * aborts the transport before it returns, and the RCCL transport bounds every wait (P264AMD_FAN_TIMEOUT_S, default 120 s,
- * then ncclCommAbort): a dead peer ends the job with an error, not with a hang.  All sends and receives of a step are posted between group_begin / group_end (ncclGroupStart /
- * ncclGroupEnd).  Rounds are double-buffered on the root: while round r is exchanged and reconstructed, round r+1 is
+ * aborts the transport before it returns.  An abort is LOCAL (ncclCommAbort tears down the caller's communicator; TCP: the
+ * peers do see "peer closed"): over RCCL the peers of a rank that left end through their own deadline - the RCCL transport
+ * polls every group's completion against P264AMD_FAN_TIMEOUT_S (default 30 s) and the communicator's asynchronous error,
+ * then aborts - so a dead peer ends the job with an error, not with a hang.  Not bounded: ncclGroupEnd itself can block in
+ * the first-use connection handshake with a peer that never arrives.  All sends and receives of a step are posted between
+ * group_begin / group_end (ncclGroupStart / ncclGroupEnd).  Rounds are double-buffered on the root: while round r is exchanged and reconstructed, round r+1 is
  * parsed (one host thread per stream) and packed.
  */
 #ifndef P264FAN_H
@@ -49,9 +52,10 @@ typedef struct p264fan_transport {
     int (*group_end)(void *ctx);
     void (*close)(void *ctx);
     const char *name;
-    /* optional: give up on the peers NOW - pending and later calls fail instead of waiting (RCCL: ncclCommAbort; TCP: the
-     * sockets are shut down, the peers see "peer closed").  A rank that cannot go on inside a round (out of memory for a
-     * message, a control block that makes no sense) calls it before it leaves, so that nobody waits for it. */
+    /* optional: give up on the peers NOW - this rank's pending and later calls fail instead of waiting (RCCL: ncclCommAbort,
+     * local: the peers run into their own deadline; TCP: the sockets are shut down, the peers see "peer closed").  A rank
+     * that cannot go on inside a round (out of memory for a message, a control block that makes no sense) calls it before
+     * it leaves. */
     void (*abort)(void *ctx);
     /* optional: the same for buffers in DEVICE memory of the rank's GPU, no staging (RCCL: ncclSend / ncclRecv straight from /
      * into the buffer).  Where both the transport and the backend offer their device entry points a worker receives a

@@ -165,8 +165,12 @@ int  p264hip_unpack_input(const p264hip_picture_t *desc, const void *packed, siz
  * trusted to have been checked by p264hip_pack_input) */
 int  p264hip_upload_packed(p264hip_ctx *ctx, int slot, const p264hip_picture_t *desc, const void *packed, size_t bytes);
 /* device producers: reserve makes room in `slot` for a picture described by desc (scalar fields; its pointers are ignored)
- * and returns where its packed arrays are to be written; the slot becomes usable with commit, which the caller issues once
- * its writes have completed (the context's stream does not wait for anybody else's). */
+ * and returns where its packed arrays are to be written (it waits for the context's stream only if work that still uses the
+ * slot's previous picture is in flight: one wait covers a whole round of reserves); the slot becomes usable with commit, which
+ * the caller issues once its writes have completed (the context's stream does not wait for anybody else's).  commit queues
+ * the record check p264hip_upload runs on the host (every macroblock's packed blocks inside coefs[]) as a kernel over the
+ * block; p264hip_reconstruct reads the verdicts of a batch's committed pictures with one wait and fails with P264HIP_EINVAL
+ * where a block is inconsistent - the producer is not trusted. */
 int  p264hip_input_reserve(p264hip_ctx *ctx, int slot, const p264hip_picture_t *desc, void **dev, size_t *bytes);
 int  p264hip_input_commit(p264hip_ctx *ctx, int slot);
 /* frame `slot` of `stream` converted to planar I420 (Y, U, V back to back, MB-aligned) in device buffer number `index` of
@@ -205,6 +209,26 @@ int  p264hip_read_frame_async(p264hip_ctx *ctx, int stream, int slot,
 int  p264hip_timing_enable(p264hip_ctx *ctx, int on);
 int  p264hip_timing_read(p264hip_ctx *ctx, double ms_sum[P264HIP_NKERNELS], int64_t count[P264HIP_NKERNELS]);
 int  p264hip_timing_reset(p264hip_ctx *ctx);
+
+/* What the last p264hip_reconstruct call launched (the workgroup shapes follow from the batch size and the device's compute
+ * units; tests assert that a batch of the bench's size selects the bench's shapes, bench.py records them).  Diagnostics only. */
+typedef struct p264hip_launch_info {
+    int32_t pictures;              /* pictures of the batch */
+    int32_t compute_units;         /* of the context's device */
+    int32_t mc_wgs_per_picture;    /* k_mc: workgroups per picture (0: no inter launch) */
+    int32_t intra_waves;           /* k_intra / k_intra_sparse: wavefronts per workgroup */
+    int32_t edge_info_fused;       /* edge-info workgroups per picture inside the k_intra_sparse launch (0: own launch k_deblock_bs) */
+    int32_t deblock_pics_per_wg, deblock_rb_log2, deblock_waves, deblock_wgs;
+    int32_t reserved[7];
+} p264hip_launch_info_t;
+int  p264hip_last_launch(p264hip_ctx *ctx, p264hip_launch_info_t *out);
+
+/* Properties of the library build.  Bit 0 (P264HIP_BUILD_TIMING): compiled with -DP264AMD_TIMING_BUILD, which unlocks the
+ * EXPM_* / EXPD_* switches of the kernel headers - pieces of the kernels compiled out to time the rest.  Such a build
+ * produces wrong pictures; p264hip_create refuses to run in it unless P264AMD_TIMING_BUILD_OK=1 is set in the environment
+ * (scratch/variants_run.sh does), bench.py records the flag and the test suite asserts it is clear. */
+#define P264HIP_BUILD_TIMING 1
+int  p264hip_build_info(void);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,15 @@ class Picture(C.Structure):
 assert C.sizeof(MbInfo) == 16
 
 
+class LaunchInfo(C.Structure):
+    """p264hip_launch_info_t"""
+    _fields_ = [(n, C.c_int32) for n in ("pictures", "compute_units", "mc_wgs_per_picture", "intra_waves", "edge_info_fused",
+                                         "deblock_pics_per_wg", "deblock_rb_log2", "deblock_waves", "deblock_wgs")] + [("reserved", C.c_int32 * 7)]
+
+
+BUILD_TIMING = 1
+
+
 class InputLayout(C.Structure):
     """p264hip_input_layout_t"""
     _fields_ = [(n, C.c_size_t) for n in ("off_mb", "off_mv", "off_ref", "off_i4", "off_coef", "off_mv_l1", "off_ref_l1", "off_weights", "bytes")]
@@ -108,6 +117,10 @@ def load(path=None):
         lib.p264hip_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.p264hip_timing_reset.restype = C.c_int
         lib.p264hip_timing_reset.argtypes = [C.c_void_p]
+        lib.p264hip_last_launch.restype = C.c_int
+        lib.p264hip_last_launch.argtypes = [C.c_void_p, C.POINTER(LaunchInfo)]
+        lib.p264hip_build_info.restype = C.c_int
+        lib.p264hip_build_info.argtypes = []
         lib.p264hip_upload_async.restype = C.c_int
         lib.p264hip_upload_async.argtypes = [C.c_void_p, C.c_int, C.POINTER(Picture)]
         lib.p264hip_host_alloc.restype = C.c_void_p

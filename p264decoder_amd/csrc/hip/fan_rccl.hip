@@ -1,7 +1,7 @@
 // fan_rccl.hip - the RCCL transport of the stream fan-out (include/p264fan.h): grouped ncclSend / ncclRecv over xGMI,
 // one process per GPU.  librccl is loaded on demand (dlopen), so the library itself does not depend on it.  The
 // interface's send / recv hand over host buffers; they are staged through device memory (a send copies host -> device
-// and posts ncclSend, a receive posts ncclRecv and copies device -> host when the group ends).  send_dev / recv_dev take
+// and posts ncclSend, a receive posts ncclRecv and copies device -> host once the group has completed).  send_dev / recv_dev take
 // device buffers as they are: a worker's pictures and planes never touch its host memory.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include <vector>
 #include "p264fan.h"
+#include "fan_wait.h"
 
 extern "C" int p264fan_set_error(const char *fmt, ...);       // fanout.c: the message p264fan_last_error() returns
 
@@ -56,16 +57,22 @@ struct Rccl {
     std::vector<void *> stage; std::vector<size_t> cap; size_t used = 0;      // staging buffers of the current group
     std::vector<Pending> pending;
     bool in_group = false, broken = false;
-    double timeout_s = 120.0;                                 // P264AMD_FAN_TIMEOUT_S: longest wait for a group before the communicator is aborted
+    double timeout_s = 30.0;                                  // P264AMD_FAN_TIMEOUT_S: longest wait for a group before the communicator is aborted
 };
 double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+// ncclCommAbort tears down THIS rank's communicator: its own pending operations fail instead of waiting.  The peers are not
+// told - each of them ends through its own deadline (P264AMD_FAN_TIMEOUT_S) or its communicator's asynchronous error.
 void rc_abort(void *c)
 {
     Rccl *r = (Rccl *)c;
     if (!r || !r->comm) return;
     (void)hipSetDevice(r->device);
-    if (g_api.abort) g_api.abort(r->comm);                     // pending operations of every rank of the communicator fail instead of waiting
+    if (g_api.abort) g_api.abort(r->comm);
     r->comm = nullptr; r->broken = true;
+    // what the aborted operations left on the stream drains now (bounded: no transfer of ours targets host memory before its
+    // group has completed, so nothing can land in a buffer the caller has given up - this only keeps the stream reusable)
+    const double t0 = now_s();
+    while (hipStreamQuery(r->stream) == hipErrorNotReady && now_s() - t0 < 2.0) usleep(200);
 }
 void *stage_buf(Rccl *r, size_t bytes)
 {
@@ -79,36 +86,32 @@ void *stage_buf(Rccl *r, size_t bytes)
     }
     return r->stage[r->used++];
 }
-// the group's transfers are on the stream: the device -> host copies of what was received follow them on the same stream
-// (real DMA when the caller's buffers are pinned, which the fan-out's frame buffers are), one wait for everything
+// The group's transfers are on the stream.  WAIT FIRST, COPY AFTERWARDS: the stream is polled against the deadline and the
+// communicator's asynchronous error (fan_wait.h) with nothing but the transfers on it, and the device -> host copies of
+// what was received are issued only once the receives have completed.  (Queued behind the receives, a copy into pageable
+// host memory - control blocks and statuses live on stacks and in malloc memory - blocks INSIDE hipMemcpyAsync until the
+// receive in front of it completes: with a dead peer the deadline below would never be reached, and a copy queued before
+// an abort could land in a buffer its owner has left.)
 int finish(Rccl *r)
 {
+    int code = 0;
+    const int w = fan_bounded_wait(
+        [&]() { const hipError_t q = hipStreamQuery(r->stream); return q == hipSuccess ? 0 : q == hipErrorNotReady ? 1 : 0x10000 + (int)q; },
+        [&]() { int ae = 0; return (g_api.async_err && r->comm && g_api.async_err(r->comm, &ae) == 0) ? ae : 0; },
+        now_s, []() { usleep(200); }, r->timeout_s, 2000 /* the first polls spin: a round's transfers take well under a millisecond */, &code);
+    if (w != FAN_WAIT_DONE) {
+        r->pending.clear(); r->used = 0;
+        if (w == FAN_WAIT_STREAM_ERROR) { r->broken = true; return HFAIL("completing a group", (hipError_t)(code - 0x10000)); }
+        const int rc = w == FAN_WAIT_COMM_ERROR ? RFAIL("asynchronous error of the communicator", code)
+                                                : p264fan_set_error("rccl transport: a group did not complete within %.0f s (a peer has gone?): communicator aborted", r->timeout_s);
+        rc_abort(r);
+        return rc;
+    }
     hipError_t e = hipSuccess;
     for (auto &p : r->pending) if (e == hipSuccess) e = hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, r->stream);
-    // a bounded wait: RCCL has no "peer closed" - a rank that died (or aborted) would leave this one in the stream forever.
-    // Poll the stream; an asynchronous error of the communicator or the deadline aborts it.
-    const double t0 = now_s();
-    unsigned spins = 0;
-    while (e == hipSuccess) {
-        const hipError_t q = hipStreamQuery(r->stream);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) { e = q; break; }
-        int ae = 0;
-        if (g_api.async_err && r->comm && g_api.async_err(r->comm, &ae) == 0 && ae != 0) {
-            r->pending.clear(); r->used = 0;
-            const int rc = RFAIL("asynchronous error of the communicator", ae);
-            rc_abort(r);
-            return rc;
-        }
-        if (now_s() - t0 > r->timeout_s) {
-            r->pending.clear(); r->used = 0;
-            rc_abort(r);
-            return p264fan_set_error("rccl transport: a group did not complete within %.0f s (a peer has gone?): communicator aborted", r->timeout_s);
-        }
-        if (++spins > 2000) usleep(200);                       // (the first polls spin: a round's transfers take well under a millisecond)
-    }
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);    // (copies only: nothing here waits for a peer)
     r->pending.clear(); r->used = 0;
-    if (e != hipSuccess) { r->broken = true; return HFAIL("completing a group", e); }
+    if (e != hipSuccess) { r->broken = true; return HFAIL("copying what a group received", e); }
     return 0;
 }
 int rc_send(void *c, int peer, const void *buf, size_t n)

@@ -4,11 +4,13 @@
 // sample filters deblock_luma_c / deblock_chroma_c / deblock_luma_intra_c /
 // deblock_chroma_intra_c (core/frame.c:302-470).
 //
-// K4a k_deblock_bs   - everything about an edge that does not depend on pixels: the 32 boundary
-//                      strengths of a macroblock (core/frame.c:535-581) and, per edge class
-//                      {left, top, inner} x {luma, chroma}, alpha / beta / tc0[bS] from the averaged
-//                      QPs (core/frame.c:472-488,593-601).  Fully parallel, one launch per batch,
-//                      64 bytes of "edge info" per macroblock.
+// K4a edge info      - everything about an edge that does not depend on pixels: the 32 boundary
+//                      strengths of a macroblock (core/frame.c:535-581) and the averaged QPs of the
+//                      edge classes {left, top, inner} x {luma, chroma} (core/frame.c:593-601), 16
+//                      bytes per macroblock (EdgeInfo below; alpha / beta / tc0 are expanded by the
+//                      consumer, edge_expand).  Fully parallel, one lane per macroblock: as extra
+//                      workgroups of the k_intra_sparse launch in batches of P pictures
+//                      (kernel_intra.h), as its own launch k_deblock_bs otherwise.
 // K4b k_deblock      - the sample filters.  The filter is defined in macroblock raster order
 //                      (left edge, inner vertical edges, top edge, inner horizontal edges of one MB
 //                      before the next MB) and the result depends on that order: MB (x,y) must see
@@ -26,7 +28,11 @@
 #define DEBLOCK_WAIT_SLEEP 16
 #endif
 
-// timing experiments (scratch/variant.sh): results are wrong unless all defaults hold
+// Timing experiments (scratch/variant.sh, r4_dbexp.sh): results are wrong unless all defaults hold, so the switches only exist
+// in a build that says what it is (-DP264AMD_TIMING_BUILD, see kernel_mc.h and p264hip_build_info()).
+#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPD_LUMA_EDGES) || defined(EXPD_CHROMA_EDGES) || defined(EXPD_STRONG) || defined(EXPD_HPASS) || defined(EXPD_BANDSYNC) || defined(EXPD_VMCNT) || defined(EXPD_STAMPS))
+#error "EXPD_* switches produce wrong pictures: they need -DP264AMD_TIMING_BUILD"
+#endif
 #ifndef EXPD_LUMA_EDGES
 #define EXPD_LUMA_EDGES 4
 #endif
@@ -102,6 +108,12 @@ __device__ __forceinline__ int bs_motion_b(uint32_t p0, uint32_t p1, uint32_t q0
     return !(straight || crossed);
 }
 
+// wave-uniform base + 32-bit byte offset per lane: the form global_load / global_store take with the base in scalar registers
+// (no 64-bit address per lane)
+template <class T> __device__ __forceinline__ const uint8_t *ubase(const T *base, uint32_t byte_off) { return (const uint8_t *)base + byte_off; }
+// the value lane - 1 of the wavefront holds (DPP wave_shr:1; lane 0 keeps its own)
+__device__ __forceinline__ uint32_t lane_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
+
 // The edge info of one macroblock from its record, vectors and reference indices plus what it loads of the neighbours.  TWO_LISTS: B pictures in the batch (their motion test:
 // bs_motion_b; pic_of = reference index -> picture, both lists, in LDS).
 struct PicOf { uint32_t of[2][P264HIP_MAX_REFS]; };
@@ -117,14 +129,28 @@ __device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, i
                                               const uint4 m0, const uint4 m1, const uint4 m2, const uint4 m3, const uint32_t refs, const PicOf *pic_tab)
 {
     const bool b_pic = TWO_LISTS && pd->slice_type == P264_SLICE_B;
-    const int li = mbx > 0 ? mbi - 1 : mbi, ti = mby > 0 ? mbi - g.mb_w : mbi;       // neighbours (self where there is none: unused)
+    // neighbours (self where there is none: unused).  (ti written so that no select needs the picture width in a vector register)
+    const int above = mbi - g.mb_w;
+    const int li = mbx > 0 ? mbi - 1 : mbi, ti = above >= 0 ? above : mbi;
     const uint4 *recs = (const uint4 *)pd->mb;
-    const uint4 recL = gload4(recs + li), recT = gload4(recs + ti);
+    const uint4 recT = gload4(ubase(recs, (uint32_t)ti * 16u));
     const int *mvs = pd->mv;
-    const uint4 mT = gload4(mvs + ti * 16 + 12);                                       // bottom row of the macroblock above
-    const AS1 int *mvg = glob(mvs);
-    const int mL[4] = { mvg[li * 16 + 3], mvg[li * 16 + 7], mvg[li * 16 + 11], mvg[li * 16 + 15] };   // right column of the left one
-    const uint32_t refsL = gload1(pd->ref_idx + li * 4), refsT = gload1(pd->ref_idx + ti * 4);
+    const uint4 mT = gload4(ubase(mvs, (uint32_t)ti * 64u + 48u));                     // bottom row of the macroblock above
+    const uint32_t refsT = gload1(ubase(pd->ref_idx, (uint32_t)ti * 4u));
+    // The left macroblock is the lane below's own macroblock (callers: consecutive lanes = consecutive macroblocks, and a lane's
+    // left neighbour is active whenever the lane is): its record, the right column of its vectors and its reference indices
+    // come out of that lane's registers (DPP wave_shr:1) - as loads they were six requests per lane for bytes that another
+    // lane of the same wavefront holds, four of them single dwords of four different 16-byte rows.  Lane 0 of a wavefront has
+    // no lane below: it loads.
+    const bool first_lane = (threadIdx.x & 63) == 0;
+    uint32_t recLx = lane_below(rec.x), recLy = lane_below(rec.y), refsL = lane_below(refs);
+    int mL[4] = { (int)lane_below(m0.w), (int)lane_below(m1.w), (int)lane_below(m2.w), (int)lane_below(m3.w) };   // right column of the left one
+    if (first_lane) {
+        const uint4 r = gload4(ubase(recs, (uint32_t)li * 16u));
+        recLx = r.x; recLy = r.y; refsL = gload1(ubase(pd->ref_idx, (uint32_t)li * 4u));
+        mL[0] = (int)gload1(ubase(mvs, (uint32_t)li * 64u + 12u)); mL[1] = (int)gload1(ubase(mvs, (uint32_t)li * 64u + 28u));
+        mL[2] = (int)gload1(ubase(mvs, (uint32_t)li * 64u + 44u)); mL[3] = (int)gload1(ubase(mvs, (uint32_t)li * 64u + 60u));
+    }
     const int mv[16] = { (int)m0.x, (int)m0.y, (int)m0.z, (int)m0.w, (int)m1.x, (int)m1.y, (int)m1.z, (int)m1.w,
                          (int)m2.x, (int)m2.y, (int)m2.z, (int)m2.w, (int)m3.x, (int)m3.y, (int)m3.z, (int)m3.w };
     const int mvTop[4] = { (int)mT.x, (int)mT.y, (int)mT.z, (int)mT.w };
@@ -135,11 +161,17 @@ __device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, i
     uint32_t own0[4] = { 0 }, own1[4] = { 0 }, lft0[2] = { 0 }, lft1[2] = { 0 }, top0[2] = { 0 }, top1[2] = { 0 };
     if (b_pic) {
         const int *m1 = pd->mv_l1;
-        const uint4 a0 = gload4(m1 + mbi * 16), a1 = gload4(m1 + mbi * 16 + 4), a2 = gload4(m1 + mbi * 16 + 8), a3 = gload4(m1 + mbi * 16 + 12);
-        const uint4 aT = gload4(m1 + ti * 16 + 12);
-        const AS1 int *m1g = glob(m1);
-        mv1L[0] = m1g[li * 16 + 3]; mv1L[1] = m1g[li * 16 + 7]; mv1L[2] = m1g[li * 16 + 11]; mv1L[3] = m1g[li * 16 + 15];
-        refs1 = gload1(pd->ref_idx_l1 + mbi * 4); refs1L = gload1(pd->ref_idx_l1 + li * 4); refs1T = gload1(pd->ref_idx_l1 + ti * 4);
+        const uint4 a0 = gload4(ubase(m1, (uint32_t)mbi * 64u)), a1 = gload4(ubase(m1, (uint32_t)mbi * 64u + 16u)), a2 = gload4(ubase(m1, (uint32_t)mbi * 64u + 32u)), a3 = gload4(ubase(m1, (uint32_t)mbi * 64u + 48u));
+        const uint4 aT = gload4(ubase(m1, (uint32_t)ti * 64u + 48u));
+        refs1 = gload1(ubase(pd->ref_idx_l1, (uint32_t)mbi * 4u)); refs1T = gload1(ubase(pd->ref_idx_l1, (uint32_t)ti * 4u));
+        // (the left macroblock's list-1 data: as above - every lane of a B picture's wavefront is here, b_pic is wave-uniform)
+        mv1L[0] = (int)lane_below(a0.w); mv1L[1] = (int)lane_below(a1.w); mv1L[2] = (int)lane_below(a2.w); mv1L[3] = (int)lane_below(a3.w);
+        refs1L = lane_below(refs1);
+        if (first_lane) {
+            mv1L[0] = (int)gload1(ubase(m1, (uint32_t)li * 64u + 12u)); mv1L[1] = (int)gload1(ubase(m1, (uint32_t)li * 64u + 28u));
+            mv1L[2] = (int)gload1(ubase(m1, (uint32_t)li * 64u + 44u)); mv1L[3] = (int)gload1(ubase(m1, (uint32_t)li * 64u + 60u));
+            refs1L = gload1(ubase(pd->ref_idx_l1, (uint32_t)li * 4u));
+        }
         const int t[16] = { (int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w,
                             (int)a2.x, (int)a2.y, (int)a2.z, (int)a2.w, (int)a3.x, (int)a3.y, (int)a3.z, (int)a3.w };
 #pragma unroll
@@ -158,8 +190,8 @@ __device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, i
     }
 
     const int m_type = rec.x & 255, m_qp = (rec.x >> 8) & 255, m_edges = (rec.w >> 8) & 255;
-    const unsigned mmask = rec.y, lmask = recL.y, tmask = recT.y;
-    const bool m_intra = P264_MB_IS_INTRA(m_type), l_intra = P264_MB_IS_INTRA(recL.x & 255), t_intra = P264_MB_IS_INTRA(recT.x & 255);
+    const unsigned mmask = rec.y, lmask = recLy, tmask = recT.y;
+    const bool m_intra = P264_MB_IS_INTRA(m_type), l_intra = P264_MB_IS_INTRA(recLx & 255), t_intra = P264_MB_IS_INTRA(recT.x & 255);
     const bool fL = m_edges & P264_EDGE_LEFT, fT = m_edges & P264_EDGE_TOP;
     auto ref_of = [](uint32_t r4, int x, int y) { return (int)((r4 >> (8 * ((y >> 1) * 2 + (x >> 1)))) & 255); };
 
@@ -194,7 +226,7 @@ __device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, i
 
     // ---- averaged QPs per edge class (deblock_edge, core/frame.c:472-488,593-601) ----
     const int cqo = pd->chroma_qp_offset;
-    const int qpL = (int)((recL.x >> 8) & 255), qpT = (int)((recT.x >> 8) & 255);
+    const int qpL = (int)((recLx >> 8) & 255), qpT = (int)((recT.x >> 8) & 255);
     const int cq_own = chroma_qp(clip3i(m_qp + cqo, 0, 51));
     const uint32_t avg = (uint32_t)((m_qp + qpL + 1) >> 1) | (uint32_t)((m_qp + qpT + 1) >> 1) << 6
                        | (uint32_t)((cq_own + chroma_qp(clip3i(qpL + cqo, 0, 51)) + 1) >> 1) << 12
@@ -221,11 +253,11 @@ void k_deblock_bs(const PicDev *__restrict__ pics, Geom g, EdgeInfo *__restrict_
     int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
     if (mbi - mby * g.mb_w >= g.mb_w) mby++;
     const int mbx = mbi - mby * g.mb_w;
-    const uint4 rec = gload4((const uint4 *)pd->mb + mbi);
+    const uint4 rec = gload4(ubase(pd->mb, (uint32_t)mbi * 16u));
     const int *mvs = pd->mv;
-    const uint4 m0 = gload4(mvs + mbi * 16), m1 = gload4(mvs + mbi * 16 + 4), m2 = gload4(mvs + mbi * 16 + 8), m3 = gload4(mvs + mbi * 16 + 12);
-    const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
-    gstore4(info + (size_t)blockIdx.y * g.n_mb + mbi, edge_info_of<TWO_LISTS>(pd, g, mbi, mbx, mby, rec, m0, m1, m2, m3, refs, &pic_tab));
+    const uint4 m0 = gload4(ubase(mvs, (uint32_t)mbi * 64u)), m1 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 16u)), m2 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 32u)), m3 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 48u));
+    const uint32_t refs = gload1(ubase(pd->ref_idx, (uint32_t)mbi * 4u));
+    gstore4((uint8_t *)(info + (size_t)blockIdx.y * g.n_mb) + (uint32_t)mbi * 16u, edge_info_of<TWO_LISTS>(pd, g, mbi, mbx, mby, rec, m0, m1, m2, m3, refs, &pic_tab));
 }
 
 // alpha | tc0 of strengths 1..3 (one dword per index A) and beta (per index B): core/frame.c:262-291
@@ -394,22 +426,30 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
     edge_tables_init(tables);
     const Geom g = g_;
     const int RB = 1 << rb_log2, PW = 8 >> rb_log2;             // rows of a band, pictures per wavefront
-    const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
-    const int o = lane >> 3, j = lane & 7;
-    const int gr = o & (RB - 1), pi = o >> rb_log2;           // row inside the band, picture inside the wavefront
+    // (the wavefront number is a scalar: without readfirstlane the compiler takes the unit loop for divergent and keeps all of its
+    // book-keeping - unit, band, picture pointers - in vector registers)
+    const int wave = rfl((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
     const int n_bands = (g.mb_h + RB - 1) >> rb_log2;
     const int n_groups = (pics_per_wg + PW - 1) / PW;         // the workgroup's pictures in groups of PW: a work unit = (band, group)
     for (int k = threadIdx.x; k < MAX_PICS_PER_WG * MAX_BANDS; k += blockDim.x) (&progress[0][0])[k] = 0;
     __syncthreads();
-    OctLds &L = lds[wave][o];
-    const int seg2 = (j >> 1) * 2, cseg2 = (j & 3) * 2;       // 2 x the bS segment of this lane's luma / chroma lines
-    const int cp = j >> 2, cr = (j & 3) * 2;                  // chroma plane, first chroma line of this lane
-    uint8_t *tile8 = (uint8_t *)L.tile;
     bool ok = true;
 
     // units in band-major order: a wavefront takes unit u only after u - n_waves, and band b of a group only waits for band
     // b - 1 of the same group, which is an earlier unit - nobody waits for a unit that has not been started
     for (int unit = wave; unit < n_bands * n_groups; unit += n_waves) {
+        // Everything that follows from the lane number is derived again per unit (a few dozen instructions against ~100 000 of the
+        // unit): hoisted out of this loop, the lane constants that only the unit's set-up needs (64-bit offsets of the lane's rows,
+        // products with the strip sizes) stayed alive through the iteration loop - the kernel has no register to spare for them
+        // and spilled 17.
+        int lane_u = lane;
+        asm volatile("" : "+v"(lane_u));
+        const int o = lane_u >> 3, j = lane_u & 7;
+        const int gr = o & (RB - 1), pi = o >> rb_log2;           // row inside the band, picture inside the wavefront
+        OctLds &L = lds[wave][o];
+        const int seg2 = (j >> 1) * 2, cseg2 = (j & 3) * 2;       // 2 x the bS segment of this lane's luma / chroma lines
+        const int cp = j >> 2, cr = (j & 3) * 2;                  // chroma plane, first chroma line of this lane
+        uint8_t *tile8 = (uint8_t *)L.tile;
         const int band = unit / n_groups, piw = (unit - band * n_groups) * PW + pi;     // picture inside the workgroup
         const int pic = blockIdx.x * pics_per_wg + piw;
         const PicDev *pd = pics + min(pic, n_pics - 1);
@@ -436,6 +476,12 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         const uint32_t sT = j < 4 ? sY : sC;
         uint8_t *topP = j < 4 ? F + (ptrdiff_t)(rowc - 1) * MB_LUMA_BYTES + 192 + j * 16
                               : F + g.coff + (ptrdiff_t)(rowc - 1) * MB_CHROMA_BYTES + (6 + (j & 1)) * 16 + ((j >> 1) & 1) * 8;
+        // Addresses inside the iteration loop: macroblock x = t - 2 gr of the row.  The lane-constant part (- 2 gr strips) is folded
+        // into the bases here, in 64-bit arithmetic, so that the loop adds only t x strip - a scalar - to one pointer per array
+        // (as (uint32) x * strip the compiler cannot fold it and keeps one 64-bit constant per array alive: registers it does not have).
+        const ptrdiff_t lag = -(ptrdiff_t)(2 * gr);
+        uint8_t *ownY0 = ownY + lag * (ptrdiff_t)sY, *ownC0 = ownC + lag * (ptrdiff_t)sC, *topP0 = topP + lag * (ptrdiff_t)sT;
+        const EdgeInfo *pinfo0 = pinfo + (ptrdiff_t)row * g.mb_w + lag;
         int *my_progress = &progress[piw & (MAX_PICS_PER_WG - 1)][band];
         const bool publisher = have_row && gr == last && j == 0;
         OctLds &Lnext = lds[wave][min(o + 1, 7)];
@@ -458,18 +504,20 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 int spins = 0;
                 while (__ballot(need && __hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)) {
                     __builtin_amdgcn_s_sleep(DEBLOCK_WAIT_SLEEP);
-                    if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(status, 1); ok = false; break; }
+                    if (++spins > SPIN_LIMIT) { if (lane_u == 0) atomicOr(status, 1); ok = false; break; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             if (actn) {
-                if (j == 0) fE = gload4(pinfo + row * g.mb_w + x);
+                if (j == 0) fE = gload4(pinfo0 + t);
+                const uint8_t *tp = topP0 + (ptrdiff_t)t * (ptrdiff_t)sT;
                 if (from_above) {
-                    if (j < 4) fT = gload4(topP + x * sT);
-                    else { uint2 v2 = gload2(topP + x * sT); fT.x = v2.x; fT.y = v2.y; }
+                    if (j < 4) fT = gload4(tp);
+                    else { uint2 v2 = gload2(tp); fT.x = v2.x; fT.y = v2.y; }
                 }
-                fYa = gload4(ownY + x * sY); fYb = gload4(ownY + x * sY + 16);
-                { const uint2 ca2 = gload2(ownC + x * sC), cb2 = gload2(ownC + x * sC + 16); fC = make_uint4(ca2.x, ca2.y, cb2.x, cb2.y); }
+                const uint8_t *yp = ownY0 + (ptrdiff_t)t * (ptrdiff_t)sY, *cp2 = ownC0 + (ptrdiff_t)t * (ptrdiff_t)sC;
+                fYa = gload4(yp); fYb = gload4(yp + 16);
+                { const uint2 ca2 = gload2(cp2), cb2 = gload2(cp2 + 16); fC = make_uint4(ca2.x, ca2.y, cb2.x, cb2.y); }
             }
         };
 
@@ -505,8 +553,9 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
             // the rows above macroblock x-1 were finished by its horizontal pass in the previous iteration
             if (flush && top_exists) {
                 const uint32_t *pr = L.ring[(x - 1) & 3];
-                if (j < 4) gstore4(topP + (x - 1) * sT, *(const uint4 *)(pr + j * 4));
-                else gstore2(topP + (x - 1) * sT, *(const uint2 *)(pr + 16 + (j - 4) * 2));
+                uint8_t *tp = topP0 + (ptrdiff_t)(t - 1) * (ptrdiff_t)sT;
+                if (j < 4) gstore4(tp, *(const uint4 *)(pr + j * 4));
+                else gstore2(tp, *(const uint2 *)(pr + 16 + (j - 4) * 2));
             }
             EdgeRegs E;
             {
@@ -574,10 +623,11 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 uint2 ta = *(const uint2 *)tCa, tb = *(const uint2 *)tCb;
                 sa.w = ya[0]; sb.w = yb[0]; ta.y = ca[0]; tb.y = cb[0];
                 uint32_t *nr = Lnext.ring[(x - 1) & 3];
+                uint8_t *yp = ownY0 + (ptrdiff_t)(t - 1) * (ptrdiff_t)sY, *cp2 = ownC0 + (ptrdiff_t)(t - 1) * (ptrdiff_t)sC;
                 if (below_in_band && j >= 6) { *(uint4 *)(nr + (2 * j - 12) * 4) = sa; *(uint4 *)(nr + (2 * j - 11) * 4) = sb; }
-                else { gstore4(ownY + (x - 1) * sY, sa); gstore4(ownY + (x - 1) * sY + 16, sb); }
+                else { gstore4(yp, sa); gstore4(yp + 16, sb); }
                 if (below_in_band && (j & 3) == 3) { *(uint2 *)(nr + 16 + cp * 4) = ta; *(uint2 *)(nr + 16 + cp * 4 + 2) = tb; }
-                else { gstore2(ownC + (x - 1) * sC, ta); gstore2(ownC + (x - 1) * sC + 16, tb); }
+                else { gstore2(cp2, ta); gstore2(cp2 + 16, tb); }
             }
             wave_lds_fence();
             // ---------- rows of macroblock x -> tile ----------

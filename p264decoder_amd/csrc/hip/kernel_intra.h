@@ -538,11 +538,17 @@ __device__ __forceinline__ void intra_picture(IntraShared &sh, const PicDev *__r
             }
             // their samples are neighbours of what is still pending: stores drained, then the sets updated
             __syncthreads();
-            for (int w = threadIdx.x; w < n_win; w += blockDim.x) m_intra[w] &= ~m_walk[w];
+            // (thread number hidden from the optimiser: it keeps &m_intra[threadIdx.x] alive from the top of the kernel otherwise -
+            // one register too many for the 64 this build has)
+            int tid_a = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid_a));
+            for (int w = tid_a; w < n_win; w += blockDim.x) m_intra[w] &= ~m_walk[w];
             if (threadIdx.x < 2) free_n[threadIdx.x] = 0;
             __syncthreads();
         }
-        for (int w = threadIdx.x; w < n_win; w += blockDim.x) m_walk[w] = m_intra[w];       // the band walk's share
+        int tid_b = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid_b));
+        for (int w = tid_b; w < n_win; w += blockDim.x) m_walk[w] = m_intra[w];             // the band walk's share
         __syncthreads();
     }
     for (int band = wave; band < n_bands; band += n_waves) {
@@ -686,19 +692,26 @@ __global__ __launch_bounds__(INTRA_ROW_WAVES * 64, INTRA_SPARSE_WAVES_PER_EU)
 void k_intra_sparse(const PicDev *__restrict__ pics, Geom g, int *status, const uint8_t *__restrict__ is_intra, EdgeInfo *__restrict__ info, uint32_t inv_mbw, int bs_wgs)
 {
     const int roles = 2 + bs_wgs;
-    const int pic = (int)(blockIdx.x / (unsigned)roles), role = (int)blockIdx.x - pic * roles;
+    const int pic = rfl((int)(blockIdx.x / (unsigned)roles)), role = (int)blockIdx.x - pic * roles;      // (the division runs on the vector unit: back to a scalar)
     if (role >= 2) {
         const PicDev *pd = pics + pic;
         if (!pd->deblock) return;
-        for (int mbi = (role - 2) * (int)blockDim.x + (int)threadIdx.x; mbi < g.n_mb; mbi += bs_wgs * (int)blockDim.x) {
+        // (stores through a buffer descriptor of the picture's edge-info array: 32-bit offsets, no 64-bit address per lane)
+        const rsrc_t info_rs = make_rsrc(info + (size_t)pic * g.n_mb, (uint32_t)g.n_mb * (uint32_t)sizeof(EdgeInfo));
+        for (int mbi_it = (role - 2) * (int)blockDim.x + (int)threadIdx.x; mbi_it < g.n_mb; mbi_it += bs_wgs * (int)blockDim.x) {
+            // (every address below is a scalar base + this 32-bit index: hidden from the loop optimiser, which otherwise turns each
+            // into a 64-bit induction variable per lane - this build has 64 registers)
+            int mbi = mbi_it;
+            asm volatile("" : "+v"(mbi));
             int mby = (int)__umulhi((unsigned)mbi, inv_mbw);
             if (mbi - mby * g.mb_w >= g.mb_w) mby++;
             const int mbx = mbi - mby * g.mb_w;
-            const uint4 rec = gload4((const uint4 *)pd->mb + mbi);
+            const uint4 rec = gload4(ubase(pd->mb, (uint32_t)mbi * 16u));
             const int *mvs = pd->mv;
-            const uint4 m0 = gload4(mvs + mbi * 16), m1 = gload4(mvs + mbi * 16 + 4), m2 = gload4(mvs + mbi * 16 + 8), m3 = gload4(mvs + mbi * 16 + 12);
-            const uint32_t refs = gload1(pd->ref_idx + mbi * 4);
-            gstore4(info + (size_t)pic * g.n_mb + mbi, edge_info_of<false>(pd, g, mbi, mbx, mby, rec, m0, m1, m2, m3, refs, nullptr));
+            const uint4 m0 = gload4(ubase(mvs, (uint32_t)mbi * 64u)), m1 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 16u)), m2 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 32u)), m3 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 48u));
+            const uint32_t refs = gload1(ubase(pd->ref_idx, (uint32_t)mbi * 4u));
+            const uint4 ei = edge_info_of<false>(pd, g, mbi, mbx, mby, rec, m0, m1, m2, m3, refs, nullptr);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ ei.x, ei.y, ei.z, ei.w }, info_rs, (int)((uint32_t)mbi_it * 16u), 0, 0);
         }
         return;
     }

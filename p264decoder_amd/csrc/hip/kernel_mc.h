@@ -40,7 +40,12 @@
 // core/quant.c:66-99,138-159, core/dct.c:55-68,205-247 with their int16 stores (A-Q8).
 #pragma once
 #include "device_common.h"
-// timing experiments (scratch/r4_mcexp.sh): results are wrong unless all defaults hold
+// Timing experiments (scratch/r4_mcexp.sh, r4_mcparts.sh): pieces of the kernels compiled out to time the rest.  Results are
+// wrong unless all defaults hold, so the switches only exist in a build that says what it is: -DP264AMD_TIMING_BUILD, in
+// which p264hip_create refuses to run without P264AMD_TIMING_BUILD_OK=1 and p264hip_build_info() reports the flag.
+#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPM_LUMA_COPY) || defined(EXPM_NO_STORE) || defined(EXPM_NO_WINDOW) || defined(EXPM_ONLY) || defined(EXPM_RESID))
+#error "EXPM_* switches produce wrong pictures: they need -DP264AMD_TIMING_BUILD"
+#endif
 #ifndef EXPM_LUMA_COPY
 #define EXPM_LUMA_COPY 0
 #endif
@@ -433,7 +438,11 @@ __device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics,
         for (int k = tid; k < b_end; k += MC_SORT_THREADS) {                  // padding entries behind every segment
             const int l = k < b_yq ? ML_YM : k < b_cm ? ML_YQ : k < b_cq ? ML_CM : ML_CQ;
             const uint32_t per = (uint32_t)mc_chunk_items(l), end = po[k];
-            const uint32_t lo = l == ML_YM ? ml.off_list[L0 + ML_YM] : l == ML_YQ ? ml.off_list[L0 + ML_YQ] : l == ML_CM ? ml.off_list[L0 + ML_CM] : ml.off_list[L0 + ML_CQ];
+            // (selects on k itself: as a chain on l the compiler builds a four-entry table in scratch memory and indexes it)
+            uint32_t lo = ml.off_list[L0 + ML_CQ];
+            if (k < b_cq) lo = ml.off_list[L0 + ML_CM];
+            if (k < b_cm) lo = ml.off_list[L0 + ML_YQ];
+            if (k < b_yq) lo = ml.off_list[L0 + ML_YM];
             for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore4(out + lo + MC_ENTRY_WORDS * p, make_uint4(0xffffffffu, 0, 0, 0));
         }
     }
@@ -447,7 +456,8 @@ void k_mc_sort(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, G
 }
 // batches with B pictures
 #ifndef MC_SORT_B_WAVES_PER_EU
-#define MC_SORT_B_WAVES_PER_EU 8       // 64 registers (9 spilled): two workgroups per CU instead of one - the MC stage of a B launch 5.44 -> 5.37 ms (scratch/r4_sortb_occ.sh)
+#define MC_SORT_B_WAVES_PER_EU 4       // 78 registers, no scratch, one workgroup per CU (round 4 shipped 8: 64 registers of which 9 spilled, two workgroups
+                                       // per CU - the MC stage of a B launch 5.44 -> 5.37 ms, scratch/r4_sortb_occ.sh; given back for a binary without scratch)
 #endif
 __global__ __launch_bounds__(MC_SORT_THREADS, MC_SORT_B_WAVES_PER_EU)
 void k_mc_sort_b(const PicDev *__restrict__ pics, uint32_t *__restrict__ mc_all, Geom g, McLayout ml, uint32_t inv_mbw, uint8_t *__restrict__ is_intra)

@@ -32,6 +32,15 @@ extern "C" int p264hip_device_count(void)
     return n;
 }
 
+extern "C" int p264hip_build_info(void)
+{
+#ifdef P264AMD_TIMING_BUILD
+    return P264HIP_BUILD_TIMING;
+#else
+    return 0;
+#endif
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PicSlot {                       // one device-resident parsed picture
@@ -41,6 +50,8 @@ struct PicSlot {                       // one device-resident parsed picture
     size_t   bytes = 0;                // bytes in use
     p264hip_picture_t meta;            // scalar fields only; pointers unused
     bool     valid = false, reserved = false;   // reserved: p264hip_input_reserve handed the block out, commit is pending
+    bool     unchecked = false;                  // committed by a device producer: the record check (k_check_records) has been queued, its verdict not yet read
+    uint64_t last_use = 0;                       // epoch of the last work queued on the context's stream that reads or writes the block
 };
 
 #define BATCH_RING 4
@@ -65,6 +76,17 @@ __global__ void k_tile_convert(uint8_t *frame, uint8_t *planar, Geom g, int to_p
     if (to_planar) *q = *t; else *t = *q;
 }
 
+// The check p264hip_upload runs on the host, for pictures that arrive in device memory (p264hip_input_reserve / _commit): every
+// macroblock's packed blocks must lie inside coefs[] - the kernels index the coefficient stream without further checks
+// (include/p264hip.h).  One flag per input slot.
+__global__ void k_check_records(const p264hip_mb_t *mb, int n_mb, uint32_t n_coef_blocks, int *bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_mb) return;
+    const uint4 r = gload4(mb + i);
+    if (r.y && (uint64_t)r.z + (uint64_t)__popc(r.y & 0x3ffffffu) > (uint64_t)n_coef_blocks) atomicOr(bad, 1);
+}
+
 struct p264hip_ctx {
     int device = 0, n_cu = 256;
     hipStream_t stream = nullptr;
@@ -77,6 +99,8 @@ struct p264hip_ctx {
     hipEvent_t batch_free[BATCH_RING] = {};
     int batch_cap = 0, ring = 0;
     int *d_status = nullptr;
+    int *d_slot_bad = nullptr;             // [max_pictures]: k_check_records' verdict per input slot
+    uint64_t epoch = 0, done_epoch = 0;    // work queued on the stream / known to have completed (a slot is free for a new producer once its last_use is done)
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
     uint32_t *d_mc = nullptr;              // [batch_cap][ml.words], motion-compensation work lists (k_mc_sort -> k_mc, k_mc_second)
     uint8_t *d_is_intra = nullptr;         // [batch_cap][n_mb], 1 = intra macroblock (k_mc_sort -> k_intra's collect pass; P / B pictures)
@@ -86,6 +110,7 @@ struct p264hip_ctx {
     std::vector<uint8_t *> planar_pool;    // p264hip_frame_planar_device: planar I420 frames that stay on the device
     // tuning knobs, read from the environment ONCE (p264hip_create); 0 = built-in choice
     int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0, tune_bs_fused = -1;
+    p264hip_launch_info_t last = {};       // what the last p264hip_reconstruct launched
     hipEvent_t markers[P264HIP_MARKERS] = {};
     int next_marker = 0;
     bool timing = false;
@@ -106,6 +131,14 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     if (!out || mb_w < 1 || mb_w > 2047 || mb_h < 1 || mb_h > MAX_MB_ROWS ||    /* (11 bits of macroblock column in a work-list entry) */
         n_streams < 1 || slots < 1 || slots > P264HIP_MAX_REFS + 1 || max_pictures < 1)
         return fail(P264HIP_EINVAL, "p264hip_create: bad argument (mb %dx%d, streams %d, slots %d, pictures %d)", mb_w, mb_h, n_streams, slots, max_pictures);
+#ifdef P264AMD_TIMING_BUILD
+    {   // a build with pieces of the kernels compiled out: its pictures are wrong, it only runs for whoever asks for exactly that
+        const char *ok = getenv("P264AMD_TIMING_BUILD_OK");
+        if (!ok || strcmp(ok, "1") != 0)
+            return fail(P264HIP_EINVAL, "this library is a timing build (-DP264AMD_TIMING_BUILD: kernels with pieces compiled out, wrong pictures); "
+                                        "set P264AMD_TIMING_BUILD_OK=1 to run it anyway");
+    }
+#endif
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(P264HIP_ENODEV, "no HIP device available: the MI355X reconstruction path cannot run (there is no CPU fallback)");
@@ -129,6 +162,7 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     c->stream_seen.assign((size_t)n_streams, 0);
     c->pics.resize((size_t)max_pictures);
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
+    c->last.compute_units = c->n_cu;                        // (p264hip_last_launch before the first batch: the device's size)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (const char *env = getenv("P264AMD_MC_WGS_PER_PIC")) c->tune_mc_wgs = atoi(env);
     if (const char *env = getenv("P264AMD_INTRA_WAVES")) c->tune_intra_waves = atoi(env);
@@ -140,6 +174,8 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     if (e == hipSuccess) e = hipMemsetAsync(c->frames, 0, c->frame_bytes * (size_t)n_streams * slots, c->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_slot_bad, sizeof(int) * (size_t)max_pictures);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_slot_bad, 0, sizeof(int) * (size_t)max_pictures, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         int rc = fail(e == hipErrorOutOfMemory ? P264HIP_ENOMEM : P264HIP_EHIP, "p264hip_create: %s", hipGetErrorString(e));
@@ -171,6 +207,7 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     for (uint8_t *p : c->planar_pool) if (p) (void)hipFree(p);
     for (auto &m : c->markers) if (m) (void)hipEventDestroy(m);
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_slot_bad) (void)hipFree(c->d_slot_bad);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -250,7 +287,7 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
     if (p->n_coef_blocks)
         HIPCHK(hipMemcpyAsync(s.dev + L.off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
     slot_meta(s, p);
-    s.valid = true;
+    s.valid = true; s.unchecked = false; s.last_use = ++c->epoch;
     return 0;
 }
 
@@ -267,7 +304,7 @@ extern "C" int p264hip_upload_packed(p264hip_ctx *c, int slot, const p264hip_pic
     if ((rc = slot_prepare(c, s, L))) return rc;
     HIPCHK(hipMemcpyAsync(s.dev, packed, L.bytes, hipMemcpyHostToDevice, c->stream));
     slot_meta(s, desc);
-    s.valid = true;
+    s.valid = true; s.unchecked = false; s.last_use = ++c->epoch;
     return P264HIP_OK;
 }
 
@@ -281,8 +318,10 @@ extern "C" int p264hip_input_reserve(p264hip_ctx *c, int slot, const p264hip_pic
     if (p264hip_input_layout(desc, &L)) return fail(P264HIP_EINVAL, "picture layout");
     PicSlot &s = c->pics[(size_t)slot];
     s.valid = false;
-    // (whatever still reads the slot's previous picture on the context's stream must be through before somebody else writes it)
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // Whatever still reads the slot's previous picture on the context's stream must be through before somebody else writes
+    // it.  One wait covers everything queued so far: the first reserve of a round waits (if the last batch is still running),
+    // the others find their slots' work already known to be done - not one hipStreamSynchronize per picture.
+    if (s.last_use > c->done_epoch) { const uint64_t upto = c->epoch; HIPCHK(hipStreamSynchronize(c->stream)); c->done_epoch = upto; }
     if ((rc = slot_prepare(c, s, L))) return rc;
     slot_meta(s, desc);
     s.reserved = true;
@@ -294,7 +333,15 @@ extern "C" int p264hip_input_commit(p264hip_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot >= c->max_pictures || !c->pics[(size_t)slot].reserved) return fail(P264HIP_EINVAL, "p264hip_input_commit: slot %d is not reserved", slot);
     PicSlot &s = c->pics[(size_t)slot];
-    s.reserved = false; s.valid = true;
+    HIPCHK(hipSetDevice(c->device));
+    // The producer wrote the arrays (it says they are complete on the device: include/p264hip.h); their records get the check
+    // p264hip_upload runs on the host, on the device - a block from a peer that packed it wrongly must become an error, not
+    // an out-of-bounds read.  The verdict is read once per batch, by p264hip_reconstruct.
+    HIPCHK(hipMemsetAsync(c->d_slot_bad + slot, 0, sizeof(int), c->stream));
+    const int n_mb = c->g.n_mb;
+    hipLaunchKernelGGL(k_check_records, dim3((n_mb + 255) / 256), dim3(256), 0, c->stream, (const p264hip_mb_t *)s.dev, n_mb, s.meta.n_coef_blocks, c->d_slot_bad + slot);
+    HIPCHK(hipGetLastError());
+    s.reserved = false; s.valid = true; s.unchecked = true; s.last_use = ++c->epoch;
     return P264HIP_OK;
 }
 
@@ -389,7 +436,7 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
     }
     HIPCHK(hipMemcpyAsync(d.dev, s.dev, need, hipMemcpyDeviceToDevice, c->stream));
     d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef; d.off_mv_l1 = s.off_mv_l1; d.off_ref_l1 = s.off_ref_l1; d.off_weights = s.off_weights; d.bytes = s.bytes;
-    d.meta = s.meta; d.valid = true;
+    d.meta = s.meta; d.valid = true; d.unchecked = s.unchecked; d.last_use = s.last_use = ++c->epoch;
     return P264HIP_OK;
 }
 
@@ -428,6 +475,23 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         HIPCHK(hipMalloc((void **)&c->d_edge, (size_t)n * c->g.n_mb * sizeof(EdgeInfo)));
         HIPCHK(hipMalloc((void **)&c->d_mc, (size_t)n * c->ml.words * sizeof(uint32_t)));
         c->batch_cap = n;
+    }
+    {   // pictures that came through p264hip_input_commit: the verdicts of their record checks, one wait for the whole batch
+        bool any_unchecked = false;
+        for (int i = 0; i < n; i++) { const int id = pic_ids[i]; if (id >= 0 && id < c->max_pictures && c->pics[(size_t)id].unchecked) any_unchecked = true; }
+        if (any_unchecked) {
+            std::vector<int> bad((size_t)c->max_pictures);
+            const uint64_t upto = c->epoch;
+            HIPCHK(hipMemcpyAsync(bad.data(), c->d_slot_bad, sizeof(int) * bad.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->done_epoch = upto;
+            for (int i = 0; i < n; i++) {
+                const int id = pic_ids[i];
+                if (id < 0 || id >= c->max_pictures || !c->pics[(size_t)id].unchecked) continue;
+                if (bad[(size_t)id]) { c->pics[(size_t)id].valid = false; c->pics[(size_t)id].unchecked = false; return fail(P264HIP_EINVAL, "picture slot %d: a macroblock's coefficient blocks lie outside coefs[] (the block a device producer committed is inconsistent)", id); }
+                c->pics[(size_t)id].unchecked = false;
+            }
+        }
     }
     const int r = c->ring; c->ring = (c->ring + 1) % BATCH_RING;
     HIPCHK(hipEventSynchronize(c->batch_free[r]));            // the copy that last used this staging buffer is done
@@ -478,6 +542,9 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     const Geom g = c->g;
     const uint32_t inv_mbw = (uint32_t)(((1ull << 32) - 1) / (unsigned)g.mb_w);
     bool bs_fused = false;
+    p264hip_launch_info_t &li = c->last;
+    memset(&li, 0, sizeof li);
+    li.pictures = n; li.compute_units = c->n_cu;
     if (any_p) {
         // motion compensation + residual of all inter macroblocks: device-side counting sort of the work items by what the
         // interpolation has to do, then the luma and chroma kernels over the sorted lists (kernel_mc.h), side by side
@@ -496,6 +563,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         if (wgs > max_wgs) wgs = max_wgs;
         if (c->tune_mc_wgs >= 4 && c->tune_mc_wgs <= max_wgs) wgs = c->tune_mc_wgs;
         if (wgs < 4) wgs = 4;
+        li.mc_wgs_per_picture = wgs;
         hipLaunchKernelGGL(k_mc, dim3(((size_t)wgs * n + 7) / 8 * 8), dim3(256), 0, c->stream, (const PicDev *)c->d_batch[r], (const uint32_t *)c->d_mc, g, ml,
                            wgs, wgs * n, (uint32_t)(((1ull << 32) - 1) / (unsigned)wgs));
         // B pictures: the blocks that predict from both lists get their second prediction (and their residual) in a second pass
@@ -509,6 +577,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // four pictures share a CU (measured +19 % at 512 and +9 % at 1024 pictures; 2048: 2 / 4 / 8 / 16 -> 1.02 / 0.87 / 0.90 / 1.10 ms)
         int intra_waves = n > 2 * c->n_cu ? INTRA_ROW_WAVES / 4 : n > c->n_cu ? INTRA_ROW_WAVES / 2 : INTRA_ROW_WAVES;
         if (c->tune_intra_waves >= 1 && c->tune_intra_waves <= INTRA_ROW_WAVES) intra_waves = c->tune_intra_waves;
+        li.intra_waves = intra_waves;
         // luma and chroma of a picture are independent chains: as two workgroups they run side by side
         if (any_i) hipLaunchKernelGGL(k_intra, dim3(n, 2), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status, (const uint8_t *)c->d_is_intra);
         else {
@@ -516,6 +585,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
             // launch, kernel_intra.h)
             bs_fused = !any_b && c->tune_bs_fused != 0;
             const int bs_wgs = bs_fused ? (c->tune_bs_fused > 0 ? c->tune_bs_fused : INTRA_BS_WGS) : 0;
+            li.edge_info_fused = bs_wgs;
             hipLaunchKernelGGL(k_intra_sparse, dim3((unsigned)n * (2 + bs_wgs)), dim3(intra_waves * 64), (size_t)intra_waves * sizeof(IntraLds), c->stream, c->d_batch[r], g, c->d_status,
                                (const uint8_t *)c->d_is_intra, c->d_edge, inv_mbw, bs_wgs);
         }
@@ -541,10 +611,20 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         const int n_units = n_bands * ((per_wg + (8 >> rb_log2) - 1) / (8 >> rb_log2));
         int waves = n_units < ROW_WAVES ? n_units : ROW_WAVES;
         if (c->tune_db_waves >= 1 && c->tune_db_waves < waves) waves = c->tune_db_waves;
+        li.deblock_pics_per_wg = per_wg; li.deblock_rb_log2 = rb_log2; li.deblock_waves = waves; li.deblock_wgs = (n + per_wg - 1) / per_wg;
         hipLaunchKernelGGL(k_deblock, dim3((n + per_wg - 1) / per_wg), dim3(waves * 64), 0, c->stream, c->d_batch[r], g,
                            (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2, per_wg);
     }
     HIPCHK(hipGetLastError());
+    ++c->epoch;
+    for (int i = 0; i < n; i++) c->pics[(size_t)pic_ids[i]].last_use = c->epoch;
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_last_launch(p264hip_ctx *c, p264hip_launch_info_t *out)
+{
+    if (!c || !out) return fail(P264HIP_EINVAL, "p264hip_last_launch: null argument");
+    *out = c->last;
     return P264HIP_OK;
 }
 
@@ -591,7 +671,7 @@ extern "C" int p264hip_sync(p264hip_ctx *c)
 #endif
     if (!c) return fail(P264HIP_EINVAL, "null context");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { const uint64_t upto = c->epoch; HIPCHK(hipStreamSynchronize(c->stream)); c->done_epoch = upto; }
     drain_stamps(c);
     int st = 0;
     HIPCHK(hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));

@@ -210,6 +210,13 @@ class HipReconstructor:
         return {names[i]: (ms[i], cnt[i]) for i in range(N.NKERNELS)}
 
 
+    def last_launch(self):
+        """What the last reconstruct call launched (p264hip_launch_info_t as a dict)."""
+        li = N.LaunchInfo()
+        self._chk(self.lib.p264hip_last_launch(self.h, C.byref(li)), "p264hip_last_launch")
+        return {n: int(getattr(li, n)) for n, _ in N.LaunchInfo._fields_ if n != "reserved"}
+
+
 def device_count(lib=None):
     lib = lib or N.load()
     return lib.p264hip_device_count() if hasattr(lib, "p264hip_device_count") else 0

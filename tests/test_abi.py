@@ -38,6 +38,12 @@ def test_library_exports_every_declared_symbol(lib):
     assert not missing, "declared in include/*.h but not exported: %s" % missing
 
 
+def test_library_is_not_a_timing_build(lib):
+    """-DP264AMD_TIMING_BUILD unlocks the EXPM_* / EXPD_* switches (kernels with pieces compiled out, wrong pictures): the
+    library under test, and the one that travels to the GPU box, must not be one."""
+    assert lib.p264hip_build_info() & N.BUILD_TIMING == 0
+
+
 def test_struct_layouts_match_the_headers(lib):
     src = r'''
 #include <stdio.h>
@@ -50,6 +56,7 @@ int main(void) {
   printf("param %zu %zu %zu %zu\n", sizeof(p264_param_t), offsetof(p264_param_t, analyse), offsetof(p264_param_t, rc), offsetof(p264_param_t, b_repeat_headers));
   printf("picture %zu %zu\n", sizeof(p264_picture_t), offsetof(p264_picture_t, img));
   printf("nal %zu %zu\n", sizeof(p264_nal_t), offsetof(p264_nal_t, p_payload));
+  printf("launch %zu %zu\n", sizeof(p264hip_launch_info_t), offsetof(p264hip_launch_info_t, deblock_wgs));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as td:
@@ -63,6 +70,7 @@ int main(void) {
     assert out["param"] == [C.sizeof(D.Param), D.Param.analyse.offset, D.Param.rc.offset, D.Param.b_repeat_headers.offset]
     assert out["picture"] == [C.sizeof(D.PictureOut), D.PictureOut.img.offset]
     assert out["nal"] == [C.sizeof(D.Nal), D.Nal.p_payload.offset]
+    assert out["launch"] == [C.sizeof(N.LaunchInfo), N.LaunchInfo.deblock_wgs.offset]
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/p264.h"), reason="reference tree not present (GPU box)")

@@ -116,6 +116,42 @@ def test_packed_upload_and_reserved_slots_match_the_plain_upload(lib):
     hip.close()
 
 
+def test_a_committed_block_with_bad_records_is_an_error_not_a_fault(lib):
+    """The device road does not trust its producer: a block written into a reserved slot whose records point outside its
+    coefficient stream (a peer that packed it wrongly) must fail the batch with an error - p264hip_upload's host check, run by
+    a kernel at commit - and the context must go on working."""
+    import ctypes as C
+    import numpy as np
+    from p264decoder_amd import HipReconstructor, Parser
+    from p264decoder_amd import _native as N
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("cif_ip"))[:2]
+    hip = HipReconstructor(pics[0].mb_w, pics[0].mb_h, n_streams=2, slots=parser.slots, max_pictures=2, lib=lib)
+    p = pics[0]
+    blk = HipReconstructor.pack(p, lib).copy()
+    # record 5: coefficient blocks far beyond the stream (coef_index is the third dword of the 16-byte record)
+    words = blk[:p.mb_w * p.mb_h * 16].view(np.uint32).reshape(-1, 4)
+    coded = int(np.flatnonzero(words[:, 1] != 0)[0])
+    words[coded, 2] = 0x7fffff00
+    dev, n = hip.input_reserve(1, p)
+    assert lib.p264hip_copy_to_device(dev, blk.ctypes.data, n) == 0
+    hip.input_commit(1)
+    with pytest.raises(Exception, match="outside coefs"):
+        hip.reconstruct([1], [1])
+    hip.sync()
+    # the same slot, the intact block: decodes like the plain upload
+    good = HipReconstructor.pack(p, lib)
+    dev, n = hip.input_reserve(1, p)
+    assert lib.p264hip_copy_to_device(dev, good.ctypes.data, n) == 0
+    hip.input_commit(1)
+    hip.upload(0, [p])
+    hip.reconstruct([0, 1], [0, 1])
+    hip.sync()
+    for a, b in zip(hip.read_frame(0, p.desc.dst_slot), hip.read_frame(1, p.desc.dst_slot)):
+        assert np.array_equal(a, b)
+    hip.close()
+
+
 def test_rccl_transport_self_exchange(lib):
     """The RCCL transport on one GPU: a communicator of one rank, a grouped ncclSend / ncclRecv to itself through the
     transport's staging buffers (host -> device -> RCCL -> device -> host).  The multi-GPU exchange uses exactly these calls."""

@@ -94,10 +94,11 @@ def test_2160p_batch_of_streams(lib):
 
 
 def test_bench_shape_batch_against_reference_hashes(lib):
-    """The batch bench.py times: more pictures than 2 x compute units in ONE reconstruct call (that is what selects the
-    small-band workgroup shapes of the row-wavefront kernels: 4 intra wavefronts, 4 pictures per deblocking workgroup),
-    1080p, every stream a private clone of the config-3 all-P pictures.  Every stream's pictures must hash to what the
-    real reference decoder produced for that stream (tests/golden/synth_cfg3_1080p_allp.sha256)."""
+    """More pictures than 2 x compute units in ONE reconstruct call (that selects the small-band workgroup shapes of the
+    row-wavefront kernels: 4 intra wavefronts, bands of 4 rows and 3 pictures per deblocking workgroup on a 256-CU device, the
+    last workgroup partly empty), 1080p, every stream a private clone of the config-3 all-P pictures.  Every stream's pictures
+    must hash to what the real reference decoder produced for that stream (tests/golden/synth_cfg3_1080p_allp.sha256).  The
+    batch bench.py itself times is test_the_bench_s_own_batch_against_reference_hashes below."""
     _, hashes = synth_cases.golden("cfg3_1080p_allp")
     parser = Parser(quiet=True, lib=lib)
     pics = parser.parse_stream(synth_cases.stream_bytes("cfg3_1080p_allp"), limit=4)      # IDR + 3 P pictures
@@ -110,6 +111,36 @@ def test_bench_shape_batch_against_reference_hashes(lib):
             hip.clone_picture(s, 0)
         hip.reconstruct(list(range(S)), list(range(S)))
         hip.sync()
+        for s in range(S):
+            assert frame_sha256(*hip.read_frame(s, p.desc.dst_slot)) == hashes[i], "picture %d stream %d differs from the reference decoder" % (i, s)
+    hip.close()
+
+
+def test_the_bench_s_own_batch_against_reference_hashes(lib):
+    """The shape bench.py's default run times, under a parity test: 8 x compute units streams (2048 on an MI355X) of the 1080p
+    all-P stream in ONE p264hip_reconstruct per picture - IDR + 3 P pictures, every stream a private clone, EVERY stream of
+    every picture hashed against what the real reference decoder produced (decoder/decoder.c:635-661 is what a picture goes
+    through).  The launch must have selected the bench's shapes: 8 pictures per deblocking workgroup in bands of four rows, 48
+    motion-compensation workgroups per picture, 4 intra wavefronts, the edge-info pass inside the intra launch of P batches."""
+    _, hashes = synth_cases.golden("cfg3_1080p_allp")
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("cfg3_1080p_allp"), limit=4)      # IDR + 3 P pictures
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    probe = HipReconstructor(mb_w, mb_h, n_streams=1, slots=parser.slots, max_pictures=1, lib=lib)
+    n_cu = probe.last_launch()["compute_units"]
+    probe.close()
+    S = 8 * n_cu
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=parser.slots, max_pictures=S, lib=lib)
+    for i, p in enumerate(pics):
+        hip.upload(0, [p])
+        for s in range(1, S):
+            hip.clone_picture(s, 0)
+        hip.reconstruct(list(range(S)), list(range(S)))
+        hip.sync()
+        li = hip.last_launch()
+        assert li["pictures"] == S and li["deblock_pics_per_wg"] == 8 and li["deblock_rb_log2"] == 2 and li["deblock_wgs"] == n_cu and li["intra_waves"] == 4, li
+        if p.desc.slice_type == 0:                     # P picture: the inter launch and the fused edge-info pass
+            assert li["mc_wgs_per_picture"] == 48 and li["edge_info_fused"] == 1, li
         for s in range(S):
             assert frame_sha256(*hip.read_frame(s, p.desc.dst_slot)) == hashes[i], "picture %d stream %d differs from the reference decoder" % (i, s)
     hip.close()

@@ -26,6 +26,8 @@ int p264hip_upload_packed(p264hip_ctx *c, int s, const p264hip_picture_t *d, con
 int p264hip_input_reserve(p264hip_ctx *c, int s, const p264hip_picture_t *d, void **dev, size_t *n) { (void)c;(void)s;(void)d;(void)dev;(void)n; return -1; }
 int p264hip_input_commit(p264hip_ctx *c, int s) { (void)c;(void)s; return -1; }
 int p264hip_frame_planar_device(p264hip_ctx *c, int s, int sl, int i, void **dev, size_t *n) { (void)c;(void)s;(void)sl;(void)i;(void)dev;(void)n; return -1; }
+int p264hip_last_launch(p264hip_ctx *c, p264hip_launch_info_t *o) { (void)c;(void)o; return -1; }
+int p264hip_build_info(void) { return 0; }
 int p264hip_copy_to_device(void *d, const void *h, size_t n) { (void)d;(void)h;(void)n; return -1; }
 int p264hip_copy_from_device(void *h, const void *d, size_t n) { (void)h;(void)d;(void)n; return -1; }
 /* the RCCL transport lives with the HIP code: not part of the host-only build */

@@ -40,6 +40,7 @@
 // core/quant.c:66-99,138-159, core/dct.c:55-68,205-247 with their int16 stores (A-Q8).
 #pragma once
 #include "device_common.h"
+#include <type_traits>
 // Timing experiments (scratch/r4_mcexp.sh, r4_mcparts.sh): pieces of the kernels compiled out to time the rest.  Results are
 // wrong unless all defaults hold, so the switches only exist in a build that says what it is: -DP264AMD_TIMING_BUILD, in
 // which p264hip_create refuses to run without P264AMD_TIMING_BUILD_OK=1 and p264hip_build_info() reports the flag.
@@ -567,11 +568,22 @@ template <bool MB> struct YItem {
 // macroblock window reaches into its third strip only when it starts in the last dword of a strip: `third` says so.
 // CLAMP: coordinates clamped to the picture = the reference's replicated borders (core/frame.c:183-222, A-Q9): a strip
 // that lies outside the picture becomes the replicated first (last) sample of the row.
-template <bool MB, int R0S, int NRS, bool CLAMP>
+// Every piece is requested by the SAME straight-line sequence of loads, all in flight together, one wait: a piece a lane does
+// not need (the third strip of an item that does not reach into it) is requested at an offset beyond the buffer, which the
+// bounds check of the descriptor answers with zeros without going to memory.  (Written as `if (needed) load`, the compiler
+// wrapped every such load into a branch of its own with a wait for the data inside it: up to three memory round trips one
+// after the other per chunk instead of one.)  NS = strips the class can reach into (2: copy / vertical, which read no columns
+// left of the blocks).
+// "all of these loads have been issued, and their data is used HERE": keeps the compiler from sinking a load into the conditional
+// block that stores its data (behind the waits and the stores of the loads in front of it)
+__device__ __forceinline__ void loads_land(u32x4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+#define MC_OOB 0xffffff00u             // raw buffer offset beyond any frame store (< 4 GiB, p264hip_create): reads return 0
+template <bool MB, int R0S, int NRS, bool CLAMP, int NS>
 __device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t roff, const Geom &g, int xs, int wy, int li, bool third)
 {
     typedef YItem<MB> I;
-    constexpr int NP = I::STRIPS * NRS, NJ = (NP + I::LANES - 1) / I::LANES;
+    static_assert(NS == 2 || (MB && NS == 3), "strips");
+    constexpr int NP = NS * NRS, NJ = (NP + I::LANES - 1) / I::LANES;
     const int sA = xs >> 4, dx4 = xs & 12;                  // first strip, byte offset of the first needed dword inside it
     u32x4 v[NJ];
     int dst[NJ];
@@ -580,17 +592,26 @@ __device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t rof
     for (int j = 0; j < NJ; j++) {
         const int p = min(li + I::LANES * j, NP - 1), s = p >= 2 * NRS ? 2 : p >= NRS ? 1 : 0, row = R0S + p - s * NRS;
         dst[j] = row * I::PITCH + s * 16 - dx4;
-        on[j] = !MB || s < 2 || third;
-        v[j] = u32x4{ 0, 0, 0, 0 };
-        if (on[j]) {
-            if (!CLAMP) v[j] = wload4(rs, roff + strip_mul(sA + s, g.ystrip) + (uint32_t)((wy + row) * 16));
-            else {
-                const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
-                u32x4 t = wload4(rs, roff + strip_mul(sc, g.ystrip) + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16));
-                if (st < 0) { const uint32_t e = perm(t.x, t.x, 0x00000000u); t.x = t.y = t.z = t.w = e; }
-                if (st >= g.mb_w) { const uint32_t e = perm(t.w, t.w, 0x03030303u); t.x = t.y = t.z = t.w = e; }
-                v[j] = t;
-            }
+        on[j] = NS == 2 || s < 2 || third;
+        if (!CLAMP) {
+            const uint32_t off = roff + strip_mul(sA + s, g.ystrip) + (uint32_t)((wy + row) * 16);
+            v[j] = wload4(rs, on[j] ? off : MC_OOB);
+        } else {
+            const int st = sA + s, sc = clip3i(st, 0, g.mb_w - 1);
+            const uint32_t off = roff + strip_mul(sc, g.ystrip) + (uint32_t)(clip3i(wy + row, 0, g.h - 1) * 16);
+            v[j] = wload4(rs, on[j] ? off : MC_OOB);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) loads_land(v[j]);
+    if (CLAMP) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int p = min(li + I::LANES * j, NP - 1), s = p >= 2 * NRS ? 2 : p >= NRS ? 1 : 0, st = sA + s;
+            u32x4 t = v[j];
+            if (st < 0) { const uint32_t e = perm(t.x, t.x, 0x00000000u); t.x = t.y = t.z = t.w = e; }
+            if (st >= g.mb_w) { const uint32_t e = perm(t.w, t.w, 0x03030303u); t.x = t.y = t.z = t.w = e; }
+            v[j] = t;
         }
     }
 #pragma unroll
@@ -885,7 +906,7 @@ __device__ __forceinline__ int xcd_logical_block()
 // the lane is one 4x4 block
 // ------------------------------------------------------------------------------------------
 template <bool MB, bool PB>
-__device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
+__device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *ref_tab, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
                                              const McLayout &ml, int sub, int role_wgs)
 {
     typedef YItem<MB> I;
@@ -900,15 +921,16 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     const int lane = threadIdx.x & 63, li = lane & (I::LANES - 1), it = lane / I::LANES;
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
-    const int n_ref = pd->n_ref;
-    const bool list_tables = n_ref > 1 || pd->slice_type == P264_SLICE_B;       // (scalar) else: the one reference of list 0
     uint32_t key_w = cls_w[chunk >> 2];
     uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
   for (;;) {
     const int next = chunk + stride;
     const bool more = next < n_chunks;
-    uint32_t key_w_next = 0; uint4 e_next = make_uint4(0, 0, 0, 0);
-    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload4(list + (size_t)(next * I::PER_WAVE + it) * MC_ENTRY_WORDS); }
+    // (requested without a condition - past the list's end the last chunk once more: under `if (more)` the compiler waits for the
+    // data inside the branch, one memory round trip per chunk that is no prefetch at all)
+    const int nx = min(next, n_chunks - 1);
+    const uint32_t key_w_next = cls_w[nx >> 2];
+    const uint4 e_next = gload4(list + (size_t)(nx * I::PER_WAVE + it) * MC_ENTRY_WORDS);
     const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);                                 // scalar: the chunk's key bits
     const int pc = key & 7;
     wave_lds_fence();                                      // the previous chunk's image has been read
@@ -920,8 +942,10 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     // chunks with residual: QP, coded-block mask and place in the coefficient stream come with the entry
     int mvp = (int)e.y;
     if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + (mby * g.mb_w + mbx) * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
-    uint32_t roff = pd->ref_off[0];
-    if (list_tables) roff = glob((e.x & MCE_LIST1) ? pd->ref_off_l1 : pd->ref_off)[e.x >> 28];       // (wave-uniform branch)
+    // the reference frame of the entry's (list, index): out of the workgroup's table in LDS (mc_roles) - as a load from the
+    // picture's tables it was a memory round trip in front of every chunk's window requests (and the wait for it also waited
+    // for the next chunk's entries, requested just before: no prefetch)
+    const uint32_t roff = ref_tab[(e.x >> 28) | ((e.x >> 19) & 16u)];
     const uint32_t cidx = PB ? (e.w & ((1u << MCE_W_SHIFT) - 1u)) : e.w;            // place in the coefficient stream
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
     const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
@@ -934,9 +958,10 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
     // front of the windows: it has arrived when they have)
     const uint32_t dsto = pd->dst_off + mb_luma_off(g, mbx, mby) + (MB ? (uint32_t)((by * 4 + bx) * 16) : (uint32_t)((by * 4 + ((bx & 1) ? 2 : 0)) * 16 + (bx >> 1) * 8));
     u32x4 prev = { 0, 0, 0, 0 };
-    if (PB && valid) {
-        if (MB) prev = bload4(rs, dsto);
-        else { const u32x2 a = bload2(rs, dsto), b = bload2(rs, dsto + 16); prev = u32x4{ a.x, a.y, b.x, b.y }; }
+    if (PB) {                                              // (compile time; padding lanes read beyond the buffer: zeros, no branch)
+        const uint32_t po = valid ? dsto : MC_OOB;
+        if (MB) prev = bload4(rs, po);
+        else { const u32x2 a = bload2(rs, po), b = bload2(rs, po + 16); prev = u32x4{ a.x, a.y, b.x, b.y }; }
     }
     // ---- prediction ----
     uint32_t out[4];
@@ -951,8 +976,16 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const PicDev *__re
         // (macroblock items) six dwords from the first one: the third strip is needed when they start in a strip's last dword
         const bool third = MB && (xs & 12) == 12 && !(pc == PC_COPY || pc == PC_V);
         constexpr int RM = MB ? 16 : 8;
-        if (!(key & MCY_CLAMP)) { if (rows_mid) stage_luma<MB, 2, RM, false>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 0, I::ROWS, false>(img, rs, roff, g, xs, wy, li, third); }
-        else                    { if (rows_mid) stage_luma<MB, 2, RM, true>(img, rs, roff, g, xs, wy, li, third);  else stage_luma<MB, 0, I::ROWS, true>(img, rs, roff, g, xs, wy, li, third); }
+        // (scalar branches: one straight-line staging sequence per shape - rows, strips, clamped or not)
+        const bool two = !MB || pc == PC_COPY || pc == PC_V;     // the class reads no columns left of the blocks: two strips at most
+        constexpr int S3 = MB ? 3 : 2;
+        if (!(key & MCY_CLAMP)) {
+            if (rows_mid) { if (two) stage_luma<MB, 2, RM, false, 2>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 2, RM, false, S3>(img, rs, roff, g, xs, wy, li, third); }
+            else          { if (two) stage_luma<MB, 0, I::ROWS, false, 2>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 0, I::ROWS, false, S3>(img, rs, roff, g, xs, wy, li, third); }
+        } else {
+            if (rows_mid) { if (two) stage_luma<MB, 2, RM, true, 2>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 2, RM, true, S3>(img, rs, roff, g, xs, wy, li, third); }
+            else          { if (two) stage_luma<MB, 0, I::ROWS, true, 2>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 0, I::ROWS, true, S3>(img, rs, roff, g, xs, wy, li, third); }
+        }
         if ((key & MCY_RESID) && coded) {
             const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
             la = gload4(cf); lb = gload4(cf + 8);
@@ -1108,11 +1141,15 @@ template <bool MB> struct CItem {
 };
 // one 16-byte row piece of a chroma strip, coordinates clamped to the picture if CLAMP (a strip outside becomes the
 // replicated first / last sample of each plane's 8 bytes)
-template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece(rsrc_t rs, uint32_t roff, const Geom &g, int strip, int y)
+template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece_load(rsrc_t rs, uint32_t roff, const Geom &g, int strip, int y, bool need)
 {
-    if (!CLAMP) return wload4(rs, roff + g.coff + strip_mul(strip, g.cstrip) + (uint32_t)(y * 16));
+    if (!CLAMP) return wload4(rs, need ? roff + g.coff + strip_mul(strip, g.cstrip) + (uint32_t)(y * 16) : MC_OOB);
     const int sc = clip3i(strip, 0, g.mb_w - 1);             // (a chroma strip is 8 samples wide: one per macroblock column)
-    u32x4 t = wload4(rs, roff + g.coff + strip_mul(sc, g.cstrip) + (uint32_t)(clip3i(y, 0, g.ch - 1) * 16));
+    return wload4(rs, need ? roff + g.coff + strip_mul(sc, g.cstrip) + (uint32_t)(clip3i(y, 0, g.ch - 1) * 16) : MC_OOB);
+}
+// a strip outside the picture becomes the replicated first / last sample of each plane's 8 bytes
+__device__ __forceinline__ u32x4 chroma_piece_clamp(u32x4 t, const Geom &g, int strip)
+{
     if (strip < 0) { const uint32_t u = perm(t.x, t.x, 0x00000000u), v = perm(t.z, t.z, 0x00000000u); t.x = t.y = u; t.z = t.w = v; }
     if (strip >= g.mb_w) { const uint32_t u = perm(t.y, t.y, 0x03030303u), v = perm(t.w, t.w, 0x03030303u); t.x = t.y = u; t.z = t.w = v; }
     return t;
@@ -1120,7 +1157,7 @@ template <bool CLAMP> __device__ __forceinline__ u32x4 chroma_piece(rsrc_t rs, u
 __device__ __forceinline__ void lds_put16(uint8_t *p, u32x4 v) { *(uint2 *)p = make_uint2(v.x, v.y); *(uint2 *)(p + 8) = make_uint2(v.z, v.w); }
 
 template <bool MB, bool PB>
-__device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
+__device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *ref_tab, const PicDev *__restrict__ pd, const uint32_t *__restrict__ mc, const Geom &g,
                                                const McLayout &ml, int sub, int role_wgs)
 {
     typedef CItem<MB> I;
@@ -1133,27 +1170,25 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
     const int lane = threadIdx.x & 63, p = lane & 1, li = lane & (I::LANES - 1), it = lane / I::LANES;
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
-    const int n_ref = pd->n_ref;
-    const bool list_tables = n_ref > 1 || pd->slice_type == P264_SLICE_B;
     uint32_t key_w = cls_w[chunk >> 2];
     uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
   for (;;) {
     const int next = chunk + stride;
     const bool more = next < n_chunks;
-    uint32_t key_w_next = 0; uint4 e_next = make_uint4(0, 0, 0, 0);
-    if (more) { key_w_next = cls_w[next >> 2]; e_next = gload4(list + (size_t)(next * I::PER_WAVE + it) * MC_ENTRY_WORDS); }
+    const int nx = min(next, n_chunks - 1);                // (unconditional, as in mc_luma_body)
+    const uint32_t key_w_next = cls_w[nx >> 2];
+    const uint4 e_next = gload4(list + (size_t)(nx * I::PER_WAVE + it) * MC_ENTRY_WORDS);
     const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
     const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x >> 13) & 1023u) : 0;
     const int q = MB ? (li >> 1) : (valid ? (int)(e.x & 3) : 0);
-    uint32_t roff = pd->ref_off[0];
-    if (list_tables) roff = glob((e.x & MCE_LIST1) ? pd->ref_off_l1 : pd->ref_off)[e.x >> 28];
+    const uint32_t roff = ref_tab[(e.x >> 28) | ((e.x >> 19) & 16u)];         // (as in mc_luma_body)
     const uint32_t cidx = PB ? (e.w & ((1u << MCE_W_SHIFT) - 1u)) : e.w;
     // the 16-byte row this lane stores (see the end of the loop); second pass: what the first pass left there
     const uint32_t dsto = pd->dst_off + mb_chroma_off(g, mbx, mby) + (uint32_t)((q >> 1) * 64 + (lane & 3) * 16);
     u32x4 prev = { 0, 0, 0, 0 };
-    if (PB && valid) prev = bload4(rs, dsto);
+    if (PB) prev = bload4(rs, valid ? dsto : MC_OOB);
     const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;      // the block's first sample
     const unsigned mask = e.z & 0x03ffffffu;
     const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
@@ -1174,17 +1209,27 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
             img = images + (wave * I::PER_WAVE + it) * I::BYTES;
             const int sA = wx >> 3;
             x0 = sA * 8; y0 = wy;
-            u32x4 v[3]; int dst[3];
+            // (ONE scalar branch around the whole sequence, every piece requested in a row and waited for once: with the clamped /
+            // plain choice made per piece the compiler waited for every piece inside its own branch - three round trips)
+            auto stage = [&](auto clamp_tag) {
+                constexpr bool CL = decltype(clamp_tag)::value;
+                u32x4 v[3]; int dst[3];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int pp = min(li + 8 * j, 17), s = pp >= 9 ? 1 : 0, row = pp - 9 * s;
-                dst[j] = row * I::PITCH + s * 16;
-                v[j] = u32x4{ 0, 0, 0, 0 };
-                if (j < 2 || li < 2)                           // (pieces 16 and 17 only: the other lanes would fetch piece 17 again)
-                    v[j] = (key & MCC_CLAMP) ? chroma_piece<true>(rs, roff, g, sA + s, wy + row) : chroma_piece<false>(rs, roff, g, sA + s, wy + row);
-            }
+                for (int j = 0; j < 3; j++) {
+                    const int pp = min(li + 8 * j, 17), s = pp >= 9 ? 1 : 0, row = pp - 9 * s;
+                    dst[j] = row * I::PITCH + s * 16;
+                    // (pieces 16 and 17 only in the third round: the other lanes ask beyond the buffer - zeros, no memory request)
+                    v[j] = chroma_piece_load<CL>(rs, roff, g, sA + s, wy + row, j < 2 || li < 2);
+                }
 #pragma unroll
-            for (int j = 0; j < 3; j++) if (j < 2 || li < 2) lds_put16(img + dst[j], v[j]);
+                for (int j = 0; j < 3; j++) loads_land(v[j]);
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (CL) v[j] = chroma_piece_clamp(v[j], g, sA + (min(li + 8 * j, 17) >= 9 ? 1 : 0));
+                    if (j < 2 || li < 2) lds_put16(img + dst[j], v[j]);
+                }
+            };
+            if (key & MCC_CLAMP) stage(std::true_type{}); else stage(std::false_type{});
         } else {
             // Four lanes = two quadrants stage together: rows 0..3 of one strip of one quadrant per load (64 contiguous
             // bytes), then row 4 of their own strips.
@@ -1328,7 +1373,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const PicDev *__
 #define MC_COST_CM 5u
 #define MC_COST_CQ 9u
 template <bool PB>
-__device__ __forceinline__ void mc_roles(uint8_t *images, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml,
+__device__ __forceinline__ void mc_roles(uint8_t *images, uint32_t *ref_tab, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml,
                                          int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
     constexpr int L0 = PB ? ML_LISTS : 0;
@@ -1339,6 +1384,14 @@ __device__ __forceinline__ void mc_roles(uint8_t *images, const PicDev *__restri
     const int s = logical - pic * wgs_per_pic;
     const PicDev *pd = pics + pic;
     const uint32_t *mc = mc_all + (size_t)pic * ml.words;  // (addresses from kernel arguments only: the first loads depend on nothing)
+    // the picture's reference frames by (list, index) for the workgroup's wavefronts: entries past a list's end repeat entry 0
+    // (p264hip_reconstruct), list 1 exists for B pictures only
+    static_assert(MCE_LIST1 == 1u << 23 && P264HIP_MAX_REFS == 16, "table index of mc_luma_body / mc_chroma_body");
+    if (threadIdx.x < 2 * P264HIP_MAX_REFS) {
+        const int k = threadIdx.x & (P264HIP_MAX_REFS - 1);
+        ref_tab[threadIdx.x] = threadIdx.x < P264HIP_MAX_REFS ? pd->ref_off[k] : (pd->slice_type == P264_SLICE_B ? pd->ref_off_l1[k] : pd->ref_off[0]);
+    }
+    __syncthreads();
     // role split (scalar): every non-empty list gets one workgroup, the rest go by cost
     const uint32_t n0 = mc[L0 + ML_YM], n1 = mc[L0 + ML_YQ], n2 = mc[L0 + ML_CM], n3 = mc[L0 + ML_CQ];
     const uint32_t t0 = n0 * MC_COST_YM, t1 = n1 * MC_COST_YQ, t2 = n2 * MC_COST_CM, t3 = n3 * MC_COST_CQ, tt = t0 + t1 + t2 + t3;
@@ -1350,10 +1403,10 @@ __device__ __forceinline__ void mc_roles(uint8_t *images, const PicDev *__restri
     if (EXPM_ONLY == 1 && s >= w0 + w1) return;                                 // (timing switches)
     if (EXPM_ONLY == 2 && s < w0 + w1) return;
     if (EXPM_ONLY == 3 && !(s < w0 || (s >= w0 + w1 && s < w0 + w1 + w2))) return;   // macroblock items only
-    if (s < w0) mc_luma_body<true, PB>(images, pd, mc, g, ml, s, w0);
-    else if (s < w0 + w1) mc_luma_body<false, PB>(images, pd, mc, g, ml, s - w0, w1);
-    else if (s < w0 + w1 + w2) mc_chroma_body<true, PB>(images, pd, mc, g, ml, s - w0 - w1, w2);
-    else mc_chroma_body<false, PB>(images, pd, mc, g, ml, s - w0 - w1 - w2, w3);
+    if (s < w0) mc_luma_body<true, PB>(images, ref_tab, pd, mc, g, ml, s, w0);
+    else if (s < w0 + w1) mc_luma_body<false, PB>(images, ref_tab, pd, mc, g, ml, s - w0, w1);
+    else if (s < w0 + w1 + w2) mc_chroma_body<true, PB>(images, ref_tab, pd, mc, g, ml, s - w0 - w1, w2);
+    else mc_chroma_body<false, PB>(images, ref_tab, pd, mc, g, ml, s - w0 - w1 - w2, w3);
 }
 #ifndef MC_IMAGE_BYTES
 #define MC_IMAGE_BYTES (YItem<false>::LEAD + 4 * 16 * YItem<false>::BYTES)        // the largest of the four roles' images
@@ -1367,12 +1420,14 @@ __global__ __launch_bounds__(256, MC_WAVES_PER_EU)
 void k_mc(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
     __shared__ __attribute__((aligned(16))) uint8_t images[MC_IMAGE_BYTES];
-    mc_roles<false>(images, pics, mc_all, g, ml, wgs_per_pic, n_wgs, inv_wgs);
+    __shared__ uint32_t ref_tab[2 * P264HIP_MAX_REFS];
+    mc_roles<false>(images, ref_tab, pics, mc_all, g, ml, wgs_per_pic, n_wgs, inv_wgs);
 }
 // B pictures: the second pass (list-1 predictions of the blocks that use both lists), behind k_mc
 __global__ __launch_bounds__(256, 4)
 void k_mc_second(const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, Geom g, McLayout ml, int wgs_per_pic, int n_wgs, uint32_t inv_wgs)
 {
     __shared__ __attribute__((aligned(16))) uint8_t images[MC_IMAGE_BYTES];
-    mc_roles<true>(images, pics, mc_all, g, ml, wgs_per_pic, n_wgs, inv_wgs);
+    __shared__ uint32_t ref_tab[2 * P264HIP_MAX_REFS];
+    mc_roles<true>(images, ref_tab, pics, mc_all, g, ml, wgs_per_pic, n_wgs, inv_wgs);
 }

@@ -98,6 +98,9 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // v_perm_b32: result byte i = byte sel[i] of {hi (4..7), lo (0..3)}; 0x0c = zero
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// v_sat_pk_u8_i16: both signed 16-bit halves of v saturated to 0..255, into bytes 0 (low half) and 1 (high half); the upper
+// bytes are not used by any caller (the compiler has no pattern for this instruction)
+__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v) { uint32_t r; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v)); return r; }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long rfl64(unsigned long long v)
 {

@@ -325,24 +325,33 @@ __device__ __forceinline__ pk16 pk_sel(pk16 m, pk16 a, pk16 b) { return (a & m) 
 // gfx950, v_pk_add_u16 in 4.3 (scratch/r4_rates/).
 __device__ __forceinline__ pk16 pk_addu(pk16 a, pk16 b) { return as_pk(as_u(a) + as_u(b)); }
 
-// the three "filterSamplesFlag" conditions, core/frame.c:311,357,398,444
-__device__ __forceinline__ pk16 pk_edge_flag(pk16 p1, pk16 p0, pk16 q0, pk16 q1, pk16 A, pk16 B)
+// Sample conditions as SIGN BITS (round 5: the kernel is bound by vector-instruction issue, so the filter arithmetic counts):
+// |d| < T  <=>  d < T and -d < T  <=>  (d - T) & (-T - d) is negative - two subtractions on the difference the filter needs anyway,
+// no absolute value, and the three conditions of the sample flag share ONE shift (the AND of their sign words).
+__device__ __forceinline__ pk16 pk_within(pk16 d, pk16 T, pk16 nT) { return (d - T) & (nT - d); }     // negative where |d| < T (nT = -T)
+__device__ __forceinline__ pk16 pk_sign(pk16 v) { return v >> (pk16)15; }                             // all ones where negative
+// the three "filterSamplesFlag" conditions, core/frame.c:311,357,398,444; e = q0 - p0 (what the filters start from)
+__device__ __forceinline__ pk16 pk_edge_flag(pk16 p1, pk16 p0, pk16 q0, pk16 q1, pk16 A, pk16 nA, pk16 B, pk16 nB, pk16 &e)
 {
-    return pk_lt(pk_absd(p0, q0), A) & pk_lt(pk_absd(p1, p0), B) & pk_lt(pk_absd(q1, q0), B);
+    e = q0 - p0;
+    return pk_sign(pk_within(e, A, nA) & pk_within(p1 - p0, B, nB) & pk_within(q1 - q0, B, nB));
 }
 
-// bS 1..3 on a luma edge (core/frame.c:302-341).  en = all ones in the lanes whose bS is 1..3.
+// bS 1..3 on a luma edge (core/frame.c:302-341).  f = sample flag in the lanes whose bS is 1..3; e = q0 - p0.  p0 and q0 come out
+// NOT clipped (p0 + delta, q0 - delta): the caller clips them where it turns them into bytes (v_sat_pk_u8_i16: one instruction
+// instead of max + min).  The masks go into the clamp bounds instead of onto the clamped value (a 32-bit AND issues in 2.4 cycles,
+// the packed forms in 4.3).
 __device__ __forceinline__ void pk_luma_normal(pk16 p2, pk16 &p1, pk16 &p0, pk16 &q0, pk16 &q1, pk16 q2,
-                                               pk16 f, pk16 ap, pk16 aq, pk16 T0)
+                                               pk16 e, pk16 f, pk16 ap, pk16 aq, pk16 T0)
 {
     const pk16 avg = pk_addu(pk_addu(p0, q0), (pk16)1) >> (pk16)1;
     const pk16 dp = pk_clamp((pk_addu(p2, avg) >> (pk16)1) - p1, -T0, T0) & (f & ap);
     const pk16 dq = pk_clamp((pk_addu(q2, avg) >> (pk16)1) - q1, -T0, T0) & (f & aq);
-    const pk16 tc = T0 - ap - aq;                                   // the masks are -1 where true
-    const pk16 delta = pk_clamp((((q0 - p0) << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -tc, tc) & f;
+    const pk16 tc = (T0 - ap - aq) & f;                             // the masks are -1 where true; 0 where the flag is off: delta = 0
+    const pk16 delta = pk_clamp(((e << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -tc, tc);
     p1 += dp; q1 += dq;
-    p0 = pk_clamp(p0 + delta, (pk16)0, (pk16)255);
-    q0 = pk_clamp(q0 - delta, (pk16)0, (pk16)255);
+    p0 = p0 + delta;
+    q0 = q0 - delta;
 }
 // bS 4 on a luma edge (core/frame.c:387-432); s = f & str in the lanes that take it
 __device__ __forceinline__ void pk_luma_strong(pk16 p3, pk16 &p2, pk16 &p1, pk16 &p0, pk16 &q0, pk16 &q1, pk16 &q2, pk16 q3,
@@ -364,13 +373,14 @@ __device__ __forceinline__ void pk_luma_strong(pk16 p3, pk16 &p2, pk16 &p1, pk16
     p2 = pk_sel(s & sp, p2s, p2); q2 = pk_sel(s & sq, q2s, q2);
 }
 // chroma edge, any bS (core/frame.c:351-377, 438-462); T = tc0+1 (from K4a), en/str = masks of the bS 1..3 / bS 4 lanes
-// any_strong (wave-uniform): some lane of the wavefront has bS 4 on this edge
-__device__ __forceinline__ void pk_chroma(pk16 p1, pk16 &p0, pk16 &q0, pk16 q1, pk16 f, pk16 en, pk16 str, bool any_strong, pk16 T)
+// any_strong (wave-uniform): some lane of the wavefront has bS 4 on this edge.  e = q0 - p0; p0 / q0 come out not clipped (as above).
+__device__ __forceinline__ void pk_chroma(pk16 p1, pk16 &p0, pk16 &q0, pk16 q1, pk16 e, pk16 f, pk16 en, pk16 str, bool any_strong, pk16 T)
 {
-    const pk16 delta = pk_clamp((((q0 - p0) << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -T, T) & (f & en);
+    const pk16 Tm = T & (f & en);
+    const pk16 delta = pk_clamp(((e << (pk16)2) + (p1 - q1) + (pk16)4) >> (pk16)3, -Tm, Tm);
     const pk16 op0 = p0, oq0 = q0;
-    p0 = pk_clamp(p0 + delta, (pk16)0, (pk16)255);
-    q0 = pk_clamp(q0 - delta, (pk16)0, (pk16)255);
+    p0 = p0 + delta;
+    q0 = q0 - delta;
     if (any_strong) {
         const pk16 p0w = pk_addu(pk_addu(pk_addu(p1, p1), op0), pk_addu(q1, (pk16)2)) >> (pk16)2, q0w = pk_addu(pk_addu(pk_addu(q1, q1), oq0), pk_addu(p1, (pk16)2)) >> (pk16)2;
         const pk16 s = f & str;
@@ -378,7 +388,19 @@ __device__ __forceinline__ void pk_chroma(pk16 p1, pk16 &p0, pk16 &q0, pk16 q1, 
         q0 = pk_sel(s, q0w, q0);
     }
 }
+// a pair clipped to 0..255 and squeezed into bytes 0 (low half) and 1 (high half): what the byte-wise consumers take
+__device__ __forceinline__ uint32_t pk_clip_bytes(pk16 v) { return sat_pk_u8_i16(as_u(v)); }
+template <int OFF> __device__ __forceinline__ void lds_put_clipped(uint8_t *base, pk16 v) { *(uint16_t *)(base + OFF) = (uint16_t)pk_clip_bytes(v); }
 
+// A 16-bit pair of samples (values 0..255 in both halves) stored as two adjacent bytes of LDS: ds_write_b8 takes bits 0..7,
+// ds_write_b8_d16_hi bits 16..23 - no v_perm to squeeze the pair into 16 bits first (the kernel is bound by vector-instruction
+// issue, the LDS pipe is not).  A wavefront's DS operations execute in order, and the extra entries in lgkmcnt only make the
+// compiler's own waits stricter.
+template <int OFF> __device__ __forceinline__ void lds_put_pair(const uint8_t *base, pk16 v)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)base;
+    asm volatile("ds_write_b8 %0, %1 offset:%2\n\tds_write_b8_d16_hi %0, %1 offset:%3" :: "v"(a), "v"(as_u(v)), "n"(OFF), "n"(OFF + 1) : "memory");
+}
 // byte K of two dwords as a 16-bit pair (a -> low half, b -> high half)
 template <int K> __device__ __forceinline__ pk16 pair_byte(uint32_t a, uint32_t b)
 {
@@ -582,12 +604,13 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     pk16 p2 = pair_byte<1>(ya[ed], yb[ed]), p1 = pair_byte<2>(ya[ed], yb[ed]), p0 = pair_byte<3>(ya[ed], yb[ed]);
                     pk16 q0 = pair_byte<0>(ya[ed+1], yb[ed+1]), q1 = pair_byte<1>(ya[ed+1], yb[ed+1]), q2 = pair_byte<2>(ya[ed+1], yb[ed+1]);
                     const EdgeParams ep(E, k);
-                    const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
-                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
-                    const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
+                    const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2()), nA = -A, nB = -B;
+                    pk16 e;
+                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, nA, B, nB, e);
+                    const pk16 ap = pk_sign(pk_within(p2 - p0, B, nB)), aq = pk_sign(pk_within(q2 - q0, B, nB));
                     const pk16 en = as_pk(mask_bs123(b, ed));
                     const pk16 op2 = p2, op1 = p1, op0 = p0, oq0 = q0, oq1 = q1, oq2 = q2;
-                    pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
+                    pk_luma_normal(p2, p1, p0, q0, q1, q2, e, f & en, ap, aq, as_pk(ep.tc2(b)));
                     // bS 4 exists on macroblock edges only (k_deblock_bs), and the strong filter changes nothing where the
                     // sample flag is off
                     if (EXPD_STRONG && ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
@@ -598,7 +621,8 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         ya[ed] = perm(as_u(sp2), ya[ed], 0x03020400u);   yb[ed] = perm(as_u(sp2), yb[ed], 0x03020600u);
                         ya[ed+1] = perm(as_u(sq2), ya[ed+1], 0x03040100u); yb[ed+1] = perm(as_u(sq2), yb[ed+1], 0x03060100u);
                     }
-                    const uint32_t tp = as_u(p1) | (as_u(p0) << 8), tq = as_u(q0) | (as_u(q1) << 8);
+                    // p0 / q0 clipped into byte pairs (row 2j in byte 0, row 2j+1 in byte 1), merged with p1 / q1: bytes {p1 a, p0 a, p1 b, p0 b}
+                    const uint32_t tp = perm(pk_clip_bytes(p0), as_u(p1), 0x05020400u), tq = perm(as_u(q1), pk_clip_bytes(q0), 0x06010400u);
                     ya[ed] = perm(tp, ya[ed], 0x05040100u);     yb[ed] = perm(tp, yb[ed], 0x07060100u);
                     ya[ed+1] = perm(tq, ya[ed+1], 0x03020504u); yb[ed+1] = perm(tq, yb[ed+1], 0x03020706u);
                 }
@@ -609,10 +633,13 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     pk16 p1 = pair_byte<2>(ca[c], cb[c]), p0 = pair_byte<3>(ca[c], cb[c]);
                     pk16 q0 = pair_byte<0>(ca[c+1], cb[c+1]), q1 = pair_byte<1>(ca[c+1], cb[c+1]);
                     const EdgeParams ep(E, k);
-                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, as_pk(ep.alpha2()), as_pk(ep.beta2()));
-                    pk_chroma(p1, p0, q0, q1, f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
-                    ca[c] = perm(as_u(p0), ca[c], 0x04020100u);     cb[c] = perm(as_u(p0), cb[c], 0x06020100u);
-                    ca[c+1] = perm(as_u(q0), ca[c+1], 0x03020104u); cb[c+1] = perm(as_u(q0), cb[c+1], 0x03020106u);
+                    const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
+                    pk16 e;
+                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, -A, B, -B, e);
+                    pk_chroma(p1, p0, q0, q1, e, f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
+                    const uint32_t P0 = pk_clip_bytes(p0), Q0 = pk_clip_bytes(q0);      // (row a in byte 0, row b in byte 1)
+                    ca[c] = perm(P0, ca[c], 0x04020100u);     cb[c] = perm(P0, cb[c], 0x05020100u);
+                    ca[c+1] = perm(Q0, ca[c+1], 0x03020104u); cb[c+1] = perm(Q0, cb[c+1], 0x03020105u);
                 }
             }
             DB_STAMP(2);
@@ -656,12 +683,13 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         if (__ballot(b != 0) == 0) continue;
                         pk16 &p3 = c[4*ed], &p2 = c[4*ed+1], &p1 = c[4*ed+2], &p0 = c[4*ed+3], &q0 = c[4*ed+4], &q1 = c[4*ed+5], &q2 = c[4*ed+6], &q3 = c[4*ed+7];
                         const EdgeParams ep(E, k);
-                        const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
-                        const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, B);
-                        const pk16 ap = pk_lt(pk_absd(p2, p0), B), aq = pk_lt(pk_absd(q2, q0), B);
+                        const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2()), nA = -A, nB = -B;
+                        pk16 e;
+                        const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, nA, B, nB, e);
+                        const pk16 ap = pk_sign(pk_within(p2 - p0, B, nB)), aq = pk_sign(pk_within(q2 - q0, B, nB));
                         const pk16 en = as_pk(mask_bs123(b, ed));
                         pk16 sp2 = p2, sp1 = p1, sp0 = p0, sq0 = q0, sq1 = q1, sq2 = q2;
-                        pk_luma_normal(p2, p1, p0, q0, q1, q2, f & en, ap, aq, as_pk(ep.tc2(b)));
+                        pk_luma_normal(p2, p1, p0, q0, q1, q2, e, f & en, ap, aq, as_pk(ep.tc2(b)));
                         if (EXPD_STRONG && ed == 0 && __ballot((as_u(f) & mask_bs4(b)) != 0)) {
                             const pk16 str = as_pk(mask_bs4(b));
                             pk_luma_strong(p3, sp2, sp1, sp0, sq0, sq1, sq2, q3, f & str, ap, aq, A);
@@ -669,11 +697,16 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                             q0 = pk_sel(str, sq0, q0); q1 = pk_sel(str, sq1, q1); q2 = pk_sel(str, sq2, q2);
                         }
                     }
-                    uint8_t *topw = (uint8_t *)ring + 2 * j;
-#pragma unroll
-                    for (int r = 1; r < 4; r++) *(uint16_t *)(topw + r * 16) = (uint16_t)perm(as_u(c[r]), as_u(c[r]), 0x0c0c0200u);
-#pragma unroll
-                    for (int r = 0; r < 15; r++) *(uint16_t *)(tile8 + 2 * j + r * 16) = (uint16_t)perm(as_u(c[4 + r]), as_u(c[4 + r]), 0x0c0c0200u);
+                    // rows -3 .. 14 back (row -4 cannot change).  The rows either side of an edge (p0 / q0: -1 | 0, 3 | 4, 7 | 8, 11 | 12) may
+                    // hold p0 + delta / q0 - delta not yet clipped: clipped into a byte pair here, one 16-bit store
+                    {
+                        uint8_t *topw = (uint8_t *)ring + 2 * j, *colw = tile8 + 2 * j;
+                        lds_put_pair<1 * 16>(topw, c[1]); lds_put_pair<2 * 16>(topw, c[2]); lds_put_clipped<3 * 16>(topw, c[3]);
+                        lds_put_clipped<0 * 16>(colw, c[4]);  lds_put_pair<1 * 16>(colw, c[5]);   lds_put_pair<2 * 16>(colw, c[6]);   lds_put_clipped<3 * 16>(colw, c[7]);
+                        lds_put_clipped<4 * 16>(colw, c[8]);  lds_put_pair<5 * 16>(colw, c[9]);   lds_put_pair<6 * 16>(colw, c[10]);  lds_put_clipped<7 * 16>(colw, c[11]);
+                        lds_put_clipped<8 * 16>(colw, c[12]); lds_put_pair<9 * 16>(colw, c[13]);  lds_put_pair<10 * 16>(colw, c[14]); lds_put_clipped<11 * 16>(colw, c[15]);
+                        lds_put_clipped<12 * 16>(colw, c[16]); lds_put_pair<13 * 16>(colw, c[17]); lds_put_pair<14 * 16>(colw, c[18]);
+                    }
                     // chroma: columns cr, cr+1 of plane cp; only rows -1, 0, 3, 4 can change
                     const uint8_t *ctop = (const uint8_t *)ring + 64 + cp * 16 + cr;
                     uint8_t *ccol = tile8 + 256 + cp * 64 + cr;
@@ -687,13 +720,16 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         const int b = E.code(1, ed, cseg2), k = edge_class(1, ed) + 3;
                         if (__ballot(b != 0) == 0) continue;
                         const EdgeParams ep(E, k);
-                        const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], as_pk(ep.alpha2()), as_pk(ep.beta2()));
-                        pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
+                        const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
+                        pk16 e;
+                        const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], A, -A, B, -B, e);
+                        pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], e, f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
                     }
-                    *(uint16_t *)((uint8_t *)ring + 64 + cp * 16 + cr + 8) = (uint16_t)perm(as_u(d[1]), as_u(d[1]), 0x0c0c0200u);
-                    *(uint16_t *)(ccol) = (uint16_t)perm(as_u(d[2]), as_u(d[2]), 0x0c0c0200u);
-                    *(uint16_t *)(ccol + 3 * 8) = (uint16_t)perm(as_u(d[5]), as_u(d[5]), 0x0c0c0200u);
-                    *(uint16_t *)(ccol + 4 * 8) = (uint16_t)perm(as_u(d[6]), as_u(d[6]), 0x0c0c0200u);
+                    // (all four are p0 / q0 rows: clipped here)
+                    lds_put_clipped<8>((uint8_t *)ring + 64 + cp * 16 + cr, d[1]);
+                    lds_put_clipped<0>(ccol, d[2]);
+                    lds_put_clipped<3 * 8>(ccol, d[5]);
+                    lds_put_clipped<4 * 8>(ccol, d[6]);
                 }
                 wave_lds_fence();
             }

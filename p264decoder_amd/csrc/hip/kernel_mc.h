@@ -44,7 +44,7 @@
 // Timing experiments (scratch/r4_mcexp.sh, r4_mcparts.sh): pieces of the kernels compiled out to time the rest.  Results are
 // wrong unless all defaults hold, so the switches only exist in a build that says what it is: -DP264AMD_TIMING_BUILD, in
 // which p264hip_create refuses to run without P264AMD_TIMING_BUILD_OK=1 and p264hip_build_info() reports the flag.
-#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPM_LUMA_COPY) || defined(EXPM_NO_STORE) || defined(EXPM_NO_WINDOW) || defined(EXPM_ONLY) || defined(EXPM_RESID))
+#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPM_LUMA_COPY) || defined(EXPM_NO_STORE) || defined(EXPM_NO_WINDOW) || defined(EXPM_ONLY) || defined(EXPM_RESID) || defined(EXPM_FORCE_KEY))
 #error "EXPM_* switches produce wrong pictures: they need -DP264AMD_TIMING_BUILD"
 #endif
 #ifndef EXPM_LUMA_COPY
@@ -61,6 +61,12 @@
 #endif
 #ifndef EXPM_RESID
 #define EXPM_RESID 1
+#endif
+// EXPM_FORCE_KEY=k: every chunk is taken for key k (scratch/mc_count.sh: static instruction counts per role and class)
+#ifdef EXPM_FORCE_KEY
+#define MC_CHUNK_KEY(v) ((void)(v), (int)(EXPM_FORCE_KEY))
+#else
+#define MC_CHUNK_KEY(v) (v)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -623,6 +629,9 @@ __device__ __forceinline__ void stage_luma(uint8_t *img, rsrc_t rs, uint32_t rof
     }
 }
 template <int PITCH> struct LWin {
+    // (Round 5 tried dword reads at the window's own byte address - gfx950's LDS takes unaligned reads - to drop the v_alignbyte per
+    // window dword: 6 % fewer vector instructions in the luma roles, and the MC stage went from 4.95 to 5.54 ms per 2048 pictures:
+    // the compiler merges them into unaligned ds_read_b64 / b96 and the LDS pipe serves those far below its aligned rate.)
     const uint8_t *img; int x0, y0;                        // the image's sample (0,0) is (x0, y0) of the reference
     template <int R0, int NR, int NC> __device__ __forceinline__ void load(uint32_t (&d)[9][3], int xw, int yw) const
     {
@@ -686,15 +695,15 @@ __device__ __forceinline__ uint32_t tap_v4(uint32_t r0, uint32_t r1, uint32_t r2
     // cycles per wavefront on gfx950, the packed add in 4.3 - scratch/r4_rates/), the rounding term rides on the first of them;
     // the taps are two packed multiply-adds.
     const uint32_t M = 0x00ff00ffu;
-    const s16x2 c20 = { 20, 20 }, cm5 = { -5, -5 }, z = { 0, 0 }, m = { 255, 255 };
+    const s16x2 c20 = { 20, 20 }, cm5 = { -5, -5 };
     const uint32_t a05 = (r0 & M) + (r5 & M) + 0x00100010u, a23 = (r2 & M) + (r3 & M), a14 = (r1 & M) + (r4 & M);
     const uint32_t b05 = ((r0 >> 8) & M) + ((r5 >> 8) & M) + 0x00100010u, b23 = ((r2 >> 8) & M) + ((r3 >> 8) & M), b14 = ((r1 >> 8) & M) + ((r4 >> 8) & M);
     s16x2 a = cm5 * as_s16x2(a14) + (c20 * as_s16x2(a23) + as_s16x2(a05));
     s16x2 b = cm5 * as_s16x2(b14) + (c20 * as_s16x2(b23) + as_s16x2(b05));
+    // (v >> 5) clipped to a byte: v_sat_pk_u8_i16 saturates both halves of a pair into bytes 0 and 1 (two instructions per pair
+    // instead of shift, max, min; one v_perm interleaves the even and the odd samples)
     a = a >> 5; b = b >> 5;
-    a = __builtin_elementwise_min(__builtin_elementwise_max(a, z), m);
-    b = __builtin_elementwise_min(__builtin_elementwise_max(b, z), m);
-    return as_u32(a) | (as_u32(b) << 8);
+    return perm(sat_pk_u8_i16(as_u32(b)), sat_pk_u8_i16(as_u32(a)), 0x05010400u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -931,7 +940,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
     const int nx = min(next, n_chunks - 1);
     const uint32_t key_w_next = cls_w[nx >> 2];
     const uint4 e_next = gload4(list + (size_t)(nx * I::PER_WAVE + it) * MC_ENTRY_WORDS);
-    const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);                                 // scalar: the chunk's key bits
+    const int key = MC_CHUNK_KEY((int)((key_w >> (8 * (chunk & 3))) & 255u));                   // scalar: the chunk's key bits
     const int pc = key & 7;
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
@@ -1178,7 +1187,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
     const int nx = min(next, n_chunks - 1);                // (unconditional, as in mc_luma_body)
     const uint32_t key_w_next = cls_w[nx >> 2];
     const uint4 e_next = gload4(list + (size_t)(nx * I::PER_WAVE + it) * MC_ENTRY_WORDS);
-    const int key = (int)((key_w >> (8 * (chunk & 3))) & 255u);
+    const int key = MC_CHUNK_KEY((int)((key_w >> (8 * (chunk & 3))) & 255u));
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
     const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x >> 13) & 1023u) : 0;

@@ -29,6 +29,7 @@ for f in glob.glob(sys.argv[1] + "/trace256/**/*kernel_stats.csv", recursive=Tru
         n = r["Name"].split("(")[0]; n = n[5:] if n.startswith("void ") else n
         if n.startswith("k_"): print("%-16s calls %4s  avg %10.1f us" % (n, r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
+[ -n "$R5_NO_PMC" ] && { echo "[r5] done (no pmc)"; exit 0; }
 i=0
 for lib in full sk; do
 for ctr in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \

@@ -30,7 +30,7 @@
 
 // Timing experiments (scratch/variant.sh, r4_dbexp.sh): results are wrong unless all defaults hold, so the switches only exist
 // in a build that says what it is (-DP264AMD_TIMING_BUILD, see kernel_mc.h and p264hip_build_info()).
-#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPD_LUMA_EDGES) || defined(EXPD_CHROMA_EDGES) || defined(EXPD_STRONG) || defined(EXPD_HPASS) || defined(EXPD_BANDSYNC) || defined(EXPD_VMCNT) || defined(EXPD_STAMPS))
+#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPD_LUMA_EDGES) || defined(EXPD_CHROMA_EDGES) || defined(EXPD_STRONG) || defined(EXPD_HPASS) || defined(EXPD_BANDSYNC) || defined(EXPD_VMCNT) || defined(EXPD_STAMPS) || defined(EXPD_NO_SAMPLE_LOADS))
 #error "EXPD_* switches produce wrong pictures: they need -DP264AMD_TIMING_BUILD"
 #endif
 #ifndef EXPD_LUMA_EDGES
@@ -50,6 +50,9 @@
 #endif
 #ifndef EXPD_VMCNT
 #define EXPD_VMCNT 1
+#endif
+#ifndef EXPD_NO_SAMPLE_LOADS
+#define EXPD_NO_SAMPLE_LOADS 0     // 1: the macroblock's own samples are not loaded (round 5: what a fused prediction + filter pass could save at most)
 #endif
 #ifdef EXPD_STAMPS
 // in-kernel clock stamps of one wavefront (diagnostic build only: scratch/r4_stamps.sh)
@@ -538,8 +541,14 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     else { uint2 v2 = gload2(tp); fT.x = v2.x; fT.y = v2.y; }
                 }
                 const uint8_t *yp = ownY0 + (ptrdiff_t)t * (ptrdiff_t)sY, *cp2 = ownC0 + (ptrdiff_t)t * (ptrdiff_t)sC;
+                if (EXPD_NO_SAMPLE_LOADS) {
+                    const uint32_t a = (uint32_t)(uintptr_t)yp, b2 = (uint32_t)(uintptr_t)cp2;
+                    fYa = make_uint4(a, a + 1, a + 2, a + 3); fYb = fYa; fC = make_uint4(b2, b2 + 1, b2 + 2, b2 + 3);
+                    asm volatile("" : "+v"(fYa.x), "+v"(fYb.y), "+v"(fC.z));
+                } else {
                 fYa = gload4(yp); fYb = gload4(yp + 16);
                 { const uint2 ca2 = gload2(cp2), cb2 = gload2(cp2 + 16); fC = make_uint4(ca2.x, ca2.y, cb2.x, cb2.y); }
+                }
             }
         };
 

@@ -604,7 +604,16 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // workgroup with more pictures than a wavefront holds (8 >> rb_log2) works on them in groups (units = band x group).
         // (Round 4: 2 rows x 4 pictures ran as fast, 2.70 ms, but every second row's bottom lines cross a band - 0.4 GB more
         // through memory per launch.)
-        int rb_log2 = per_wg == 1 ? 3 : 2;
+        // Which shape: the stage's time follows the wavefront-iterations it issues (round 5: 1.07 ms per 16 units of 127 iterations at
+        // 2 ... 15 pictures per workgroup, half-empty units included - it is bound by vector-instruction issue).  Bands of 4 rows hold
+        // two pictures per wavefront: an odd picture count leaves one unit in every band half empty; bands of 8 rows hold one picture,
+        // but run 8 iterations longer and the last band of a 68-row picture is half empty.  Take the cheaper one.
+        auto units_cost = [&](int lg) {
+            const int rows = 1 << lg, pw = 8 >> lg;
+            const long bands = (g.mb_h + rows - 1) / rows, groups = (per_wg + pw - 1) / pw;
+            return bands * groups * (long)(g.mb_w + 1 + 2 * (rows - 1));
+        };
+        int rb_log2 = units_cost(3) < units_cost(2) ? 3 : 2;
         if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) rb_log2 = c->tune_rb_log2;
         if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= MAX_PICS_PER_WG) per_wg = c->tune_pics_per_wg;
         const int n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;

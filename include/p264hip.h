@@ -219,7 +219,8 @@ typedef struct p264hip_launch_info {
     int32_t intra_waves;           /* k_intra / k_intra_sparse: wavefronts per workgroup */
     int32_t edge_info_fused;       /* edge-info workgroups per picture inside the k_intra_sparse launch (0: own launch k_deblock_bs) */
     int32_t deblock_pics_per_wg, deblock_rb_log2, deblock_waves, deblock_wgs;
-    int32_t reserved[7];
+    int32_t deblock_odd_single;    /* 1: odd pictures per workgroup - pairs in bands of 4 rows, the last picture alone in bands of 8 */
+    int32_t reserved[6];
 } p264hip_launch_info_t;
 int  p264hip_last_launch(p264hip_ctx *ctx, p264hip_launch_info_t *out);
 

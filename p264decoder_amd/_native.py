@@ -52,7 +52,7 @@ assert C.sizeof(MbInfo) == 16
 class LaunchInfo(C.Structure):
     """p264hip_launch_info_t"""
     _fields_ = [(n, C.c_int32) for n in ("pictures", "compute_units", "mc_wgs_per_picture", "intra_waves", "edge_info_fused",
-                                         "deblock_pics_per_wg", "deblock_rb_log2", "deblock_waves", "deblock_wgs")] + [("reserved", C.c_int32 * 7)]
+                                         "deblock_pics_per_wg", "deblock_rb_log2", "deblock_waves", "deblock_wgs", "deblock_odd_single")] + [("reserved", C.c_int32 * 6)]
 
 
 BUILD_TIMING = 1

@@ -443,26 +443,41 @@ struct OctLds {                    // per octet: 212 dwords
 #define MAX_BANDS (MAX_MB_ROWS / 2)
 
 __global__ __launch_bounds__(ROW_WAVES * 64)
-void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status, int n_pics, int rb_log2, int pics_per_wg)
+void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status, int n_pics, int rb_log2_, int pics_per_wg, int odd_single)
 {
     __shared__ int progress[MAX_PICS_PER_WG][MAX_BANDS];     // fully stored macroblocks of a band's last row
     __shared__ OctLds lds[ROW_WAVES][8];
     __shared__ EdgeTables tables;
     edge_tables_init(tables);
     const Geom g = g_;
-    const int RB = 1 << rb_log2, PW = 8 >> rb_log2;             // rows of a band, pictures per wavefront
     // (the wavefront number is a scalar: without readfirstlane the compiler takes the unit loop for divergent and keeps all of its
     // book-keeping - unit, band, picture pointers - in vector registers)
     const int wave = rfl((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
-    const int n_bands = (g.mb_h + RB - 1) >> rb_log2;
-    const int n_groups = (pics_per_wg + PW - 1) / PW;         // the workgroup's pictures in groups of PW: a work unit = (band, group)
+    // A work unit = (band, group of pictures): `1 << rb_log2` rows of `8 >> rb_log2` pictures.  odd_single (with bands of 4 rows and
+    // an odd number of pictures, round 5): the pictures go in pairs and the LAST one on its own in bands of 8 rows - a pair's
+    // group with one picture missing would issue every instruction of its 17 units for half the lanes.
+    const int n_bands_all = (g.mb_h + (1 << rb_log2_) - 1) >> rb_log2_;
+    const int n_groups_all = (pics_per_wg + (8 >> rb_log2_) - 1) / (8 >> rb_log2_);
+    const int n_pairs = pics_per_wg >> 1, n_bands8 = (g.mb_h + 7) >> 3, per_step = 2 * n_pairs + 1;     // odd_single: units per two pair bands + one single band
+    const int n_units = !odd_single ? n_bands_all * n_groups_all : (n_bands8 - 1) * per_step + (n_bands_all - 2 * (n_bands8 - 1)) * n_pairs + 1;
     for (int k = threadIdx.x; k < MAX_PICS_PER_WG * MAX_BANDS; k += blockDim.x) (&progress[0][0])[k] = 0;
     __syncthreads();
     bool ok = true;
 
     // units in band-major order: a wavefront takes unit u only after u - n_waves, and band b of a group only waits for band
     // b - 1 of the same group, which is an earlier unit - nobody waits for a unit that has not been started
-    for (int unit = wave; unit < n_bands * n_groups; unit += n_waves) {
+    for (int unit = wave; unit < n_units; unit += n_waves) {
+        // the unit's shape, band and first picture (scalars).  odd_single: steps of {band 2s of every pair, band s of the single
+        // picture, band 2s + 1 of every pair} - a band still only waits for the band above it of the same pictures, an earlier unit
+        int rb_log2 = rb_log2_, band, pic0;
+        if (!odd_single) { band = unit / n_groups_all; pic0 = (unit - band * n_groups_all) * (8 >> rb_log2_); }
+        else {
+            const int st = unit / per_step, r = unit - st * per_step;
+            if (r < n_pairs) { band = 2 * st; pic0 = 2 * r; }
+            else if (r == n_pairs) { rb_log2 = 3; band = st; pic0 = pics_per_wg - 1; }
+            else { band = 2 * st + 1; pic0 = 2 * (r - n_pairs - 1); }
+        }
+        const int RB = 1 << rb_log2, PW = 8 >> rb_log2;         // rows of the band, pictures of the wavefront
         // Everything that follows from the lane number is derived again per unit (a few dozen instructions against ~100 000 of the
         // unit): hoisted out of this loop, the lane constants that only the unit's set-up needs (64-bit offsets of the lane's rows,
         // products with the strip sizes) stayed alive through the iteration loop - the kernel has no register to spare for them
@@ -475,7 +490,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         const int seg2 = (j >> 1) * 2, cseg2 = (j & 3) * 2;       // 2 x the bS segment of this lane's luma / chroma lines
         const int cp = j >> 2, cr = (j & 3) * 2;                  // chroma plane, first chroma line of this lane
         uint8_t *tile8 = (uint8_t *)L.tile;
-        const int band = unit / n_groups, piw = (unit - band * n_groups) * PW + pi;     // picture inside the workgroup
+        const int piw = pic0 + pi;                                // picture inside the workgroup
         const int pic = blockIdx.x * pics_per_wg + piw;
         const PicDev *pd = pics + min(pic, n_pics - 1);
         const bool pic_ok = pi < PW && piw < pics_per_wg && pic < n_pics && pd->deblock;

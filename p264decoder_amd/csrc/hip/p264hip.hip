@@ -109,7 +109,7 @@ struct p264hip_ctx {
     uint8_t *d_planar = nullptr;           // planar staging for p264hip_read_frame / p264hip_write_frame
     std::vector<uint8_t *> planar_pool;    // p264hip_frame_planar_device: planar I420 frames that stay on the device
     // tuning knobs, read from the environment ONCE (p264hip_create); 0 = built-in choice
-    int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0, tune_bs_fused = -1;
+    int tune_mc_wgs = 0, tune_intra_waves = 0, tune_rb_log2 = 0, tune_pics_per_wg = 0, tune_db_waves = 0, tune_bs_fused = -1, tune_odd_single = -1;
     p264hip_launch_info_t last = {};       // what the last p264hip_reconstruct launched
     hipEvent_t markers[P264HIP_MARKERS] = {};
     int next_marker = 0;
@@ -167,6 +167,7 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     if (const char *env = getenv("P264AMD_MC_WGS_PER_PIC")) c->tune_mc_wgs = atoi(env);
     if (const char *env = getenv("P264AMD_INTRA_WAVES")) c->tune_intra_waves = atoi(env);
     if (const char *env = getenv("P264AMD_DEBLOCK_RB_LOG2")) c->tune_rb_log2 = atoi(env);
+    if (const char *env = getenv("P264AMD_DEBLOCK_ODD_SINGLE")) c->tune_odd_single = atoi(env) != 0;   /* 0: never, 1: whenever the shape allows it */
     if (const char *env = getenv("P264AMD_DEBLOCK_PICS_PER_WG")) c->tune_pics_per_wg = atoi(env);
     if (const char *env = getenv("P264AMD_DEBLOCK_WAVES")) c->tune_db_waves = atoi(env);
     if (const char *env = getenv("P264AMD_BS_FUSED")) { c->tune_bs_fused = atoi(env); if (c->tune_bs_fused > 16) c->tune_bs_fused = 16; }   // 0: own launch; n: n edge-info workgroups per picture in the k_intra_sparse launch
@@ -614,15 +615,21 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
             return bands * groups * (long)(g.mb_w + 1 + 2 * (rows - 1));
         };
         int rb_log2 = units_cost(3) < units_cost(2) ? 3 : 2;
-        if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) rb_log2 = c->tune_rb_log2;
-        if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= MAX_PICS_PER_WG) per_wg = c->tune_pics_per_wg;
+        // an odd number (>= 3) of pictures: the pairs in bands of 4 rows, the last picture alone in bands of 8 (k_deblock, odd_single)
+        const long cost_mixed = (per_wg >= 3 && (per_wg & 1)) ? ((g.mb_h + 3) / 4) * (long)(per_wg / 2) * (g.mb_w + 7) + ((g.mb_h + 7) / 8) * (long)(g.mb_w + 15) : -1;
+        int odd_single = cost_mixed >= 0 && cost_mixed < units_cost(rb_log2);
+        if (odd_single) rb_log2 = 2;
+        if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) { rb_log2 = c->tune_rb_log2; odd_single = 0; }
+        if (c->tune_pics_per_wg >= 1 && c->tune_pics_per_wg <= MAX_PICS_PER_WG) { per_wg = c->tune_pics_per_wg; odd_single = 0; }
+        if (c->tune_odd_single >= 0) odd_single = c->tune_odd_single && rb_log2 == 2 && per_wg >= 3 && (per_wg & 1);
         const int n_bands = (g.mb_h + (1 << rb_log2) - 1) >> rb_log2;
-        const int n_units = n_bands * ((per_wg + (8 >> rb_log2) - 1) / (8 >> rb_log2));
+        const int n_units = !odd_single ? n_bands * ((per_wg + (8 >> rb_log2) - 1) / (8 >> rb_log2)) : n_bands * (per_wg / 2) + (g.mb_h + 7) / 8;
         int waves = n_units < ROW_WAVES ? n_units : ROW_WAVES;
         if (c->tune_db_waves >= 1 && c->tune_db_waves < waves) waves = c->tune_db_waves;
         li.deblock_pics_per_wg = per_wg; li.deblock_rb_log2 = rb_log2; li.deblock_waves = waves; li.deblock_wgs = (n + per_wg - 1) / per_wg;
+        li.deblock_odd_single = odd_single;
         hipLaunchKernelGGL(k_deblock, dim3((n + per_wg - 1) / per_wg), dim3(waves * 64), 0, c->stream, c->d_batch[r], g,
-                           (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2, per_wg);
+                           (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2, per_wg, odd_single);
     }
     HIPCHK(hipGetLastError());
     ++c->epoch;

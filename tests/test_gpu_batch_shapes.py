@@ -42,6 +42,58 @@ def test_workgroup_shapes(lib, oracle, case, rb, per_wg, intra_waves, monkeypatc
     hip.close()
 
 
+@pytest.mark.parametrize("per_wg,S", [("3", 7), ("5", 11), ("7", 7), ("13", 14)])
+@pytest.mark.parametrize("case", ["cif_ip", "col_Nx1", "wide_70", "dense", "qpdelta"])
+def test_odd_picture_counts_as_pairs_and_a_single(lib, oracle, case, per_wg, S, monkeypatch):
+    """An odd number of pictures per k_deblock workgroup (what a batch of 3 / 5 / 7 pictures per compute unit selects by itself):
+    the pictures in pairs through bands of 4 rows and the last one alone through bands of 8 (odd_single) - unit order, band
+    numbering and progress counters of two shapes in one workgroup; picture heights with an odd and an even number of 4-row
+    bands; the last workgroup partly empty."""
+    monkeypatch.setenv("P264AMD_DEBLOCK_RB_LOG2", "2")
+    monkeypatch.setenv("P264AMD_DEBLOCK_PICS_PER_WG", per_wg)
+    monkeypatch.setenv("P264AMD_DEBLOCK_ODD_SINGLE", "1")
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes(case))[:6]
+    mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+    store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+    hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=parser.slots, max_pictures=len(pics), lib=lib)
+    hip.upload(0, pics)
+    for i, p in enumerate(pics):
+        want = oracle_bind.reconstruct(oracle, store, p)
+        hip.reconstruct([i] * S, list(range(S)))
+        li = hip.last_launch()
+        assert li["deblock_odd_single"] == 1 and li["deblock_rb_log2"] == 2 and li["deblock_pics_per_wg"] == int(per_wg), li
+        for s in range(S):
+            got = hip.read_frame(s, p.desc.dst_slot)
+            for plane, (a, b) in enumerate(zip(got, want)):
+                assert np.array_equal(a, b), "%s, %s pictures per workgroup: picture %d stream %d plane %d differs" % (case, per_wg, i, s, plane)
+    hip.close()
+
+
+def test_odd_picture_counts_at_1080p(lib, oracle, monkeypatch):
+    """The same at the bench's picture size: three and five 1080p pictures in one workgroup (17 bands of 4 rows per pair, 9 bands
+    of 8 rows for the single picture: more units than wavefronts)."""
+    monkeypatch.setenv("P264AMD_DEBLOCK_RB_LOG2", "2")
+    monkeypatch.setenv("P264AMD_DEBLOCK_ODD_SINGLE", "1")
+    for per_wg, S in (("3", 3), ("5", 6)):
+        monkeypatch.setenv("P264AMD_DEBLOCK_PICS_PER_WG", per_wg)
+        parser = Parser(quiet=True, lib=lib)
+        pics = parser.parse_stream(synth_cases.stream_bytes("cfg3_1080p_allp"))[:3]
+        mb_w, mb_h = pics[0].mb_w, pics[0].mb_h
+        store = oracle_bind.FrameStore(mb_w, mb_h, parser.slots)
+        hip = HipReconstructor(mb_w, mb_h, n_streams=S, slots=parser.slots, max_pictures=len(pics), lib=lib)
+        hip.upload(0, pics)
+        for i, p in enumerate(pics):
+            want = oracle_bind.reconstruct(oracle, store, p)
+            hip.reconstruct([i] * S, list(range(S)))
+            assert hip.last_launch()["deblock_odd_single"] == 1
+            for s in range(S):
+                got = hip.read_frame(s, p.desc.dst_slot)
+                for plane, (a, b) in enumerate(zip(got, want)):
+                    assert np.array_equal(a, b), "%s pictures per workgroup: picture %d stream %d plane %d differs" % (per_wg, i, s, plane)
+        hip.close()
+
+
 @pytest.mark.parametrize("fused", ["0", "1", "3", "16"])
 @pytest.mark.parametrize("case", ["cif_ip", "qpdelta", "wide_70"])
 def test_edge_info_inside_the_intra_launch_or_on_its_own(lib, oracle, case, fused, monkeypatch):

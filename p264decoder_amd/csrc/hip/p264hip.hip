@@ -556,7 +556,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         // one launch for luma / chroma, macroblock / quadrant items (k_mc): every picture gets the same number of workgroups,
         // which split into the four roles on the device.  Enough workgroups per picture to fill the chip a few times over,
         // no more than there can be chunks (four wavefronts per workgroup, one chunk per wavefront pass).
-        int wgs = (c->n_cu * 192 + n - 1) / n;
+        int wgs = (c->n_cu * 48 + n - 1) / n;   // (a dozen rounds of workgroups on small batches.  Round 5, 256 pictures per launch: 48 / 64 / 96 / 128 / 192 / 256
+                                           //  per picture -> 0.685 / 0.687 / 0.691 / 0.704 / 0.724 / 0.751 ms for the stage - a wavefront's first chunk has no prefetch)
         if (wgs < 48) wgs = 48;            // (2048 pictures: 24 / 32 / 48 / 64 / 96 per picture -> 5.34 / 5.31 / 5.24 / 5.31 / 5.34 ms; with 24 the stage's reads grew by half:
                                            //  a picture's roles drift apart and stop sharing reference lines in L2)
         int max_wgs = 0;

@@ -4,11 +4,14 @@
 // One context = one GPU = one HIP stream.  The product has no CPU reconstruction path: when no
 // device is usable every entry point fails with P264HIP_ENODEV.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 #include "p264hip.h"
 #include "device_common.h"
 #include "kernel_deblock.h"
@@ -395,14 +398,54 @@ extern "C" int p264hip_upload_async(p264hip_ctx *c, int slot, const p264hip_pict
     return upload_one(c, slot, pic);
 }
 
+// Host buffers the device reads by DMA (the parsers write their pictures into them: p264parse_set_allocator).  Ordinary pages,
+// advised as huge pages where the buffer is large, touched and then pinned with hipHostRegister - NOT hipHostMalloc: round 5
+// found the parser threads 36 % slower on hipHostMalloc'ed buffers with or without a device at work (7.0 s against 5.15 s per 3 072
+// 1080p pictures on 16 threads; registered 4 KB pages 5.7 s, registered huge pages 5.55 s, scratch/r5_pipe2.sh / r5_pipe3.sh) - the
+// parser reads its own output back all the time (neighbour vectors, coefficient counts) through 4 KB translations.  The
+// end-to-end pipeline went from 6.5 - 6.9 k to 8.3 k frames/s.  P264AMD_HOST_ALLOC = 0 (hipHostMalloc, coherent) / 1
+// (non-coherent) / 2 (registered 4 KB pages) / 3 (the default) stay as a knob for the experiment.
+static std::mutex g_host_mu;
+static std::unordered_map<void *, int> g_host_registered;     // pointers from posix_memalign + hipHostRegister
+static int host_alloc_mode()
+{
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("P264AMD_HOST_ALLOC"); int m = e ? atoi(e) : 3; mode = (m < 0 || m > 3) ? 3 : m; }
+    return mode;
+}
 extern "C" void *p264hip_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+    const size_t n = bytes ? bytes : 1;
+    const int mode = host_alloc_mode();
+    if (mode >= 2) {
+        const bool huge = mode == 3 && n >= ((size_t)256 << 10);
+        const size_t al = huge ? ((size_t)2 << 20) : 4096, rounded = (n + al - 1) & ~(al - 1);
+        if (posix_memalign(&p, al, rounded) == 0) {
+            if (huge) (void)madvise(p, rounded, MADV_HUGEPAGE);
+            for (size_t o = 0; o < rounded; o += 4096) ((volatile char *)p)[o] = 0;          // (faulted in before they are pinned)
+            if (hipHostRegister(p, rounded, hipHostRegisterPortable) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(g_host_mu);
+                g_host_registered[p] = 1;
+                return p;
+            }
+            (void)hipGetLastError();
+            free(p); p = nullptr;
+        }
+        // (could not be registered: pinned memory of the runtime's own)
+    }
+    if (hipHostMalloc(&p, n, hipHostMallocPortable | (mode == 1 ? hipHostMallocNonCoherent : 0)) != hipSuccess) return nullptr;
     return p;
 }
 
-extern "C" void p264hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" void p264hip_host_free(void *p)
+{
+    if (!p) return;
+    bool registered;
+    { std::lock_guard<std::mutex> lk(g_host_mu); registered = g_host_registered.erase(p) != 0; }
+    if (registered) { (void)hipHostUnregister(p); free(p); }
+    else (void)hipHostFree(p);
+}
 
 extern "C" int p264hip_marker(p264hip_ctx *c)
 {

@@ -118,7 +118,9 @@ p264pipe *p264pipe_open(int device, int n_streams, int n_threads)
     for (int i = 0; i < n_streams; i++) {
         p->st[i].parser = p264parse_open(P264PARSE_OPT_QUIET);
         if (!p->st[i].parser) { p264pipe_close(p); return NULL; }
-        if (device >= 0) p264parse_set_allocator(p->st[i].parser, p264hip_host_alloc, p264hip_host_free);
+        /* picture buffers in pinned host memory when they are uploaded (P264AMD_PIPE_PINNED=0 / 1 forces either kind: experiments) */
+        const char *pin = getenv("P264AMD_PIPE_PINNED");
+        if (pin ? atoi(pin) != 0 : device >= 0) p264parse_set_allocator(p->st[i].parser, p264hip_host_alloc, p264hip_host_free);
         p->st[i].last_slot = -1;
     }
     for (int i = 0; i < p->n_threads; i++) {
@@ -146,11 +148,11 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
     if (!ids || !sts || !pics) { free(ids); free(sts); free(pics); return -1; }
     int markers[2] = { -1, -1 }, rounds = 0, rc = 0;
     int64_t pictures = 0, uploaded = 0;
-    double submit = 0;
+    double submit = 0, wait_parse = 0, wait_gpu = 0;          /* (the main thread's waits: P264AMD_PIPE_DEBUG=1 prints them) */
     const double t0 = now_s();
     start_round(p);                                          /* round 0 */
     for (int r = 0;; r++) {
-        finish_round(p);
+        { const double w0 = now_s(); finish_round(p); wait_parse += now_s() - w0; }
         int n = 0;
         for (int i = 0; i < p->n_streams; i++) {
             pstream_t *s = &p->st[i];
@@ -166,7 +168,9 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
             }
         }
         /* the parsers are about to overwrite the buffers of round r-1: its uploads must have been consumed */
-        if (p->ctx && markers[(r + 1) & 1] >= 0 && p264hip_marker_wait(p->ctx, markers[(r + 1) & 1])) { rc = -1; break; }
+        { const double w0 = now_s();
+          if (p->ctx && markers[(r + 1) & 1] >= 0 && p264hip_marker_wait(p->ctx, markers[(r + 1) & 1])) { rc = -1; break; }
+          wait_gpu += now_s() - w0; }
         start_round(p);                                      /* round r+1 parses while round r is submitted and runs */
         if (p->ctx) {
             const double s0 = now_s();
@@ -183,6 +187,9 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
     }
     if (p->ctx && p264hip_sync(p->ctx)) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
     const double t1 = now_s();
+    if (getenv("P264AMD_PIPE_DEBUG"))
+        fprintf(stderr, "p264pipe_run: %d rounds, %.3f s: main thread waited %.3f s for the parsers, %.3f s for the device, submitted for %.3f s; parser threads %.3f s in all (%d threads)\n",
+                rounds, t1 - t0, wait_parse, wait_gpu, submit, p->parse_seconds, p->n_threads);
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->pictures = pictures; stats->seconds = t1 - t0; stats->parse_seconds = p->parse_seconds; stats->submit_seconds = submit;

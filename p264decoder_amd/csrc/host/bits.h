@@ -17,8 +17,9 @@ typedef struct {
     size_t   pos;       /* next byte to load into the window */
     uint64_t win;       /* bits are left-aligned: next bit is bit 63 */
     int      avail;     /* valid bits in win */
-    size_t   consumed;  /* total bits consumed */
 } bitrd_t;
+/* total bits consumed: every loaded byte adds 8 to both terms (not counted per skip: one add less in the hottest function) */
+static inline size_t br_consumed(const bitrd_t *b) { return b->pos * 8 - (size_t)b->avail; }
 
 static inline void br_refill(bitrd_t *b)
 {
@@ -42,7 +43,7 @@ static inline void br_refill(bitrd_t *b)
 
 static inline void br_init(bitrd_t *b, const uint8_t *buf, size_t size)
 {
-    b->buf = buf; b->size = size; b->pos = 0; b->win = 0; b->avail = 0; b->consumed = 0;
+    b->buf = buf; b->size = size; b->pos = 0; b->win = 0; b->avail = 0;
     br_refill(b);
 }
 
@@ -51,7 +52,7 @@ static inline uint32_t br_peek(bitrd_t *b, int n) { return (uint32_t)(b->win >> 
 
 static inline void br_skip(bitrd_t *b, int n)
 {
-    b->win <<= n; b->avail -= n; b->consumed += (size_t)n;
+    b->win <<= n; b->avail -= n;
     br_refill(b);
 }
 
@@ -66,10 +67,10 @@ static inline uint32_t br_u(bitrd_t *b, int n)
 static inline uint32_t br_u1(bitrd_t *b) { return br_u(b, 1); }
 
 /* bits left in the buffer (may go negative after an over-read) */
-static inline long br_bits_left(const bitrd_t *b) { return (long)(b->size * 8) - (long)b->consumed; }
-static inline int  br_overrun(const bitrd_t *b)   { return b->consumed > b->size * 8; }
+static inline long br_bits_left(const bitrd_t *b) { return (long)(b->size * 8) - (long)br_consumed(b); }
+static inline int  br_overrun(const bitrd_t *b)   { return br_consumed(b) > b->size * 8; }
 /* mirrors bs_eof (core/bs.h:63-66): true once the byte cursor reached the end */
-static inline int  br_eof(const bitrd_t *b)       { return (b->consumed >> 3) >= b->size; }
+static inline int  br_eof(const bitrd_t *b)       { return (br_consumed(b) >> 3) >= b->size; }
 
 static inline uint32_t br_ue(bitrd_t *b)
 {

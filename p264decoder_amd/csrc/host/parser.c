@@ -1269,7 +1269,7 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
         /* slice_data( ) with CABAC (7.3.4): alignment bits, the engine started on the next byte, contexts from the slice QP;
          * per macroblock mb_skip_flag (P / B), the macroblock, end_of_slice_flag */
         if (!p->cinfo) { ERR(p, "CABAC slice without its context storage (Baseline parameter set)"); return -1; }
-        const size_t at = (size_t)((b.consumed + 7) >> 3);
+        const size_t at = (size_t)((br_consumed(&b) + 7) >> 3);
         if (at >= (size_t)size) { ERR(p, "CABAC slice without data"); return -1; }
         p264cabac_init_contexts(&p->cb, sh.type == P264_SLICE_I, sh.cabac_init_idc, sh.qp);
         p264cabac_start(&p->cb, payload + at, (size_t)size - at);
@@ -1290,7 +1290,7 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
     p->skip_run = -1;
     while (p->next_mb < p->n_mb) {
         p->mbi = p->next_mb; p->mbx = p->mbi % p->mb_w; p->mby = p->mbi / p->mb_w;
-        if (p->skip_run <= 0 && (long)b.consumed >= stop) break;   /* !more_rbsp_data(): the slice ends here */
+        if (p->skip_run <= 0 && (long)br_consumed(&b) >= stop) break;   /* !more_rbsp_data(): the slice ends here */
         if (sh.type != P264_SLICE_I && p->skip_run < 0) {
             p->skip_run = (int)br_ue(&b);
             if (p->skip_run > p->n_mb - p->next_mb) { ERR(p, "mb_skip_run %d runs past the picture", p->skip_run); p->pic_open = 0; return -1; }
@@ -1299,7 +1299,7 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
             if (sh.type == P264_SLICE_B) decode_bskip(p); else decode_pskip(p);
             p->skip_run--;
         } else {
-            if ((long)b.consumed >= stop) break;
+            if ((long)br_consumed(&b) >= stop) break;
             if (parse_mb(p, &b) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
             p->skip_run = -1;
         }

@@ -8,8 +8,8 @@ S2=$(python3 -c "
 from tests import synth_cases
 print(synth_cases.generate(synth_cases.ORACLE_CASES['main_1080p_cabac_ipb']))")
 build() { # dir of host sources, output
-  for f in parser vlc cabac dropin pipeline fanout input_layout; do gcc -O2 -std=gnu11 -I$R/include -I$1 -c $1/$f.c -o /tmp/$f.o || exit 1; done
-  gcc -O2 -I$R/include -c $R/tests/tools/hip_stub.c -o /tmp/stub.o; gcc -O2 -I$R/include $R/scratch/pg/drv.c /tmp/parser.o /tmp/vlc.o /tmp/cabac.o /tmp/dropin.o /tmp/pipeline.o /tmp/fanout.o /tmp/input_layout.o /tmp/stub.o -o $2 -lpthread -ldl 2>/dev/null
+  for f in parser vlc cabac dropin pipeline fanout input_layout; do gcc -O3 -std=gnu11 -fPIC -I$R/include -I$1 -c $1/$f.c -o /tmp/$f.o || exit 1; done
+  gcc -O2 -I$R/include -c $R/tests/tools/hip_stub.c -o /tmp/stub.o; gcc -O3 -I$R/include $R/scratch/pg/drv.c /tmp/parser.o /tmp/vlc.o /tmp/cabac.o /tmp/dropin.o /tmp/pipeline.o /tmp/fanout.o /tmp/input_layout.o /tmp/stub.o -o $2 -lpthread -ldl 2>/dev/null
 }
 build $R/scratch/pg/old /tmp/drv_old; build $R/p264decoder_amd/csrc/host /tmp/drv_new
 for i in 1 2 3; do echo -n "old: "; /tmp/drv_old $S 15; echo -n "new: "; /tmp/drv_new $S 15; done

@@ -132,7 +132,9 @@ int  p264hip_upload(p264hip_ctx *ctx, int first, const p264hip_picture_t *pics, 
  * a marker taken after this call has been reached (p264hip_marker / p264hip_marker_wait) or p264hip_sync returns;
  * they should live in pinned memory (p264hip_host_alloc) for the copies to be real DMA transfers. */
 int  p264hip_upload_async(p264hip_ctx *ctx, int slot, const p264hip_picture_t *pic);
-/* Pinned host memory for picture inputs (hipHostMalloc); usable without a context. */
+/* Pinned host memory for picture inputs and frame downloads; usable without a context.  Ordinary (huge) pages registered with
+ * the runtime - the CPU writes and re-reads them at full speed, which it does not on hipHostMalloc'ed memory;
+ * P264AMD_HOST_ALLOC = 0 gives hipHostMalloc back. */
 void *p264hip_host_alloc(size_t bytes);
 void  p264hip_host_free(void *p);
 /* A marker is a point in the context's stream; marker_wait blocks the calling host thread until everything

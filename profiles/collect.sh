@@ -9,10 +9,12 @@ tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BENCH="bench.py --steps 3 --warmup 1 --no-extras"
-BENCH_FULL="bench.py"
+# STREAMS=<n>: the same passes at n pictures per launch (e.g. SURVEY 8d's batch: STREAMS=256 bash profiles/collect.sh r05_b256)
+S=${STREAMS:+--streams $STREAMS}
+BENCH="bench.py --steps 3 --warmup 1 --no-extras $S"
+BENCH_FULL="bench.py $S"
 echo "[collect] bench" | tee $out/progress.log
-python3 bench.py > $out/bench.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
+python3 bench.py $S ${STREAMS:+--no-extras} > $out/bench.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
 echo "[collect] kernel trace" | tee -a $out/progress.log
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $BENCH_FULL --no-cpu-baseline --no-extras > $out/trace.log 2>&1 || { echo "trace failed"; tail -5 $out/trace.log; exit 1; }
 i=0

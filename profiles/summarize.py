@@ -55,6 +55,9 @@ bs_own_launch = any(k.startswith("k_deblock_bs") and pmc[k].get("launches_averag
 traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra_sparse" if "k_intra_sparse" in pmc else "k_intra"), "deblock": hbm_any("k_deblock") if bs_own_launch else hbm("k_deblock"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
 traffic["pictures_per_launch"] = int(json.load(open(os.path.join(here, tag + "_bench.json")))["config"]["pictures_per_step"])   # bench.py's default batch, which collect.sh profiles
-json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)
+if "--no-latest" in sys.argv:                              # (a profile of another batch size: its own file, bench.py's roofline keeps the default batch's)
+    json.dump(traffic, open(os.path.join(here, tag + "_traffic.json"), "w"), indent=1)
+else:
+    json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(traffic))
 print(open(os.path.join(here, tag + "_kernel_stats.csv")).read())

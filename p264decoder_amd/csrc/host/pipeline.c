@@ -1,14 +1,17 @@
 /* pipeline.c - multi-stream, multi-threaded decode pipeline on top of the two C ABIs
  * (p264parse.h: host bitstream layer, p264hip.h: MI355X reconstruction).  See include/p264pipe.h.
  *
- * Round r: every stream that still has data gets its next picture parsed (threads pull streams from a shared
- * counter); when all are done the main thread hands the picture descriptors to the GPU - asynchronous uploads
- * out of the parsers' pinned double buffers, one batched reconstruct - and immediately releases the threads
- * into round r+1.  A parser reuses the buffers of round r-1 in round r+1, so before releasing the threads
- * the main thread waits for the marker taken after round r-1's uploads: the only host-side wait on the device.
+ * Round r = the next picture of every stream that still has data.  The parser threads pull (round, stream) tasks from one
+ * running counter and do NOT stop at the end of a round (round 5; until then they met at a barrier per round and the
+ * stragglers of every round cost 4 - 8 % of 16 threads): a task of round R may start once the stream's picture of round R - 1 is
+ * parsed and the device has finished with round R - 2, whose buffers the parser is about to reuse (it has two per stream).
+ * The main thread waits for the last task of round r, hands the pictures to the GPU - asynchronous uploads out of the parsers'
+ * pinned double buffers, one batched reconstruct - and waits for the marker behind them: by then the threads are well into
+ * round r + 1, and that wait is what lets them into round r + 2.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,10 +34,18 @@ struct p264pipe {
     int device, n_streams, n_threads;
     pstream_t *st;
     p264hip_ctx *ctx; int mb_w, mb_h, slots;
-    /* thread pool: generation counter + two condition variables */
+    /* thread pool */
     pthread_t *threads; int started;
     pthread_mutex_t mu; pthread_cond_t go, idle;
-    int generation, busy, quit, next_stream, max_pictures;
+    int generation, busy, quit, max_pictures;
+    /* one run: tasks t = round * n_streams + stream, taken in order */
+    long long next_task;                 /* (atomic) */
+    int done_rounds;                     /* rounds the device has finished with (under mu; waited for through `go`) */
+    int stop;                            /* (atomic) no more tasks */
+    int *parsed;                         /* [stream] rounds parsed so far (atomic) */
+    int parsed_in_round[2];              /* tasks finished per round parity (under mu; its last one signals `idle`) */
+    int failed_in_round[2];              /* a task of the round failed (under mu) */
+    const p264hip_picture_t **round_pic[2];  /* [round parity][stream]: the picture a round's task produced, or NULL */
     double parse_seconds;
 };
 
@@ -50,13 +61,13 @@ static void parse_one(p264pipe *p, pstream_t *s)
         if (len < 1) continue;
         if (len + 8 > s->rbsp_cap) {
             free(s->rbsp); s->rbsp_cap = len * 2 + 64; s->rbsp = (uint8_t *)malloc((size_t)s->rbsp_cap);
-            if (!s->rbsp) { s->failed = 1; s->done = 1; return; }
+            if (!s->rbsp) { __atomic_store_n(&s->failed, 1, __ATOMIC_RELAXED); s->done = 1; return; }
         }
         p264_nal_t nal; nal.p_payload = s->rbsp;
         p264_nal_decode(&nal, (void *)(s->in + off), (int)len);
         const p264hip_picture_t *pic = NULL;
         int rc = p264parse_nal(s->parser, nal.i_type, nal.i_ref_idc, nal.p_payload, nal.i_payload, &pic);
-        if (rc < 0) { s->failed = 1; s->done = 1; return; }
+        if (rc < 0) { __atomic_store_n(&s->failed, 1, __ATOMIC_RELAXED); s->done = 1; return; }
         if (rc == 1) { s->pic = pic; s->pictures++; return; }
     }
     s->done = 1;
@@ -73,31 +84,70 @@ static void *worker(void *arg)
         seen = p->generation;
         pthread_mutex_unlock(&p->mu);
         double spent = 0;
-        for (;;) {
-            int i = __atomic_fetch_add(&p->next_stream, 1, __ATOMIC_RELAXED);
-            if (i >= p->n_streams) break;
+        const int S = p->n_streams;
+        while (!__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) {
+            const long long t = __atomic_fetch_add(&p->next_task, 1, __ATOMIC_RELAXED);
+            const int R = (int)(t / S), s = (int)(t % S);
+            /* the device is done with round R - 2 (whose buffers this task writes) */
+            pthread_mutex_lock(&p->mu);
+            while (R > p->done_rounds + 1 && !p->stop) pthread_cond_wait(&p->go, &p->mu);
+            pthread_mutex_unlock(&p->mu);
+            if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) break;
+            /* the stream's previous picture is parsed (tasks are taken in order, so it nearly always is: a parser is not reentrant) */
+            while (__atomic_load_n(&p->parsed[s], __ATOMIC_ACQUIRE) < R && !__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) sched_yield();
+            if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) break;
             double t0 = now_s();
-            parse_one(p, &p->st[i]);
+            parse_one(p, &p->st[s]);
             spent += now_s() - t0;
+            p->round_pic[R & 1][s] = p->st[s].pic;
+            __atomic_store_n(&p->parsed[s], R + 1, __ATOMIC_RELEASE);
+            const int failed = __atomic_load_n(&p->st[s].failed, __ATOMIC_RELAXED);
+            pthread_mutex_lock(&p->mu);
+            if (failed) p->failed_in_round[R & 1] = 1;
+            if (++p->parsed_in_round[R & 1] == S) pthread_cond_signal(&p->idle);
+            pthread_mutex_unlock(&p->mu);
         }
         pthread_mutex_lock(&p->mu);
         p->parse_seconds += spent;
-        if (--p->busy == 0) pthread_cond_signal(&p->idle);
+        if (--p->busy == 0) pthread_cond_broadcast(&p->idle);
         pthread_mutex_unlock(&p->mu);
     }
 }
 
-static void start_round(p264pipe *p)
+/* release the threads into a run / end it and wait until every thread has left its task loop */
+static void start_run(p264pipe *p)
 {
     pthread_mutex_lock(&p->mu);
-    p->next_stream = 0; p->busy = p->n_threads; p->generation++;
+    p->next_task = 0; p->done_rounds = 0; p->stop = 0; p->parsed_in_round[0] = p->parsed_in_round[1] = 0; p->failed_in_round[0] = p->failed_in_round[1] = 0;
+    memset(p->parsed, 0, sizeof(int) * (size_t)p->n_streams);
+    p->busy = p->n_threads; p->generation++;
     pthread_cond_broadcast(&p->go);
     pthread_mutex_unlock(&p->mu);
 }
-static void finish_round(p264pipe *p)
+static void end_run(p264pipe *p)
 {
     pthread_mutex_lock(&p->mu);
+    __atomic_store_n(&p->stop, 1, __ATOMIC_RELEASE);
+    pthread_cond_broadcast(&p->go);
     while (p->busy) pthread_cond_wait(&p->idle, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+/* wait for the last task of round r; returns whether one of them failed */
+static int finish_round(p264pipe *p, int r)
+{
+    pthread_mutex_lock(&p->mu);
+    while (p->parsed_in_round[r & 1] < p->n_streams) pthread_cond_wait(&p->idle, &p->mu);
+    const int failed = p->failed_in_round[r & 1];
+    p->parsed_in_round[r & 1] = 0; p->failed_in_round[r & 1] = 0;   /* (nobody starts round r + 2 before round r is through the device) */
+    pthread_mutex_unlock(&p->mu);
+    return failed;
+}
+/* the device has finished with rounds 0 .. r: the threads may start round r + 2 */
+static void rounds_done(p264pipe *p, int r)
+{
+    pthread_mutex_lock(&p->mu);
+    p->done_rounds = r + 1;
+    pthread_cond_broadcast(&p->go);
     pthread_mutex_unlock(&p->mu);
 }
 
@@ -113,8 +163,11 @@ p264pipe *p264pipe_open(int device, int n_streams, int n_threads)
     p->device = device; p->n_streams = n_streams; p->n_threads = n_threads < n_streams ? n_threads : n_streams;
     p->st = (pstream_t *)calloc((size_t)n_streams, sizeof *p->st);
     p->threads = (pthread_t *)calloc((size_t)p->n_threads, sizeof *p->threads);
+    p->parsed = (int *)calloc((size_t)n_streams, sizeof(int));
+    p->round_pic[0] = (const p264hip_picture_t **)calloc((size_t)n_streams, sizeof(void *));
+    p->round_pic[1] = (const p264hip_picture_t **)calloc((size_t)n_streams, sizeof(void *));
     pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->idle, NULL);
-    if (!p->st || !p->threads) { p264pipe_close(p); return NULL; }
+    if (!p->st || !p->threads || !p->parsed || !p->round_pic[0] || !p->round_pic[1]) { p264pipe_close(p); return NULL; }
     for (int i = 0; i < n_streams; i++) {
         p->st[i].parser = p264parse_open(P264PARSE_OPT_QUIET);
         if (!p->st[i].parser) { p264pipe_close(p); return NULL; }
@@ -146,18 +199,18 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
     int *ids = (int *)malloc(sizeof(int) * (size_t)p->n_streams), *sts = (int *)malloc(sizeof(int) * (size_t)p->n_streams);
     const p264hip_picture_t **pics = (const p264hip_picture_t **)malloc(sizeof(void *) * (size_t)p->n_streams);
     if (!ids || !sts || !pics) { free(ids); free(sts); free(pics); return -1; }
-    int markers[2] = { -1, -1 }, rounds = 0, rc = 0;
+    int rounds = 0, rc = 0;
     int64_t pictures = 0, uploaded = 0;
     double submit = 0, wait_parse = 0, wait_gpu = 0;          /* (the main thread's waits: P264AMD_PIPE_DEBUG=1 prints them) */
     const double t0 = now_s();
-    start_round(p);                                          /* round 0 */
+    start_run(p);
     for (int r = 0;; r++) {
-        { const double w0 = now_s(); finish_round(p); wait_parse += now_s() - w0; }
+        { const double w0 = now_s(); if (finish_round(p, r)) rc = -1; wait_parse += now_s() - w0; }
         int n = 0;
         for (int i = 0; i < p->n_streams; i++) {
             pstream_t *s = &p->st[i];
-            if (s->failed) rc = -1;
-            if (s->pic) { pics[n] = s->pic; sts[n] = i; ids[n] = i * 2 + (r & 1); s->last_slot = s->pic->dst_slot; n++; }
+            const p264hip_picture_t *pic = p->round_pic[r & 1][i];
+            if (pic) { pics[n] = pic; sts[n] = i; ids[n] = i * 2 + (r & 1); s->last_slot = pic->dst_slot; n++; }
         }
         if (n == 0 || rc) break;
         rounds++; pictures += n;
@@ -167,11 +220,6 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
                 fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; break;
             }
         }
-        /* the parsers are about to overwrite the buffers of round r-1: its uploads must have been consumed */
-        { const double w0 = now_s();
-          if (p->ctx && markers[(r + 1) & 1] >= 0 && p264hip_marker_wait(p->ctx, markers[(r + 1) & 1])) { rc = -1; break; }
-          wait_gpu += now_s() - w0; }
-        start_round(p);                                      /* round r+1 parses while round r is submitted and runs */
         if (p->ctx) {
             const double s0 = now_s();
             for (int k = 0; k < n && !rc; k++) {
@@ -180,11 +228,18 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
                 else uploaded += (int64_t)p->mb_w * p->mb_h * (16 + 64 + 4 + 16) + (int64_t)pics[k]->n_coef_blocks * 32;
             }
             if (!rc && p264hip_reconstruct(p->ctx, ids, sts, n)) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
-            if (!rc) { markers[r & 1] = p264hip_marker(p->ctx); if (markers[r & 1] < 0) rc = -1; }
+            int marker = -1;
+            if (!rc) { marker = p264hip_marker(p->ctx); if (marker < 0) rc = -1; }
             submit += now_s() - s0;
-            if (rc) { finish_round(p); break; }
+            if (rc) break;
+            /* the parsers reuse round r's buffers in round r + 2: its uploads must have been consumed (the threads are in round r + 1) */
+            const double w0 = now_s();
+            if (p264hip_marker_wait(p->ctx, marker)) { rc = -1; break; }
+            wait_gpu += now_s() - w0;
         }
+        rounds_done(p, r);
     }
+    end_run(p);
     if (p->ctx && p264hip_sync(p->ctx)) { fprintf(stderr, "p264pipe_run: %s\n", p264hip_last_error()); rc = -1; }
     const double t1 = now_s();
     if (getenv("P264AMD_PIPE_DEBUG"))
@@ -228,5 +283,6 @@ void p264pipe_close(p264pipe *p)
     if (p->st) for (int i = 0; i < p->n_streams; i++) { if (p->st[i].parser) p264parse_close(p->st[i].parser); free(p->st[i].rbsp); }
     if (p->ctx) p264hip_destroy(p->ctx);
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->idle);
+    free(p->parsed); free((void *)p->round_pic[0]); free((void *)p->round_pic[1]);
     free(p->st); free(p->threads); free(p);
 }

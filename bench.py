@@ -282,7 +282,7 @@ def extras(lib):
     try:
         from p264decoder_amd import Pipeline
         quota = cpu_quota()
-        distinct = [open(synth_cases.generate(synth_args(24, 1000 + g)), "rb").read() for g in range(4)]
+        distinct = [open(synth_cases.generate(synth_args(72, 1000 + g)), "rb").read() for g in range(4)]   # (72 pictures per stream: the context's creation behind the first round is 2 % of the run, not 7)
         n_streams = 128
 
         def run(threads, device):

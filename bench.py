@@ -589,9 +589,12 @@ def main():
                 names = {"inter": ("k_mc_sort", "k_mc"), "intra": ("k_intra_sparse",), "deblock": ("k_deblock",) if EDGE_INFO_FUSED else ("k_deblock", "k_deblock_bs<false>")}[stage]
                 insts = sum(int(pmc[k]["SQ_INSTS_VALU"]) for k in names)
                 prop = torch.cuda.get_device_properties(local_rank)
-                simds, hz = prop.multi_processor_count * 4, 2.4e9          # (hipDeviceProp_t.clockRate of the MI355X: 2400 MHz)
+                # (the clock under these kernels' load: 2.24 GHz by GRBM_GUI_ACTIVE / 8 XCDs / kernel time, scratch/r5_pmc2.sh - not the
+                # 2400 MHz of hipDeviceProp_t.clockRate, which rounds 1 - 4 had assumed)
+                simds, hz = prop.multi_processor_count * 4, 2.24e9
                 return {"wave_instructions_per_launch": insts, "issue_cycles_frac": round(insts * 4.0 / (kernels[stage]["avg_ms"] * 1e-3 * hz * simds), 3),
-                        "simds": simds, "clock_MHz": round(hz / 1e6), "source": "static: profiles/%s (SQ_INSTS_VALU), 4 cycles per wave instruction" % tj["source"]}
+                        "simds": simds, "clock_MHz": round(hz / 1e6), "clock_source": "measured under load in round 5 (GRBM_GUI_ACTIVE), static here",
+                        "source": "static: profiles/%s (SQ_INSTS_VALU), 4 cycles per wave instruction" % tj["source"]}
             except Exception:
                 return None
 

@@ -1,6 +1,8 @@
 """The multi-stream pipeline end to end on the MI355X: threaded parse into pinned buffers, asynchronous uploads, one
 batched reconstruction per round.  Streams of different content and length run side by side; the last picture of
 every stream must be the real reference decoder's (committed SHA-256)."""
+import os
+
 import pytest
 
 from p264decoder_amd import Pipeline
@@ -41,3 +43,39 @@ def test_pipeline_1080p(lib):
     for i in range(6):
         assert frame_sha256(*pipe.read_frame(i)) == hashes[9]
     pipe.close()
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
+def test_host_buffer_kinds(mode):
+    """The four kinds of host memory the parsers' picture buffers and the frame downloads can live in (P264AMD_HOST_ALLOC:
+    hipHostMalloc coherent / non-coherent, registered 4 KB pages, registered huge pages = the default since round 5): the same
+    pictures through the pipeline and through the drop-in API.  The kind is latched at the first allocation of a process, so
+    every kind gets a process of its own."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import hashlib, os, sys
+sys.path.insert(0, %r)
+from p264decoder_amd import Decoder, Pipeline
+from tests.conftest import frame_sha256
+data = open(%r, "rb").read()
+hashes = [l.split()[1] for l in open(%r) if l.strip()]
+pipe = Pipeline([data, data, data], threads=2, device=0)
+st = pipe.run(max_pictures=12)
+assert st["pictures"] == 36, st
+for s in range(3):
+    assert frame_sha256(*pipe.read_frame(s)) == hashes[11], "pipeline stream %%d" %% s
+pipe.close()
+dec = Decoder()
+n = 0
+for y, u, v in dec.decode_annexb(data):
+    assert frame_sha256(y, u, v) == hashes[n], "drop-in picture %%d" %% n
+    n += 1
+    if n == 6: break
+dec.close()
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests", "golden", "f26.264"), os.path.join(ROOT, "tests", "golden", "f26_frames.sha256"))
+    env = dict(os.environ, P264AMD_HOST_ALLOC=mode)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:]

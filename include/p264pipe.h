@@ -3,8 +3,9 @@
  * N Annex-B streams are decoded side by side: a pool of host threads runs the CAVLC parsers (one stream at a
  * time per thread, the part of the decoder that stays on the CPU), and the next picture of every stream goes to the
  * MI355X as ONE batch (p264hip_upload_async + p264hip_reconstruct).  The parsers write their picture arrays straight
- * into pinned memory, so the uploads are plain DMA; while the GPU works on round r the threads already parse round
- * r+1.  Output pictures stay in HBM (the frame stores of p264hip); p264pipe_read_frame fetches the last one of a
+ * into pinned memory (registered huge pages, p264hip_host_alloc), so the uploads are plain DMA; while the GPU works on round r
+ * the threads already parse round r+1 - they do not stop at the end of a round: a stream's next picture may be parsed as
+ * soon as its previous one is and the device has finished with the round before that (whose buffers the parser reuses).  Output pictures stay in HBM (the frame stores of p264hip); p264pipe_read_frame fetches the last one of a
  * stream.  There is no counterpart in the reference (its decoder is single-stream, single-threaded,
  * p264decoder.c:164-381); the per-stream behaviour is that of p264_decoder_decode.
  *

@@ -76,6 +76,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ AS1 T *glob(T *p) { return (AS1 T *)p; }
 __device__ __forceinline__ uint4 gload4(const void *p) { u32x4 v = *(const AS1 u32x4 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ uint3 gload3(const void *p) { u32x3 v = *(const AS1 u32x3 *)p; return make_uint3(v.x, v.y, v.z); }
 __device__ __forceinline__ uint2 gload2(const void *p) { u32x2 v = *(const AS1 u32x2 *)p; return make_uint2(v.x, v.y); }
 __device__ __forceinline__ uint2 gload2(const AS1 void *p) { u32x2 v = *(const AS1 u32x2 *)p; return make_uint2(v.x, v.y); }
 __device__ __forceinline__ uint32_t gload1(const void *p) { return *(const AS1 uint32_t *)p; }

@@ -91,13 +91,15 @@ __host__ __device__ static inline int mc_chunk_items(int l) { return l == ML_YM 
 __host__ __device__ static inline int mc_list_keys(int l) { return l < ML_CM ? MCY_KEYS : MCC_KEYS; }
 
 // Per-picture scratch written by k_mc_sort (32-bit words): [l] chunks in use of list l, then per list one class byte
-// per chunk, then the lists.  A list entry is 16 bytes: x = reference index << 28 | macroblock row << 13 | column << 2 |
-// quadrant (low 28 bits all ones = padding; no division in the consumers), y = the item's vector (packed), z = the macroblock's coded-block mask | QP << 26, w = its
-// place in the coefficient stream - all a wavefront needs to start fetching its windows AND its coded levels without
-// looking at the macroblock arrays (each look-up is a dependent memory round trip per wavefront).  Same layout for
-// every picture of a batch.
+// per chunk, then the lists.  A first-pass entry is 8 bytes: x = reference index << 28 | flags | macroblock row << 13 |
+// column << 2 | quadrant (low 28 bits all ones = padding; no division in the consumers), y = the item's vector (packed) -
+// all a wavefront needs to start fetching its windows; chunks with residual (a third of them in the bench's pictures) fetch
+// the macroblock's record for QP, coded-block mask and place in the coefficient stream, one chunk ahead (round 4 carried the
+// three in every entry: 16 bytes, written and read for all chunks, and the sort read the record a second time to fill them
+// in).  Second-pass entries (B pictures) stay 16 bytes: z = coded-block mask | QP << 26, w = place in the coefficient
+// stream | weight of the pair of references << 23.  Same layout for every picture of a batch.
 #define MC_ITEM_MASK 0x0fffffffu
-#define MC_ENTRY_WORDS 4u
+__host__ __device__ static inline uint32_t mc_entry_words(int pass) { return pass ? 4u : 2u; }
 struct McLayout {
     uint32_t band_log2, n_bands;
     uint32_t max_chunks[2 * ML_LISTS], off_cls[2 * ML_LISTS], off_list[2 * ML_LISTS], words;     // [pass * ML_LISTS + list]
@@ -116,7 +118,7 @@ static inline McLayout mc_layout(int mb_w, int mb_h, int band_log2)
         L.off_cls[l] = at; at += (L.max_chunks[l] + 3) / 4;
     }
     at = (at + 15) & ~15u;
-    for (int l = 0; l < 2 * ML_LISTS; l++) { L.off_list[l] = at; at += L.max_chunks[l] * (uint32_t)mc_chunk_items(l % ML_LISTS) * MC_ENTRY_WORDS; }
+    for (int l = 0; l < 2 * ML_LISTS; l++) { L.off_list[l] = at; at += L.max_chunks[l] * (uint32_t)mc_chunk_items(l % ML_LISTS) * mc_entry_words(l / ML_LISTS); }
     L.words = (at + 63) & ~63u;
     return L;
 }
@@ -159,11 +161,12 @@ struct McMb { uint32_t info, key[4], vec[4]; };
 #define MCMB_WHOLE 2u
 #define MCE_LIST1  (1u << 23)       // entry flag: the reference index counts in list 1
 #define MCE_KEEP   (1u << 24)       // entry flag (second pass, chroma quadrant entries): pass the samples through
+#define MCE_Z      (1u << 25)       // entry flag (first pass): no residual here - the second pass adds it
 #define MCE_W_SHIFT 23              // second pass: w = place in the coefficient stream | weight << 23
 __device__ __forceinline__ uint32_t mcmb_entry(const McMb &k, int mbx, int mby, int q, int pass)
 {
     const uint32_t l1 = (k.info >> (24 + q)) & 1u, z = (k.info >> (28 + q)) & 1u;
-    return ((k.info >> (8 + 4 * q)) & 15u) << 28 | (l1 ? MCE_LIST1 : 0u) | ((pass && z) ? MCE_KEEP : 0u) | (uint32_t)mby << 13 | (uint32_t)mbx << 2 | (uint32_t)q;
+    return ((k.info >> (8 + 4 * q)) & 15u) << 28 | (l1 ? MCE_LIST1 : 0u) | (z ? (pass ? MCE_KEEP : MCE_Z) : 0u) | (uint32_t)mby << 13 | (uint32_t)mbx << 2 | (uint32_t)q;
 }
 __device__ __forceinline__ bool quad_uniform(const uint4 &m0, const uint4 &m1, const uint4 &m2, const uint4 &m3, int q, uint32_t &v)
 {
@@ -325,34 +328,49 @@ __device__ __forceinline__ void mc_scatter(const McSortCtx &c, const McMb &k, in
     if (!(k.info & MCMB_INTER)) return;
     int mbx, mby;
     split_mb(mbi, g, inv_mbw, mbx, mby);
+    if (!c.pass) {
+        // first pass: 8-byte entries, nothing of the record in them
+        if (k.info & MCMB_WHOLE) {
+            const uint2 e = make_uint2(mcmb_entry(k, mbx, mby, 0, 0), k.vec[0]);
+            gstore2(c.out + c.l_ym + 2u * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
+            gstore2(c.out + c.l_cm + 2u * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
+        } else {
+            const uint32_t cq = atomicAdd(&c.pos[c.b_cq + (k.key[0] >> 16)], 4u);     // (a multiple of 4: every segment starts on a chunk)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint2 e = make_uint2(mcmb_entry(k, mbx, mby, q, 0), k.vec[q]);
+                gstore2(c.out + c.l_yq + 2u * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
+                gstore2(c.out + c.l_cq + 2u * (cq + (uint32_t)q), e);
+            }
+        }
+        return;
+    }
+    // second pass: the record's residual fields and the weight of the pair of references (the table the parser derived,
+    // core/macroblock.c:525-583; 32 = plain average) ride in the entry
     const uint4 rec = gload4(c.pd->mb + mbi);              // (second look at the record: out of the cache)
     const uint32_t ez = (rec.y & 0x03ffffffu) | ((rec.x >> 8) & 63u) << 26;
-    uint32_t ew[4] = { rec.z, rec.z, rec.z, rec.z };
-    if (c.pass) {
-        // second pass: the weight of the pair of references (the table the parser derived, core/macroblock.c:525-583) rides
-        // in the entry; 32 = plain average
-        const uint32_t refs = gload1(c.pd->ref_idx + mbi * 4);
+    uint32_t ew[4];
+    const uint32_t refs = gload1(c.pd->ref_idx + mbi * 4);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int w = 32;
-            if (c.pd->weighted) {
-                const int r0 = min(max((int)(int8_t)(refs >> (8 * q)), 0), c.pd->n_ref - 1), r1 = (int)((k.info >> (8 + 4 * q)) & 15u);
-                w = (int)glob(c.pd->bipred_w)[r0 * P264HIP_MAX_REFS + r1];
-            }
-            ew[q] = (rec.z & ((1u << MCE_W_SHIFT) - 1u)) | (uint32_t)w << MCE_W_SHIFT;
+    for (int q = 0; q < 4; q++) {
+        int w = 32;
+        if (c.pd->weighted) {
+            const int r0 = min(max((int)(int8_t)(refs >> (8 * q)), 0), c.pd->n_ref - 1), r1 = (int)((k.info >> (8 + 4 * q)) & 15u);
+            w = (int)glob(c.pd->bipred_w)[r0 * P264HIP_MAX_REFS + r1];
         }
+        ew[q] = (rec.z & ((1u << MCE_W_SHIFT) - 1u)) | (uint32_t)w << MCE_W_SHIFT;
     }
     if (k.info & MCMB_WHOLE) {
-        const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, 0, c.pass), k.vec[0], ((k.info >> 28) & 1u) ? (ez & 0xfc000000u) : ez, ew[0]);
-        gstore4(c.out + c.l_ym + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
-        gstore4(c.out + c.l_cm + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
+        const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, 0, 1), k.vec[0], ((k.info >> 28) & 1u) ? (ez & 0xfc000000u) : ez, ew[0]);
+        gstore4(c.out + c.l_ym + 4u * atomicAdd(&c.pos[c.b_ym + (k.key[0] & 0xffffu)], 1u), e);
+        gstore4(c.out + c.l_cm + 4u * atomicAdd(&c.pos[c.b_cm + (k.key[0] >> 16)], 1u), e);
     } else {
-        const uint32_t cq = atomicAdd(&c.pos[c.b_cq + (k.key[0] >> 16)], 4u);     // (a multiple of 4: every segment starts on a chunk)
+        const uint32_t cq = atomicAdd(&c.pos[c.b_cq + (k.key[0] >> 16)], 4u);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, q, c.pass), k.vec[q], ((k.info >> (28 + q)) & 1u) ? (ez & 0xfc000000u) : ez, ew[q]);
-            if (mcmb_luma_quad(k, q, c.pass)) gstore4(c.out + c.l_yq + MC_ENTRY_WORDS * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
-            gstore4(c.out + c.l_cq + MC_ENTRY_WORDS * (cq + (uint32_t)q), e);
+            const uint4 e = make_uint4(mcmb_entry(k, mbx, mby, q, 1), k.vec[q], ((k.info >> (28 + q)) & 1u) ? (ez & 0xfc000000u) : ez, ew[q]);
+            if (mcmb_luma_quad(k, q, 1)) gstore4(c.out + c.l_yq + 4u * atomicAdd(&c.pos[c.b_yq + (k.key[q] & 0xffffu)], 1u), e);
+            gstore4(c.out + c.l_cq + 4u * (cq + (uint32_t)q), e);
         }
     }
 }
@@ -450,7 +468,10 @@ __device__ __forceinline__ void mc_sort_picture(const PicDev *__restrict__ pics,
             if (k < b_cq) lo = ml.off_list[L0 + ML_CM];
             if (k < b_cm) lo = ml.off_list[L0 + ML_YQ];
             if (k < b_yq) lo = ml.off_list[L0 + ML_YM];
-            for (uint32_t p = end; p < (end + per - 1) / per * per; p++) gstore4(out + lo + MC_ENTRY_WORDS * p, make_uint4(0xffffffffu, 0, 0, 0));
+            for (uint32_t p = end; p < (end + per - 1) / per * per; p++) {
+                if (ps) gstore4(out + lo + 4u * p, make_uint4(0xffffffffu, 0, 0, 0));
+                else gstore2(out + lo + 2u * p, make_uint2(0xffffffffu, 0));
+            }
         }
     }
 }
@@ -910,6 +931,23 @@ __device__ __forceinline__ int xcd_logical_block()
     return (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
 }
 
+// A list entry as the consumers keep it (first pass: x, y; second pass: all four words), and the macroblock record behind a
+// first-pass entry of a chunk with residual (other chunks and padding entries: record 0, one cached request per wavefront -
+// asked for without a condition so that the wait for it stays where the record is used).
+template <bool PB>
+__device__ __forceinline__ uint4 mc_entry_load(const uint32_t *list, int item)
+{
+    if (PB) return gload4(list + (size_t)item * 4);
+    const uint2 t = gload2(list + (size_t)item * 2);
+    return make_uint4(t.x, t.y, 0, 0);
+}
+__device__ __forceinline__ uint3 mc_entry_record(const PicDev *__restrict__ pd, const Geom &g, uint32_t ex, bool resid)
+{
+    const bool use = resid && (ex & MC_ITEM_MASK) != MC_ITEM_MASK;
+    const int mbi = use ? (int)((ex >> 13) & 1023u) * g.mb_w + (int)((ex >> 2) & 2047u) : 0;
+    return gload3(pd->mb + mbi);          // (three words: asked for all four, the compiler recycles the unused register at once and waits for the load there)
+}
+
 // ------------------------------------------------------------------------------------------
 // mc_luma_body<MB, PB> (a role of k_mc / k_mc_second): one wavefront = one chunk of one key: 4 macroblock items of 16 lanes, or 16 quadrant items of 4 lanes;
 // the lane is one 4x4 block
@@ -931,7 +969,9 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     uint32_t key_w = cls_w[chunk >> 2];
-    uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
+    uint4 e = mc_entry_load<PB>(list, chunk * I::PER_WAVE + it);
+    uint3 rec = make_uint3(0, 0, 0);
+    if (!PB) rec = mc_entry_record(pd, g, e.x, (MC_CHUNK_KEY((int)((key_w >> (8 * (chunk & 3))) & 255u)) & MCY_RESID) != 0);
   for (;;) {
     const int next = chunk + stride;
     const bool more = next < n_chunks;
@@ -939,7 +979,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
     // data inside the branch, one memory round trip per chunk that is no prefetch at all)
     const int nx = min(next, n_chunks - 1);
     const uint32_t key_w_next = cls_w[nx >> 2];
-    const uint4 e_next = gload4(list + (size_t)(nx * I::PER_WAVE + it) * MC_ENTRY_WORDS);
+    const uint4 e_next = mc_entry_load<PB>(list, nx * I::PER_WAVE + it);
     const int key = MC_CHUNK_KEY((int)((key_w >> (8 * (chunk & 3))) & 255u));                   // scalar: the chunk's key bits
     const int pc = key & 7;
     wave_lds_fence();                                      // the previous chunk's image has been read
@@ -948,19 +988,29 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
     // block position inside the macroblock
     const int q = MB ? 0 : (valid ? (int)(e.x & 3) : 0);
     const int bx = MB ? (li & 3) : (q & 1) * 2 + (li & 1), by = MB ? (li >> 2) : (q >> 1) * 2 + (li >> 1);
-    // chunks with residual: QP, coded-block mask and place in the coefficient stream come with the entry
+    // chunks with residual: QP, coded-block mask and place in the coefficient stream come with the entry (second pass) or
+    // with the macroblock's record, requested while the previous chunk was at work
     int mvp = (int)e.y;
     if (!MB && pc == PC_GEN) mvp = (int)gload1(pd->mv + (mby * g.mb_w + mbx) * 16 + by * 4 + bx);   // sub-8x8 partitions: the block's own vector
     // the reference frame of the entry's (list, index): out of the workgroup's table in LDS (mc_roles) - as a load from the
     // picture's tables it was a memory round trip in front of every chunk's window requests (and the wait for it also waited
     // for the next chunk's entries, requested just before: no prefetch)
     const uint32_t roff = ref_tab[(e.x >> 28) | ((e.x >> 19) & 16u)];
-    const uint32_t cidx = PB ? (e.w & ((1u << MCE_W_SHIFT) - 1u)) : e.w;            // place in the coefficient stream
     const int ix = mbx * 16 + bx * 4 + (mv_x(mvp) >> 2), iy = mby * 16 + by * 4 + (mv_y(mvp) >> 2);
     const int fx = mv_x(mvp) & 3, fy = mv_y(mvp) & 3;
-    const unsigned mask = e.z & 0x03ffffffu;
     const int blk = blk_at(bx, by);                        // decode-order index: bit of coef_mask, position in the packed stream
-    const bool coded = valid && ((mask >> blk) & 1);
+    // (filled in where the chunk asks for its levels, BEHIND its window requests: the record is waited for there and nowhere
+    // else - read up here, the wait sat in front of the windows, a memory round trip per wavefront at its first chunk)
+    unsigned mask = 0; int qp = 0; uint32_t cidx = 0; bool coded = false;
+    auto resid_fields = [&]() {
+        if (PB) { cidx = e.w & ((1u << MCE_W_SHIFT) - 1u); mask = e.z & 0x03ffffffu; qp = (int)(e.z >> 26); }
+        else {
+            asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z));
+            cidx = rec.z; mask = (e.x & MCE_Z) ? 0u : (rec.y & 0x03ffffffu); qp = (int)((rec.x >> 8) & 63u);
+        }
+        coded = valid && ((mask >> blk) & 1);
+    };
+    if (PB) resid_fields();
     // coded levels (requested right behind the windows: they fly while the prediction is computed)
     uint4 la = make_uint4(0, 0, 0, 0), lb = la;
     // second pass: the list-0 prediction the first pass left in the destination, as the lane will store it (requested in
@@ -995,9 +1045,12 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
             if (rows_mid) { if (two) stage_luma<MB, 2, RM, true, 2>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 2, RM, true, S3>(img, rs, roff, g, xs, wy, li, third); }
             else          { if (two) stage_luma<MB, 0, I::ROWS, true, 2>(img, rs, roff, g, xs, wy, li, third); else stage_luma<MB, 0, I::ROWS, true, S3>(img, rs, roff, g, xs, wy, li, third); }
         }
-        if ((key & MCY_RESID) && coded) {
-            const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
-            la = gload4(cf); lb = gload4(cf + 8);
+        if (key & MCY_RESID) {
+            if (!PB) resid_fields();
+            if (coded) {
+                const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
+                la = gload4(cf); lb = gload4(cf + 8);
+            }
         }
         wave_lds_fence();
         const LWin<I::PITCH> w = { img, xs & ~3, wy };
@@ -1005,9 +1058,12 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
     } else {
         // The vectors differ inside the quadrant (sub-8x8 partitions), every lane has its own window and phase: windows
         // straight from memory, one pass per phase class present among the lanes.
-        if ((key & MCY_RESID) && coded) {
-            const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
-            la = gload4(cf); lb = gload4(cf + 8);
+        if (key & MCY_RESID) {
+            if (!PB) resid_fields();
+            if (coded) {
+                const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
+                la = gload4(cf); lb = gload4(cf + 8);
+            }
         }
         // one prediction per lane from reference frame `ro` with vector `mv` (lanes with use = false are left alone)
         auto predict = [&](uint32_t ro, int mv, bool use, uint32_t (&o4)[4]) {
@@ -1050,6 +1106,9 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
             }
         }
     }
+    // the next chunk's record (its entries have long arrived: they were requested in front of this chunk's windows), in flight
+    // while this chunk adds its residual and stores
+    if (!PB) rec = mc_entry_record(pd, g, e_next.x, (MC_CHUNK_KEY((int)((key_w_next >> (8 * (nx & 3))) & 255u)) & MCY_RESID) != 0);
     if (PB) {
         // (core/macroblock.c:525-583, core/mc.c:76-132) the first pass's rows back into block order, then the mean or the weighted sum
         uint32_t p0[4];
@@ -1069,7 +1128,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<false>(lv, col);
-        dequant_cols(col, (int)(e.z >> 26));
+        dequant_cols(col, qp);
         uint32_t px[4] = { out[0], out[1], out[2], out[3] };
         idct_add(col, px);
         if (coded) { out[0] = px[0]; out[1] = px[1]; out[2] = px[2]; out[3] = px[3]; }
@@ -1180,28 +1239,37 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
     const uint32_t *cls_w = mc + ml.off_cls[LIST], *list = mc + ml.off_list[LIST];
     const rsrc_t rs = make_rsrc(pd->store, pd->store_bytes);
     uint32_t key_w = cls_w[chunk >> 2];
-    uint4 e = gload4(list + (size_t)(chunk * I::PER_WAVE + it) * MC_ENTRY_WORDS);
+    uint4 e = mc_entry_load<PB>(list, chunk * I::PER_WAVE + it);
+    uint3 rec = make_uint3(0, 0, 0);
+    if (!PB) rec = mc_entry_record(pd, g, e.x, (MC_CHUNK_KEY((int)((key_w >> (8 * (chunk & 3))) & 255u)) & MCC_RESID) != 0);
   for (;;) {
     const int next = chunk + stride;
     const bool more = next < n_chunks;
     const int nx = min(next, n_chunks - 1);                // (unconditional, as in mc_luma_body)
     const uint32_t key_w_next = cls_w[nx >> 2];
-    const uint4 e_next = gload4(list + (size_t)(nx * I::PER_WAVE + it) * MC_ENTRY_WORDS);
+    const uint4 e_next = mc_entry_load<PB>(list, nx * I::PER_WAVE + it);
     const int key = MC_CHUNK_KEY((int)((key_w >> (8 * (chunk & 3))) & 255u));
     wave_lds_fence();                                      // the previous chunk's image has been read
     const bool valid = (e.x & MC_ITEM_MASK) != MC_ITEM_MASK;
     const int mbx = valid ? (int)((e.x >> 2) & 2047u) : 0, mby = valid ? (int)((e.x >> 13) & 1023u) : 0;
     const int q = MB ? (li >> 1) : (valid ? (int)(e.x & 3) : 0);
     const uint32_t roff = ref_tab[(e.x >> 28) | ((e.x >> 19) & 16u)];         // (as in mc_luma_body)
-    const uint32_t cidx = PB ? (e.w & ((1u << MCE_W_SHIFT) - 1u)) : e.w;
     // the 16-byte row this lane stores (see the end of the loop); second pass: what the first pass left there
     const uint32_t dsto = pd->dst_off + mb_chroma_off(g, mbx, mby) + (uint32_t)((q >> 1) * 64 + (lane & 3) * 16);
     u32x4 prev = { 0, 0, 0, 0 };
     if (PB) prev = bload4(rs, valid ? dsto : MC_OOB);
     const int CX = mbx * 8 + (q & 1) * 4, CY = mby * 8 + (q >> 1) * 4;      // the block's first sample
-    const unsigned mask = e.z & 0x03ffffffu;
     const int cb = 16 + 4 * p + q;                           // this block's bit of coef_mask
-    const bool has_res = valid && (mask & (0x00ff0000u | P264_COEF_CHROMA_DC)) != 0;
+    unsigned mask = 0; int qp = 0; uint32_t cidx = 0; bool has_res = false;      // (filled in behind the window requests, as in mc_luma_body)
+    auto resid_fields = [&]() {
+        if (PB) { cidx = e.w & ((1u << MCE_W_SHIFT) - 1u); mask = e.z & 0x03ffffffu; qp = (int)(e.z >> 26); }
+        else {
+            asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z));
+            cidx = rec.z; mask = (e.x & MCE_Z) ? 0u : (rec.y & 0x03ffffffu); qp = (int)((rec.x >> 8) & 63u);
+        }
+        has_res = valid && (mask & (0x00ff0000u | P264_COEF_CHROMA_DC)) != 0;
+    };
+    if (PB) resid_fields();
     uint4 la = make_uint4(0, 0, 0, 0), lb = la; uint2 dcl = make_uint2(0, 0);
     // ---- prediction ----
     uint32_t out[4];
@@ -1257,6 +1325,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
             img = pimg + (i >> 1) * I::BYTES;
         }
         if (key & MCC_RESID) {
+            if (!PB) resid_fields();
             const int16_t *cf = pd->coefs + (size_t)cidx * 16;
             if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
@@ -1275,6 +1344,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
         // follows its own vector): clamped windows straight from memory, one pass per piece, wave-uniformly skipped when
         // nobody needs it
         if (key & MCC_RESID) {
+            if (!PB) resid_fields();
             const int16_t *cf = pd->coefs + (size_t)cidx * 16;
             if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
@@ -1321,6 +1391,8 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
             }
         }
     }
+    // (the next chunk's record, as in mc_luma_body)
+    if (!PB) rec = mc_entry_record(pd, g, e_next.x, (MC_CHUNK_KEY((int)((key_w_next >> (8 * (nx & 3))) & 255u)) & MCC_RESID) != 0);
     if (PB) {
         // the first pass's rows (dwords U left, U right, V left, V right) back into block order; then the mean or the weighted
         // sum, or - quadrants that were finished in the first pass - the samples as they are
@@ -1337,7 +1409,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
     }
     // ---- residual (decoder/macroblock.c:851-890): chroma DC through the 2x2 transform, AC, inverse transform ----
     if (EXPM_RESID && (key & MCC_RESID) && __ballot(has_res)) {
-        const int qpc = chroma_qp(clip3i((int)(e.z >> 26) + pd->chroma_qp_offset, 0, 51));
+        const int qpc = chroma_qp(clip3i(qp + pd->chroma_qp_offset, 0, 51));
         const uint32_t lv[8] = { la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w };
         uint32_t col[4][2];
         unscan_cols<true>(lv, col);

@@ -221,6 +221,64 @@ def small_batch_leg(lib, S=256, K=20, Wm=3):
                     "fractions of the 8 TB/s roofline at the same algorithmic bytes per macroblock as the headline (MC: 836 B per inter macroblock)"}
 
 
+def upload_inclusive_leg(lib, S=512, K=10, Wm=2):
+    """The metric's workload with the host->HBM copies of the parsed inputs inside the timed region (the seam hands over host
+    buffers: p264hip_upload_packed from pinned memory, one copy per picture): every step uploads the S pictures it then
+    reconstructs.  No parse.  Reported under extras.upload_inclusive - never `value`."""
+    import ctypes as C
+    import numpy as np
+    from p264decoder_amd import HipReconstructor, Parser
+    from tests import synth_cases
+    from tests.conftest import frame_sha256
+    T = 1 + Wm + K
+    golden_hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    parsed = []
+    for g in range(DISTINCT):
+        path = synth_cases.generate("cfg3_1080p_allp") if g == 0 else synth_cases.generate(synth_args(T, 1000 + g))
+        parsed.append(Parser(quiet=True, lib=lib).parse_stream(open(path, "rb").read(), limit=T))
+    # the packed inputs in pinned memory (one block per distinct picture; every stream's copy of it is its own transfer)
+    pinned, total = [], 0
+    for g in range(DISTINCT):
+        row = []
+        for t in range(T):
+            pk = HipReconstructor.pack(parsed[g][t], lib=lib)
+            ptr = lib.p264hip_host_alloc(pk.size)
+            if not ptr:
+                raise RuntimeError("p264hip_host_alloc failed")
+            C.memmove(ptr, pk.ctypes.data, pk.size)
+            row.append((ptr, pk.size))
+        pinned.append(row)
+    hip = HipReconstructor(MB_W, MB_H, n_streams=S, slots=2, max_pictures=S * 2, lib=lib)
+    streams = list(range(S))
+
+    def step(t):
+        nonlocal total
+        base = (t & 1) * S                                   # two sets of input slots: the copies of step t + 1 never touch step t's
+        for s in streams:
+            ptr, n = pinned[s % DISTINCT][t]
+            hip._chk(lib.p264hip_upload_packed(hip.h, base + s, C.byref(parsed[s % DISTINCT][t].desc), ptr, n), "p264hip_upload_packed")
+            total += n
+        hip.reconstruct([base + s for s in streams], streams)
+    for t in range(1 + Wm):
+        step(t)
+    hip.sync()
+    total = 0
+    t0 = time.perf_counter()
+    for t in range(1 + Wm, T):
+        step(t)
+    hip.sync()
+    elapsed = time.perf_counter() - t0
+    ok = frame_sha256(*hip.read_frame(0, parsed[0][-1].desc.dst_slot)) == golden_hashes[T - 1]
+    hip.close()
+    for row in pinned:
+        for ptr, _ in row:
+            lib.p264hip_host_free(ptr)
+    return {"value": round(S * K / elapsed, 1), "unit": "frames/s", "streams": S, "steps": K, "input_bytes_per_picture": int(total / (S * K)),
+            "upload_GBps": round(total / elapsed / 1e9, 2), "last_picture_matches_reference": ok,
+            "what": "the metric's all-P workload with every picture's parsed input (records, vectors, reference indices, coded levels: one packed "
+                    "block in pinned host memory) copied host -> HBM inside the timed region, %d pictures per launch; no parse" % S}
+
+
 def extras(lib):
     """Figures that are NOT the metric (never `value`): the other single-GPU configurations of BASELINE.json and the
     end-to-end rates, each on a bounded run."""
@@ -232,6 +290,10 @@ def extras(lib):
         out["batch_256"] = small_batch_leg(lib)
     except Exception as e:                                    # never let an extra take the metric down
         out["batch_256"] = {"error": str(e)}
+    try:
+        out["upload_inclusive"] = upload_inclusive_leg(lib)
+    except Exception as e:
+        out["upload_inclusive"] = {"error": str(e)}
     # config 2: 1280x720 Baseline CAVLC, I slices only (intra + IDCT path), 10 pictures x 1024 streams (as many streams as
     # the metric's run: with 256 the two row-wavefront kernels leave most of the chip idle - 97 k against 144 k frames/s)
     pics = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes("cfg2_720p_intra"))[:10]

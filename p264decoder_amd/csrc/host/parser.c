@@ -620,11 +620,34 @@ static nbmv_t nb_motion(const p264parse *p, int x4, int y4) { return nb_motion_l
 
 /* H.264 8.4.1.3 (core/macroblock.c:87-175).  (bx,by,bw) in 4x4 units inside the MB;
  * dir: 0 none, 1 = 16x8 upper, 2 = 16x8 lower, 3 = 8x16 left, 4 = 8x16 right. */
+/* the block `sub` of macroblock i (which exists and is decoded) as a predictor */
+static inline nbmv_t nb_of_mb(const p264parse *p, int i, int sub, int list)
+{
+    const picbuf_t *q = &p->buf[p->cur];
+    const int8_t *ref = list ? q->ref1 : q->ref; const int16_t *mv = list ? q->mv1 : q->mv;
+    nbmv_t r;
+    r.ref = ref[i * 4 + (((sub >> 2) & 2) | ((sub >> 1) & 1))];
+    r.mvx = mv[(i * 16 + sub) * 2]; r.mvy = mv[(i * 16 + sub) * 2 + 1];
+    return r;
+}
 static void predict_mv_l(const p264parse *p, int bx, int by, int bw, int ref, int dir, int *px, int *py, int list)
 {
     int x0 = p->mbx * 4 + bx, y0 = p->mby * 4 + by;
-    nbmv_t a = nb_motion_l(p, x0 - 1, y0, list), b = nb_motion_l(p, x0, y0 - 1, list), c = nb_motion_l(p, x0 + bw, y0 - 1, list);
-    if (c.ref == -2) c = nb_motion_l(p, x0 - 1, y0 - 1, list);
+    nbmv_t a, b, c;
+    if (bw == 4 && by == 0) {
+        /* the whole macroblock or its upper half (P_L0_16x16, P_SKIP, B 16x16, spatial direct, 16x8 upper - most calls): the neighbours are block 3 of the
+         * macroblock to the left, block 12 of the one above, block 12 of the one above to the right or else block 15 of the
+         * one above to the left; nothing but the availability flags to ask */
+        const nbmv_t none = { -2, 0, 0 };
+        const unsigned av = p->cur_avail;
+        a = (av & P264_AVAIL_LEFT) ? nb_of_mb(p, p->mbi - 1, 3, list) : none;
+        b = (av & P264_AVAIL_TOP) ? nb_of_mb(p, p->mbi - p->mb_w, 12, list) : none;
+        c = (av & P264_AVAIL_TOPRIGHT) ? nb_of_mb(p, p->mbi - p->mb_w + 1, 12, list)
+          : (av & P264_AVAIL_TOPLEFT) ? nb_of_mb(p, p->mbi - p->mb_w - 1, 15, list) : none;
+    } else {
+        a = nb_motion_l(p, x0 - 1, y0, list); b = nb_motion_l(p, x0, y0 - 1, list); c = nb_motion_l(p, x0 + bw, y0 - 1, list);
+        if (c.ref == -2) c = nb_motion_l(p, x0 - 1, y0 - 1, list);
+    }
     if (dir == 1 && b.ref == ref) { *px = b.mvx; *py = b.mvy; return; }
     if (dir == 2 && a.ref == ref) { *px = a.mvx; *py = a.mvy; return; }
     if (dir == 3 && a.ref == ref) { *px = a.mvx; *py = a.mvy; return; }

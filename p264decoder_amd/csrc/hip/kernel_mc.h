@@ -1449,10 +1449,12 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
 // windows ask for it (as four launches every kernel pulled the whole reference through HBM again: measured 7.0 GB of reads
 // against 3.1 GB of reference samples), and the bandwidth-bound chroma work shares its CU with the issue-bound luma work.
 // ------------------------------------------------------------------------------------------
-#define MC_COST_YM 7u               // relative cost of one chunk (wavefront pass) per role, from the round-2 profiles
+#ifndef MC_COST_YM
+#define MC_COST_YM 7u               // relative cost of one chunk (wavefront pass) per role, from the round-2 profiles (swept again in round 5: scratch/r5_mccost.sh)
 #define MC_COST_YQ 10u
 #define MC_COST_CM 5u
 #define MC_COST_CQ 9u
+#endif
 template <bool PB>
 __device__ __forceinline__ void mc_roles(uint8_t *images, uint32_t *ref_tab, const PicDev *__restrict__ pics, const uint32_t *__restrict__ mc_all, const Geom &g, const McLayout &ml,
                                          int wgs_per_pic, int n_wgs, uint32_t inv_wgs)

@@ -30,7 +30,7 @@
 
 // Timing experiments (scratch/variant.sh, r4_dbexp.sh): results are wrong unless all defaults hold, so the switches only exist
 // in a build that says what it is (-DP264AMD_TIMING_BUILD, see kernel_mc.h and p264hip_build_info()).
-#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPD_LUMA_EDGES) || defined(EXPD_CHROMA_EDGES) || defined(EXPD_STRONG) || defined(EXPD_HPASS) || defined(EXPD_BANDSYNC) || defined(EXPD_VMCNT) || defined(EXPD_STAMPS) || defined(EXPD_NO_SAMPLE_LOADS))
+#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPD_LUMA_EDGES) || defined(EXPD_CHROMA_EDGES) || defined(EXPD_STRONG) || defined(EXPD_HPASS) || defined(EXPD_BANDSYNC) || defined(EXPD_VMCNT) || defined(EXPD_STAMPS) || defined(EXPD_NO_SAMPLE_LOADS) || defined(EXPD_EDGE_INFO_EDGES))
 #error "EXPD_* switches produce wrong pictures: they need -DP264AMD_TIMING_BUILD"
 #endif
 #ifndef EXPD_LUMA_EDGES
@@ -50,6 +50,9 @@
 #endif
 #ifndef EXPD_VMCNT
 #define EXPD_VMCNT 1
+#endif
+#ifndef EXPD_EDGE_INFO_EDGES
+#define EXPD_EDGE_INFO_EDGES 4     // 1: the edge-info pass looks at the macroblock edges only (round 5: what a cheap road for macroblocks with one vector could save at most)
 #endif
 #ifndef EXPD_NO_SAMPLE_LOADS
 #define EXPD_NO_SAMPLE_LOADS 0     // 1: the macroblock's own samples are not loaded (round 5: what a fused prediction + filter pass could save at most)
@@ -203,7 +206,7 @@ __device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, i
 #pragma unroll
     for (int dir = 0; dir < 2; dir++)
 #pragma unroll
-        for (int e = 0; e < 4; e++)
+        for (int e = 0; e < EXPD_EDGE_INFO_EDGES; e++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int x = dir == 0 ? e : i, y = dir == 0 ? i : e;

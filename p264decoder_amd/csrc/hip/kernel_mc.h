@@ -575,19 +575,27 @@ __device__ __forceinline__ void bstore4(rsrc_t r, uint32_t off, uint32_t a, uint
 // Luma work items: MB = a whole macroblock (16 lanes, window 21 rows x up to 3 strips) or an 8x8 quadrant (4 lanes, 13 rows x 2
 // strips).  The image holds only the dword columns the item reads, ROTATED so that column 0 is the dword of the first
 // sample the class needs (x0 = xs & ~3): a lane's reads are at column (its block column + k) whatever the vector, and pitch
-// and item stride are chosen so that every read instruction of a wavefront is free of bank conflicts BY CONSTRUCTION
-// (64 banks of 4 bytes):
-//   macroblock items: dword = item * 208 + (4 by + r) * 9 + bx + k   ->  bank = 16 item + 36 by + bx + const: the sixteen
-//                     (item, by) pairs land on sixteen different 4-bank slots;
-//   quadrant items:   dword = item * 130 + (4 ly + r) * 8 + lx + k   ->  bank = 2 item + 32 ly + lx + const.
+// and item placement are chosen so that every read instruction of a wavefront is free of bank conflicts BY CONSTRUCTION.  For
+// ds_read_b32 / ds_read2_b32 and every ds_write the LDS of gfx950 has 32 banks of 4 bytes and serves a wavefront as two groups
+// of 32 lanes (MI355X_MICROARCH.md, LDS): the 32 lanes of a group must land on 32 different banks.
+//   macroblock items: dword = item * 208 + (4 by + r) * 9 + bx + k   ->  bank = 16 item + 4 by + bx + const (two items per group);
+//   quadrant items:   dword = (item / 2) * 264 + (item % 2) * 130 + (4 ly + r) * 9 + lx + k
+//                                                                    ->  bank = 8 (item / 2) + 2 (item % 2) + 4 ly + lx + const
+//                     (eight items per group).  Rounds 3 - 5 had a pitch of 8 dwords and 130 dwords per item, laid out for 64
+//                     banks across all 64 lanes: 32 ly fell away modulo 32 and the two block rows of every item met on the
+//                     same banks in every read - 150 M of the kernel's 271 M bank-conflict cycles per launch (scratch/r5_ldsconf.sh).
 // (With the strips stored side by side at a pitch of 52 / 36 bytes, the lanes of different items met on the same banks at
 // random: LDS bank-conflict cycles were twice the LDS issue cycles of these kernels.)  The staging stores of a 16-byte row
 // piece go to columns 4 s - dx .. 4 s - dx + 3; columns outside 0 .. 5 (0 .. 3) fall into the row's padding or the padding of
 // the row above - nobody reads them.  LEAD bytes in front of the first item take the negative columns of its first row.
 template <bool MB> struct YItem {
     static constexpr int LANES = MB ? 16 : 4, PER_WAVE = 64 / LANES, STRIPS = MB ? 3 : 2, ROWS = MB ? 21 : 13;
-    static constexpr int PITCH = MB ? 36 : 32, BYTES = MB ? 832 : 520, LEAD = 16;
-    static_assert(ROWS * PITCH + 12 <= BYTES, "item image");
+    static constexpr int PITCH = 36, BYTES = MB ? 832 : 520, LEAD = 16;
+    static constexpr int PAIR = 1056;                       // quadrant items: bytes per pair of items (264 dwords)
+    static constexpr int WAVE_BYTES = MB ? PER_WAVE * BYTES : (PER_WAVE / 2) * PAIR;
+    static_assert(ROWS * PITCH + 12 <= BYTES && (MB || BYTES + ROWS * PITCH + 12 <= PAIR), "item image");
+    // first byte of item i (counted over the workgroup's wavefronts) behind LEAD
+    __device__ static __forceinline__ int item_off(int i) { return MB ? i * BYTES : (i >> 1) * PAIR + (i & 1) * BYTES; }
 };
 
 // Stage rows R0S .. R0S+NRS-1 of the window whose first needed sample is (xs, wy); li = lane inside the item.  Piece p = strip
@@ -1028,7 +1036,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
         // the item's window (all its lanes hold the same vector): top-left sample (wx, wy), staged in LDS
         const int ox = MB ? bx * 4 : (li & 1) * 4, oy = MB ? by * 4 : (li >> 1) * 4;
         const int wx = ix - ox - 2, wy = iy - oy - 2;
-        uint8_t *img = images + I::LEAD + (wave * I::PER_WAVE + it) * I::BYTES;
+        uint8_t *img = images + I::LEAD + I::item_off(wave * I::PER_WAVE + it);
         const bool rows_mid = pc <= PC_H;                  // copy / horizontal: no rows above and below the blocks
         // first sample the class reads in a row (copy / vertical: no columns left of the blocks); image column 0 = its dword
         const int xs = (pc == PC_COPY || pc == PC_V) ? wx + 2 : wx;
@@ -1206,6 +1214,15 @@ __device__ __forceinline__ void mc_chroma_clamped(uint32_t (&out)[4], rsrc_t rs,
 template <bool MB> struct CItem {
     static constexpr int LANES = MB ? 8 : 2, PER_WAVE = 64 / LANES, ROWS = MB ? 9 : 5;
     static constexpr int PITCH = 40, BYTES = ROWS * PITCH + 8;
+    // macroblock items: a lane reads dword row * 10 + 2 plane + (block column) of its item, the block rows 40 dwords apart: the
+    // eight lanes of an item cover banks {0 .. 3} and {8 .. 11} (of 32, see YItem).  Items in pairs, 100 dwords apart inside a
+    // pair and 208 from pair to pair: bank = 16 (item / 2) + 4 (item % 2) + ... - the four items of a 32-lane group tile the 32
+    // banks (92 dwords per item as before put items 0 and 2, 1 and 3 on the same banks).  What is left of this role's conflicts
+    // comes from the windows' own column offset (0, 1, 4 or 5 dwords by the vector), which differs from item to item.
+    static constexpr int PAIR = 832, SECOND = 400;
+    static constexpr int WAVE_BYTES = MB ? (PER_WAVE / 2) * PAIR : PER_WAVE * BYTES;
+    static_assert(!MB || (BYTES <= SECOND && SECOND + BYTES <= PAIR), "item image");
+    __device__ static __forceinline__ int item_off(int i) { return MB ? (i >> 1) * PAIR + (i & 1) * SECOND : i * BYTES; }
 };
 // one 16-byte row piece of a chroma strip, coordinates clamped to the picture if CLAMP (a strip outside becomes the
 // replicated first / last sample of each plane's 8 bytes)
@@ -1283,7 +1300,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
         int x0, y0;                                                          // image origin
         if (MB) {
             // 9 rows x 2 strips = 18 pieces over 8 lanes: piece li + 8j = strip (p / 9), row p % 9
-            img = images + (wave * I::PER_WAVE + it) * I::BYTES;
+            img = images + I::item_off(wave * I::PER_WAVE + it);
             const int sA = wx >> 3;
             x0 = sA * 8; y0 = wy;
             // (ONE scalar branch around the whole sequence, every piece requested in a row and waited for once: with the clamped /
@@ -1492,10 +1509,10 @@ __device__ __forceinline__ void mc_roles(uint8_t *images, uint32_t *ref_tab, con
     else mc_chroma_body<false, PB>(images, ref_tab, pd, mc, g, ml, s - w0 - w1 - w2, w3);
 }
 #ifndef MC_IMAGE_BYTES
-#define MC_IMAGE_BYTES (YItem<false>::LEAD + 4 * 16 * YItem<false>::BYTES)        // the largest of the four roles' images
+#define MC_IMAGE_BYTES (YItem<false>::LEAD + 4 * YItem<false>::WAVE_BYTES)         // the largest of the four roles' images
 #endif
-static_assert(EXPM_ONLY == 3 || (MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 8 * CItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 32 * CItem<false>::BYTES), "image space");
-static_assert(MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * 4 * YItem<true>::BYTES && MC_IMAGE_BYTES >= 4 * 8 * CItem<true>::BYTES, "image space of the macroblock roles");
+static_assert(EXPM_ONLY == 3 || (MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * YItem<true>::WAVE_BYTES && MC_IMAGE_BYTES >= 4 * CItem<true>::WAVE_BYTES && MC_IMAGE_BYTES >= 4 * CItem<false>::WAVE_BYTES), "image space");
+static_assert(MC_IMAGE_BYTES >= YItem<true>::LEAD + 4 * YItem<true>::WAVE_BYTES && MC_IMAGE_BYTES >= 4 * CItem<true>::WAVE_BYTES, "image space of the macroblock roles");
 #ifndef MC_WAVES_PER_EU
 #define MC_WAVES_PER_EU 4
 #endif

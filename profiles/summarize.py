@@ -19,11 +19,17 @@ here = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(here, "..", "gpurun_out", tag)
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(here, tag + "_bench.json"))
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+def newest(pattern):
+    """gpurun merges every collection of a tag into the same directory: only the latest file of a pass counts."""
+    found = glob.glob(pattern, recursive=True)
+    return max(found, key=os.path.getmtime) if found else None
+
+
+stats = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(here, tag + "_kernel_stats.csv"))
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+for f in filter(None, (newest(os.path.join(d, "**", "*counter_collection.csv")) for d in sorted(glob.glob(os.path.join(src, "pmc*")))  if os.path.isdir(d))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
         k = k[5:] if k.startswith("void ") else k              # (template instances: "void k_deblock_bs<false>")

@@ -24,7 +24,7 @@ HIP_ARCH = "gfx950"
 # host code for AVX2 / BMI2 machines (every EPYC; the GPU boxes are Zen 5): the CABAC parse gains 4.5 % per thread, CAVLC
 # nothing (scratch/r5_parse_flags.sh; -march=znver3, -O2 and a profile-guided build all lose on CAVLC).  p264parse_open refuses
 # to run on an older CPU.
-HOST_ARCH = ["-march=x86-64-v3"]
+HOST_ARCH = ["-march=x86-64-v3", "-falign-functions=64"]     # (functions on cache-line boundaries: CAVLC + 1.5 % per thread, scratch/r5_parse_ab.sh)
 
 
 def _hipcc():

@@ -4,8 +4,10 @@
 # box:   gpurun -- 'bash scratch/r5_parse_ab.sh run base cur'
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 if [ "$1" = build ]; then
-  W=/tmp/pab_$2; mkdir -p $W scratch/t
-  for f in parser vlc cabac dropin pipeline fanout input_layout; do gcc -O3 -march=x86-64-v3 -std=gnu11 -Iinclude -Ip264decoder_amd/csrc/host -c p264decoder_amd/csrc/host/$f.c -o $W/$f.o || exit 1; done
+  n=$2; shift 2                                      # (further arguments: extra compiler flags)
+  W=/tmp/pab_$n; mkdir -p $W scratch/t
+  set -- "$n" "$n" "$@"
+  for f in parser vlc cabac dropin pipeline fanout input_layout; do gcc -O3 -march=x86-64-v3 -falign-functions=64 "${@:3}" -std=gnu11 -Iinclude -Ip264decoder_amd/csrc/host -c p264decoder_amd/csrc/host/$f.c -o $W/$f.o || exit 1; done
   gcc -O2 -Iinclude -c tests/tools/hip_stub.c -o $W/stub.o && gcc -O2 -Iinclude scratch/pg/drv.c $W/*.o -o scratch/t/drv_$2 -lpthread -ldl 2>/dev/null && echo built scratch/t/drv_$2
   exit
 fi

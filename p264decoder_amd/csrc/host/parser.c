@@ -683,25 +683,6 @@ static void set_motion_l(p264parse *p, int bx, int by, int bw, int bh, int mvx, 
 }
 static void set_motion(p264parse *p, int bx, int by, int bw, int bh, int mvx, int mvy) { set_motion_l(p, bx, by, bw, bh, mvx, mvy, 0); }
 
-/* total_coeff predictor nC (H.264 9.2.1; core/macroblock.c:53-65).  blk: 0-15 luma, 16-23 chroma */
-static int predict_nc(const p264parse *p, int blk)
-{
-    const uint8_t *cur = p->nnz + (size_t)p->mbi * 24;
-    int na = -1, nb = -1;
-    const int left_ok = p->cur_avail & P264_AVAIL_LEFT, top_ok = p->cur_avail & P264_AVAIL_TOP;    /* (begin_mb) */
-    if (blk < 16) {
-        int x = blk_x[blk], y = blk_y[blk];
-        if (x > 0) na = cur[blk_of_xy[y][x-1]]; else if (left_ok) na = (cur - 24)[blk_of_xy[y][3]];
-        if (y > 0) nb = cur[blk_of_xy[y-1][x]]; else if (top_ok) nb = (cur - 24 * p->mb_w)[blk_of_xy[3][x]];
-    } else {
-        int base = blk < 20 ? 16 : 20, c = blk - base, x = c & 1, y = c >> 1;
-        if (x > 0) na = cur[blk - 1]; else if (left_ok) na = (cur - 24)[base + y * 2 + 1];
-        if (y > 0) nb = cur[blk - 2]; else if (top_ok) nb = (cur - 24 * p->mb_w)[base + 2 + x];
-    }
-    if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
-    return na >= 0 ? na : nb >= 0 ? nb : 0;
-}
-
 /* Intra4x4PredMode predictor (H.264 8.3.1.1; core/macroblock.c:40-51) */
 static int predict_i4mode(const p264parse *p, int blk)
 {
@@ -740,20 +721,45 @@ static int coef_reserve(picbuf_t *q, size_t more)
 #include "parser_cabac.h"
 
 /* residual( ) - decoder/macroblock.c:410-486 */
+/* total_coeff predictor nC (H.264 9.2.1; core/macroblock.c:53-65): the mean of the counts of the blocks to the left and above.
+ * The coefficient counts around and inside the macroblock on an 8-wide grid (left neighbour of a block one to the left, upper one
+ * eight back; 0x80 = no such neighbour): luma block (x, y) at 8 (1 + y) + 1 + x, Cb (x, y) at 8 (6 + y) + 1 + x, Cr at
+ * 8 (6 + y) + 5 + x.  nC of 9.2.1 is then two loads and a rounded mean that an absent neighbour falls out of by itself
+ * (predict_nc: two table look-ups and four branches per block). */
+static const uint8_t nc_pos[24] = { 9, 10, 17, 18, 11, 12, 19, 20, 25, 26, 33, 34, 27, 28, 35, 36,  49, 50, 57, 58,  53, 54, 61, 62 };
+static inline int nc_of(const uint8_t *nc, int at)
+{
+    int r = nc[at - 1] + nc[at - 8];
+    if (r < 0x80) r = (r + 1) >> 1;
+    return r & 0x7f;
+}
 static int parse_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *cf)
 {
     uint8_t *nnz = p->nnz + (size_t)p->mbi * 24;
     int cbp_l = m->cbp & 15, cbp_c = m->cbp >> 4, tc;
+    uint8_t nc[64];
+    {
+        const uint8_t *left = nnz - 24, *top = nnz - 24 * (size_t)p->mb_w;
+        if (p->cur_avail & P264_AVAIL_LEFT) {
+            nc[8] = left[5]; nc[16] = left[7]; nc[24] = left[13]; nc[32] = left[15];
+            nc[48] = left[17]; nc[56] = left[19]; nc[52] = left[21]; nc[60] = left[23];
+        } else nc[8] = nc[16] = nc[24] = nc[32] = nc[48] = nc[56] = nc[52] = nc[60] = 0x80;
+        if (p->cur_avail & P264_AVAIL_TOP) {
+            nc[1] = top[10]; nc[2] = top[11]; nc[3] = top[14]; nc[4] = top[15];
+            nc[41] = top[18]; nc[42] = top[19]; nc[45] = top[22]; nc[46] = top[23];
+        } else nc[1] = nc[2] = nc[3] = nc[4] = nc[41] = nc[42] = nc[45] = nc[46] = 0x80;
+    }
     if (m->mb_type == P264_MB_I16x16) {
-        if ((tc = cavlc_read_block(b, predict_nc(p, 0), 16, cf->dc_luma)) < 0) return -1;
+        if ((tc = cavlc_read_block(b, nc_of(nc, nc_pos[0]), 16, cf->dc_luma)) < 0) return -1;
         if (tc) cf->mask |= P264_COEF_LUMA_DC;
     }
     int maxc = m->mb_type == P264_MB_I16x16 ? 15 : 16;
     for (int i = 0; i < 16; i++) {
-        nnz[i] = 0;
+        const int at = nc_pos[i];
+        nnz[i] = 0; nc[at] = 0;
         if (!(cbp_l & (1 << (i >> 2)))) continue;
-        if ((tc = cavlc_read_block(b, predict_nc(p, i), maxc, cf->blk[i])) < 0) return -1;
-        nnz[i] = (uint8_t)tc;
+        if ((tc = cavlc_read_block(b, nc_of(nc, at), maxc, cf->blk[i])) < 0) return -1;
+        nnz[i] = (uint8_t)tc; nc[at] = (uint8_t)tc;
         if (tc) cf->mask |= 1u << i;
     }
     if (cbp_c) {
@@ -764,10 +770,11 @@ static int parse_residual(p264parse *p, bitrd_t *b, p264hip_mb_t *m, mbcoef_t *c
         if (t0 | t1) cf->mask |= P264_COEF_CHROMA_DC;
     }
     for (int i = 16; i < 24; i++) {
-        nnz[i] = 0;
+        const int at = nc_pos[i];
+        nnz[i] = 0; nc[at] = 0;
         if (!(cbp_c & 2)) continue;
-        if ((tc = cavlc_read_block(b, predict_nc(p, i), 15, cf->blk[i])) < 0) return -1;
-        nnz[i] = (uint8_t)tc;
+        if ((tc = cavlc_read_block(b, nc_of(nc, at), 15, cf->blk[i])) < 0) return -1;
+        nnz[i] = (uint8_t)tc; nc[at] = (uint8_t)tc;
         if (tc) cf->mask |= 1u << i;
     }
     return 0;

@@ -805,11 +805,19 @@ static void begin_mb(p264parse *p, p264hip_mb_t *m)
     memset(m, 0, sizeof *m);
     p->mv_done = 0; p->mv_done1 = 0;
     if (p->cabac_on) { p->cinfo[p->mbi] = 0; memset(p->mvd_abs[0] + p->mbi * 32, 0, 32); memset(p->mvd_abs[1] + p->mbi * 32, 0, 32); }
+    /* the four neighbours (mb_avail, spelled out: they all lie in front of this macroblock, so only the picture's borders and
+     * the slice they belong to are left to ask) */
     int a = 0;
-    if (mb_avail(p, p->mbx - 1, p->mby))     a |= P264_AVAIL_LEFT;
-    if (mb_avail(p, p->mbx, p->mby - 1))     a |= P264_AVAIL_TOP;
-    if (mb_avail(p, p->mbx + 1, p->mby - 1)) a |= P264_AVAIL_TOPRIGHT;
-    if (mb_avail(p, p->mbx - 1, p->mby - 1)) a |= P264_AVAIL_TOPLEFT;
+    {
+        const int w = p->mb_w, i = p->mbi, x = p->mbx;
+        const uint16_t sn = (uint16_t)p->slice_no, *so = p->slice_of;
+        if (x > 0 && so[i - 1] == sn) a |= P264_AVAIL_LEFT;
+        if (p->mby > 0) {
+            if (so[i - w] == sn) a |= P264_AVAIL_TOP;
+            if (x + 1 < w && so[i - w + 1] == sn) a |= P264_AVAIL_TOPRIGHT;
+            if (x > 0 && so[i - w - 1] == sn) a |= P264_AVAIL_TOPLEFT;
+        }
+    }
     m->avail = (uint8_t)a;
     p->cur_avail = a;
     int e = 0;

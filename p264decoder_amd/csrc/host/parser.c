@@ -616,7 +616,6 @@ static nbmv_t nb_motion_l(const p264parse *p, int x4, int y4, int list)
     r.mvx = mv[(i * 16 + sub) * 2]; r.mvy = mv[(i * 16 + sub) * 2 + 1];
     return r;
 }
-static nbmv_t nb_motion(const p264parse *p, int x4, int y4) { return nb_motion_l(p, x4, y4, 0); }
 
 /* H.264 8.4.1.3 (core/macroblock.c:87-175).  (bx,by,bw) in 4x4 units inside the MB;
  * dir: 0 none, 1 = 16x8 upper, 2 = 16x8 lower, 3 = 8x16 left, 4 = 8x16 right. */
@@ -853,10 +852,12 @@ static void decode_pskip(p264parse *p)
     memset(q->ref + p->mbi * 4, 0, 4);
     memset(q->i4 + p->mbi * 16, 2, 16);
     int mvx = 0, mvy = 0;
-    int x0 = p->mbx * 4, y0 = p->mby * 4;
-    nbmv_t a = nb_motion(p, x0 - 1, y0), b = nb_motion(p, x0, y0 - 1);
-    if (!(a.ref == -2 || b.ref == -2 || (a.ref == 0 && a.mvx == 0 && a.mvy == 0) || (b.ref == 0 && b.mvx == 0 && b.mvy == 0)))
-        predict_mv(p, 0, 0, 4, 0, 0, &mvx, &mvy);
+    /* (8.4.1.1: the zero vector without a left or an upper neighbour or next to one at rest on reference 0; else the 16x16 prediction) */
+    if ((p->cur_avail & (P264_AVAIL_LEFT | P264_AVAIL_TOP)) == (P264_AVAIL_LEFT | P264_AVAIL_TOP)) {
+        const nbmv_t a = nb_of_mb(p, p->mbi - 1, 3, 0), b = nb_of_mb(p, p->mbi - p->mb_w, 12, 0);
+        if (!((a.ref == 0 && a.mvx == 0 && a.mvy == 0) || (b.ref == 0 && b.mvx == 0 && b.mvy == 0)))
+            predict_mv(p, 0, 0, 4, 0, 0, &mvx, &mvy);
+    }
     set_motion(p, 0, 0, 4, 4, mvx, mvy);
     m->coef_index = (uint32_t)q->coef_n;
     finish_mb_qp(p, m, 0, p->sh.qp);

@@ -72,10 +72,26 @@ def run_rank(rank, world, port, streams, max_pictures, use_oracle, q, fail=None,
         q.put(("error", "%d: %r" % (rank, e), None))
 
 
+def free_port(hint):
+    """`hint` if nobody holds it (not even a socket of an earlier run in TIME_WAIT), else a port the kernel picks: two test
+    runs shortly after one another - or a port the rendezvous of another test left behind - otherwise fail now and then."""
+    import socket
+    for want in (hint, 0):
+        try:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", want))
+                return s.getsockname()[1]
+        except OSError:
+            continue
+    return hint
+
+
 def run_job(world, streams, max_pictures, use_oracle, port, fail=None, delay=0.0, transport=None, expect_errors=False):
     """Runs one job with `world` processes.  Every rank must come back (a hang fails the test by time-out) and exit.
     expect_errors: return the raw per-rank results instead of asserting that nobody failed."""
     import multiprocessing as mp
+    if transport is None:
+        port = free_port(port)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=run_rank, args=(r, world, port, streams, max_pictures, use_oracle, q, fail, delay, transport)) for r in range(world)]

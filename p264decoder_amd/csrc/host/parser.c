@@ -799,26 +799,29 @@ static int store_coefs(p264parse *p, p264hip_mb_t *m, const mbcoef_t *cf)
     return 0;
 }
 
+/* the four neighbours (mb_avail, spelled out: they all lie in front of this macroblock, so only the picture's borders and the
+ * slice they belong to are left to ask) */
+static inline int mb_neighbours(p264parse *p)
+{
+    int a = 0;
+    const int w = p->mb_w, i = p->mbi, x = p->mbx;
+    const uint16_t sn = (uint16_t)p->slice_no, *so = p->slice_of;
+    if (x > 0 && so[i - 1] == sn) a |= P264_AVAIL_LEFT;
+    if (p->mby > 0) {
+        if (so[i - w] == sn) a |= P264_AVAIL_TOP;
+        if (x + 1 < w && so[i - w + 1] == sn) a |= P264_AVAIL_TOPRIGHT;
+        if (x > 0 && so[i - w - 1] == sn) a |= P264_AVAIL_TOPLEFT;
+    }
+    p->cur_avail = a;
+    return a;
+}
 static void begin_mb(p264parse *p, p264hip_mb_t *m)
 {
     memset(m, 0, sizeof *m);
     p->mv_done = 0; p->mv_done1 = 0;
     if (p->cabac_on) { p->cinfo[p->mbi] = 0; memset(p->mvd_abs[0] + p->mbi * 32, 0, 32); memset(p->mvd_abs[1] + p->mbi * 32, 0, 32); }
-    /* the four neighbours (mb_avail, spelled out: they all lie in front of this macroblock, so only the picture's borders and
-     * the slice they belong to are left to ask) */
-    int a = 0;
-    {
-        const int w = p->mb_w, i = p->mbi, x = p->mbx;
-        const uint16_t sn = (uint16_t)p->slice_no, *so = p->slice_of;
-        if (x > 0 && so[i - 1] == sn) a |= P264_AVAIL_LEFT;
-        if (p->mby > 0) {
-            if (so[i - w] == sn) a |= P264_AVAIL_TOP;
-            if (x + 1 < w && so[i - w + 1] == sn) a |= P264_AVAIL_TOPRIGHT;
-            if (x > 0 && so[i - w - 1] == sn) a |= P264_AVAIL_TOPLEFT;
-        }
-    }
+    const int a = mb_neighbours(p);
     m->avail = (uint8_t)a;
-    p->cur_avail = a;
     int e = 0;
     if (p->sh.disable_deblock != 1) {
         e = P264_EDGE_INNER;
@@ -1316,7 +1319,7 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
             if (p->next_mb >= p->n_mb) { ERR(p, "slice data runs past the picture"); p->pic_open = 0; return -1; }
             p->mbi = p->next_mb; p->mbx = p->mbi % p->mb_w; p->mby = p->mbi / p->mb_w;
             /* (the neighbour flags of the macroblock are needed before its first bin: begin_mb computes them again, identically) */
-            { p264hip_mb_t tmp; begin_mb(p, &tmp); }
+            mb_neighbours(p);
             if (sh.type != P264_SLICE_I && cb_mb_skip_flag(p)) { if (sh.type == P264_SLICE_B) decode_bskip(p); else decode_pskip(p); }
             else if (parse_mb(p, &b) < 0) { ERR(p, "macroblock read failed [%d,%d]", p->mbx, p->mby); p->pic_open = 0; return -1; }
             if (p264cabac_bits_left(&p->cb) < -64) { ERR(p, "CABAC data overrun"); p->pic_open = 0; return -1; }

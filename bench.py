@@ -13,8 +13,11 @@ frame store.  The IDR picture and W P pictures are the untimed warm-up, then exa
 pictures per stream are timed.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S]
-  N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-       one rank per GPU, streams sharded across ranks, no data-path collective (weak scaling).
+  N>1: one rank per GPU, streams sharded across ranks, no data-path collective (weak scaling).  Either the caller starts the
+       ranks (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...: RANK / WORLD_SIZE in the
+       environment) or bench.py does: `python bench.py --gpus N` without WORLD_SIZE starts that same command as a child
+       process - the parent never touches the GPU - and relays rank 0's JSON line.  A WORLD_SIZE that differs from --gpus
+       is an error (exit 2), never a silent one-rank run.
 
 Prints ONE JSON line (rank 0).  Besides the contract's fields: `roofline` (the dominant stage), `kernels` (every stage with
 its own fraction of the HBM roofline), `cpu_baseline` (the real reference decoder on one host core, N=1 only), a
@@ -279,7 +282,7 @@ def upload_inclusive_leg(lib, S=512, K=10, Wm=2):
                     "block in pinned host memory) copied host -> HBM inside the timed region, %d pictures per launch; no parse" % S}
 
 
-def extras(lib):
+def extras(lib, baseline_stream=None):
     """Figures that are NOT the metric (never `value`): the other single-GPU configurations of BASELINE.json and the
     end-to-end rates, each on a bounded run."""
     from p264decoder_amd import Decoder, Parser
@@ -370,6 +373,12 @@ def extras(lib):
                                       "upload_GBps": round(st["bytes_uploaded"] / st["seconds"] / 1e9, 2) if "bytes_uploaded" in st else None,
                                       "what": "Annex-B in host memory -> CAVLC parse on the host threads (into registered huge pages) -> DMA uploads -> batched reconstruction; pictures stay in HBM; "
                                               "bound by the host parse: compare parse_only_fps (same threads, no GPU)"}
+        # ... and the reference beside it: as many reference processes as the pipeline had parser threads, on the same cores
+        try:
+            if baseline_stream:
+                out["end_to_end_pipeline"]["cpu_baseline_n"] = cpu_baseline_n(baseline_stream, threads)
+        except Exception as e:
+            out["end_to_end_pipeline"]["cpu_baseline_n"] = {"error": str(e)}
         # the same for config 4's kind of stream (Main profile, CABAC, I + P + B): the CABAC parse is the slower one
         try:
             main = open(synth_cases.generate(synth_cases.ORACLE_CASES["main_1080p_cabac_ipb"]), "rb").read()
@@ -410,20 +419,32 @@ def fanout_leg(rank, local_rank, world, lib):
     limit - whatever happens in there cannot disturb the timed result above.  Rank 0 returns the root child's report."""
     import torch.distributed as dist
     from p264decoder_amd import fanout
+    # (rehearsal on a box with fewer GPUs than ranks - P264AMD_BENCH_DEVICE pins every rank to one GPU - : two ranks cannot share
+    # a device in one RCCL communicator, so the same protocol runs over the TCP transport with its device entry points on)
+    tcp = bool(os.environ.get("P264AMD_BENCH_DEVICE")) or os.environ.get("P264AMD_BENCH_FAN_TRANSPORT") == "tcp"
     uid = [None]
     if rank == 0:
         try:
-            uid[0] = fanout.rccl_unique_id(lib).hex()
+            if tcp:
+                import socket
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    uid[0] = "port:%d" % s.getsockname()[1]
+            else:
+                uid[0] = fanout.rccl_unique_id(lib).hex()
         except Exception as e:
             uid[0] = "error: %s" % e
     dist.broadcast_object_list(uid, src=0)
     if uid[0].startswith("error"):
         return {"error": uid[0]}
-    cmd = [sys.executable, "-m", "p264decoder_amd.tools.fan_bench", "--rank", str(rank), "--world", str(world), "--transport", "rccl",
-           "--uid", uid[0], "--device", str(local_rank), "--streams", str(max(world, 8)), "--pictures", "12"]
+    cmd = [sys.executable, "-m", "p264decoder_amd.tools.fan_bench", "--rank", str(rank), "--world", str(world),
+           "--device", str(local_rank), "--streams", str(max(world, 8)), "--pictures", "12"]
+    cmd += ["--transport", "tcp", "--port", uid[0][5:]] if tcp else ["--transport", "rccl", "--uid", uid[0]]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK"):
         env.pop(k, None)
+    if tcp:
+        env["P264AMD_FAN_TCP_DEVICE"] = "1"
     res = {"error": "no report"}
     try:
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
@@ -438,6 +459,8 @@ def fanout_leg(rank, local_rank, world, lib):
                 res = json.loads(line[7:])                 # the report, or {"error": the transport's / RCCL's own message}
         if res.get("error") == "no report" and p.returncode not in (0, None):
             res = {"error": "rank %d: child exited with %s: %s" % (rank, p.returncode, err.strip().splitlines()[-1] if err.strip() else "")}
+        elif res.get("error") == "no report" and rank and p.returncode == 0:
+            res = {"ok": True}                            # a worker that left in step has nothing to report
     except Exception as e:                                    # noqa: BLE001
         res = {"error": "rank %d: %r" % (rank, e)}
     # the root's report plus whatever the other ranks have to say (a worker's RCCL error is the interesting one when the
@@ -483,6 +506,28 @@ def cpu_baseline(stream_path, n_pictures):
             "sample": "%d 1920x1088 pictures through the scalar oracle (reconstruction only, parse excluded)" % n}
 
 
+def cpu_baseline_n(stream_path, n_procs, loops=12):
+    """stream-parallel figures sit next to N independent reference processes on N cores (the reference is
+    single-threaded, core/core.c:48, so N streams are N processes).  n_procs copies of oracle/_ref/p264ref_driver decode the
+    same all-P 1080p stream `loops` times each, started together; value = all their pictures over the wall clock from the
+    first start to the last exit.  None where the real reference did not travel (no port stands in here)."""
+    driver = os.path.join(ROOT, "oracle", "_ref", "p264ref_driver")
+    if not os.path.exists(driver):
+        return None
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([driver, "time", stream_path, str(loops)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(n_procs)]
+    frames, per = 0, []
+    for p in procs:
+        out = p.communicate(timeout=900)[0].split()
+        frames += int(out[out.index("frames") + 1])
+        per.append(float(out[out.index("fps") + 1]))
+    dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": n_procs, "processes": n_procs, "kind": "reference", "cpu_model": cpu_model(), "cpu_quota": cpu_quota(),
+            "fps_per_process_min_max": [round(min(per), 2), round(max(per), 2)], "includes_parse": True,
+            "sample": "%d reference decoder processes side by side, each decoding the bench's 1920x1088 all-P stream %d times (parse + reconstruction), %d pictures in %.1f s"
+                      % (n_procs, loops, frames, dt)}
+
+
 def measured_copy_bandwidth(torch):
     """Achievable HBM ceiling on this box next to the 8 TB/s vendor peak: device-to-device copy of 1 GiB,
     bytes read + bytes written per second."""
@@ -504,6 +549,40 @@ def measured_copy_bandwidth(torch):
     return round(gbps, 1)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the GPU (no
+    HIP call, not even torch imported) and never will: the ranks are fresh children of `python -m torch.distributed.run`
+    (a subprocess, not an exec), rank 0's JSON line is relayed on stdout, everything else on stderr."""
+    import socket
+    rc, line = 1, None
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + argv
+        env = dict(os.environ)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+        out, err = p.communicate()
+        rc = p.returncode
+        sys.stderr.write(err)
+        for l in out.splitlines():
+            if l.startswith("{") and '"metric"' in l:
+                line = l
+            else:
+                sys.stderr.write(l + "\n")
+        # (the port was free when it was picked and may be taken when the rendezvous binds it: once more on exactly that)
+        if rc == 0 or not any(w in err for w in ("ddress already in use", "EADDRINUSE", "failed to bind")):
+            break
+    if rc != 0 or line is None:
+        raise SystemExit("bench.py --gpus %d: the ranks failed (exit code %s, %s)" % (n, rc, "no JSON line" if line is None else "JSON line present"))
+    if json.loads(line).get("n_gpus") != n:
+        raise SystemExit("bench.py --gpus %d: the job reports n_gpus = %s" % (n, json.loads(line).get("n_gpus")))
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -518,9 +597,15 @@ def main():
     ap.add_argument("--only-batch-256", action="store_true", help="print extras.batch_256 (the metric's workload at 256 pictures per launch) and nothing else")
     args = ap.parse_args()
 
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:    # no launcher around us: be the launcher (before anything touches the GPU)
+        return launch_ranks(args.gpus, sys.argv[1:])
     from p264decoder_amd import shard
     rank, local_rank, world = shard.env_rank()
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE = %d: start one rank per GPU (or run without a launcher and let "
+                         "bench.py start them)\n" % (args.gpus, world))
+        raise SystemExit(2)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the reconstruction path")
     # (rehearsal knobs for a box with fewer GPUs than ranks: P264AMD_BENCH_DEVICE pins every rank to one GPU,
@@ -605,9 +690,14 @@ def main():
         golden_check.update(checked=True, streams_checked=sorted({0, clone}), sha256=golden_hashes[T - 1][:16] + "...",
                             source="tests/golden/synth_%s.sha256 (oracle/_ref, the real reference decoder)" % golden_case)
 
+    # what every rank did (N > 1: the streams each rank owns are its own - S per rank, weak scaling - and every rank checks its
+    # own golden stream against the reference's hash)
+    ranks = shard.gather_objects({"rank": rank, "device": local_rank, "streams": S, "frames": S * K, "golden_checked": golden_check["checked"],
+                                  "first_global_stream": rank * S})
     copy_gbps = measured_copy_bandwidth(torch) if rank == 0 else None
     if rank == 0:
-        frames = S * K * world
+        frames = sum(r["frames"] for r in ranks)
+        assert frames == S * K * world and len(ranks) == world
         fps = frames / elapsed
         alg = algorithmic_bytes([parsed[s % DISTINCT][t] for s in streams for t in (T - 1,)], EDGE_INFO_FUSED)   # one representative step
         kernels = {}
@@ -690,6 +780,7 @@ def main():
             "kernels": kernels,
             "reconstruct_call_ms": round(timing["reconstruct"][0] / max(timing["reconstruct"][1], 1), 4),
             "golden_check": golden_check,
+            "ranks": ranks,
             "launch": launch,
             "build": {"timing_build": bool(lib.p264hip_build_info() & 1)},
         }
@@ -701,7 +792,7 @@ def main():
         fan = fanout_leg(rank, local_rank, world, lib)       # after the timed region, in child processes, never `value`
     if rank == 0:
         if not args.no_extras and world == 1:
-            out["extras"] = extras(lib)
+            out["extras"] = extras(lib, None if args.no_cpu_baseline else paths[0])
         if fan is not None:
             out.setdefault("extras", {})["fanout_config5"] = fan
         print(json.dumps(out), flush=True)

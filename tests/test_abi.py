@@ -173,3 +173,36 @@ def test_picture_alloc_and_clean(lib):
     assert C.cast(pic.img.plane[1], C.c_void_p).value == base + 64 * 32 and C.cast(pic.img.plane[2], C.c_void_p).value == base + 64 * 32 * 5 // 4
     lib.p264_picture_clean(C.byref(pic))
     assert pic.img.i_plane == 0 and not pic.img.plane[0]
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "p264decoder.c")), reason="build container only: the reference's source does not travel")
+def test_the_reference_cli_links_unchanged_against_the_library(lib, tmp_path):
+    """the reference's own caller (p264decoder.c:69-381: main, Decode, write_frame) compiled from
+    where it lies, UNCHANGED, with the reference's headers, and linked against libp264amd.so instead of the reference's core/ and
+    decoder/ objects - every symbol it needs (p264_param_default, p264_decoder_open / _decode / _close, p264_nal_decode,
+    p264_mdate) must resolve to the library.  The one thing supplied is the `config.h` its line 44 includes: upstream's configure
+    writes it, this tree has no configure, SURVEY App. C uses an empty one - so does this test (in tmp, nothing enters the repo).
+    Run here without a GPU the binary must get as far as the reference would with a decoder that cannot open: Help() on no
+    arguments, and "p264_decoder_open failed" on `-d` (p264decoder.c:203-207) - through OUR p264_decoder_open."""
+    (tmp_path / "config.h").write_text("")
+    exe = str(tmp_path / "p264decoder_ref_cli")
+    cc = subprocess.run(["gcc", "-O1", "-std=gnu99", "-w", "-D__P264__", "-DHAVE_STDINT_H", "-I" + str(tmp_path), "-I" + REF, os.path.join(REF, "p264decoder.c"),
+                         "-L" + os.path.dirname(N.LIB_PATH), "-lp264amd", "-Wl,-rpath," + os.path.dirname(N.LIB_PATH), "-Wl,--no-undefined", "-lm", "-o", exe],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert cc.returncode == 0, cc.stdout[-3000:]
+    # every p264_* symbol the caller leaves undefined is one the library defines
+    undefined = {l.split()[-1] for l in subprocess.run(["nm", "-u", exe], stdout=subprocess.PIPE, text=True).stdout.splitlines() if " p264_" in l or l.strip().startswith("U p264_")}
+    undefined = {u.split("@")[0] for u in undefined}
+    assert {"p264_param_default", "p264_decoder_open", "p264_decoder_decode", "p264_decoder_close", "p264_nal_decode", "p264_mdate"} <= undefined
+    assert all(hasattr(lib, u) for u in undefined), undefined
+    ldd = subprocess.run(["ldd", exe], stdout=subprocess.PIPE, text=True).stdout
+    assert "libp264amd.so" in ldd and "not found" not in ldd
+    import torch
+    if not torch.cuda.is_available():
+        stream = os.path.join(ROOT, "tests", "golden", "f26.264")
+        run = subprocess.run([exe, "-d", stream, str(tmp_path / "out.yuv")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120,
+                             env=dict(os.environ, P264AMD_QUIET="1"))
+        assert "p264_decoder_open failed" in run.stderr             # no HIP device: the drop-in refuses to open (no CPU fallback)

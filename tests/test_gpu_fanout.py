@@ -214,3 +214,25 @@ def test_rccl_two_ranks(lib):
     for s in range(4):
         for i in range(6):
             assert got[(s, i)] == hashes[i], "stream %d picture %d differs from the reference decoder" % (s, i)
+
+
+@pytest.mark.parametrize("device_road", [False, True])
+def test_fanout_config5_stream_two_ranks_one_gpu(lib, monkeypatch, device_road):
+    """BASELINE config 5's own kind of stream - 1080p Main profile, CABAC, I + P + B - through two ranks with the product
+    backend on both: parsed on rank 0 (CABAC), scattered with its list-1 arrays and weight tables, reconstructed by the HIP
+    kernels of both ranks, gathered, every picture against the committed oracle hashes (the reference cannot decode it).  Host
+    road and device road."""
+    if device_road:
+        monkeypatch.setenv("P264AMD_FAN_TCP_DEVICE", "1")
+    else:
+        monkeypatch.delenv("P264AMD_FAN_TCP_DEVICE", raising=False)
+    name = "main_1080p_cabac_ipb"
+    data = open(synth_cases.generate(synth_cases.ORACLE_CASES[name]), "rb").read()
+    hashes = synth_cases.oracle_golden(name)[1]
+    n = len(hashes)
+    got, st = fan_helpers.run_job(2, [data, data, data], n, False, 31000 + (os.getpid() % 200))
+    assert st["pictures"] == 3 * n and st["pictures_remote"] == n and st["bytes_gathered"] == n * 3133440
+    assert st["device_road_rounds"] == (n if device_road else 0)
+    for s in range(3):
+        for i in range(n):
+            assert got[(s, i)] == hashes[i], "stream %d picture %d differs from the oracle" % (s, i)

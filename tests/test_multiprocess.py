@@ -6,6 +6,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -65,3 +67,29 @@ def test_sharding_is_a_partition():
     for world in (1, 2, 4, 8):
         owned = [shard.streams_of_rank(37, r, world) for r in range(world)]
         assert sorted(sum(owned, [])) == list(range(37))
+
+
+def _bench(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if "WORLD_SIZE" not in env_extra:
+        env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """`--gpus 8` under a launcher that started one rank used to run ONE rank and print n_gpus = 1."""
+    out = _bench(["--gpus", "8", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert out.returncode == 2 and "--gpus 8 but WORLD_SIZE = 1" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """No WORLD_SIZE: bench.py is its own launcher.  Without a GPU the ranks it starts refuse to run (no CPU fallback) - both of
+    them, each under its own RANK - and the parent reports the failure instead of a JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher (the GPU box runs tests/test_gpu_bench_ranks.py)")
+    out = _bench(["--gpus", "2", "--steps", "1", "--streams", "2", "--no-extras"], {})
+    assert out.returncode != 0 and not out.stdout.strip()
+    assert out.stderr.count("bench.py needs an MI355X") == 2 and "the ranks failed" in out.stderr

@@ -371,6 +371,7 @@ def extras(lib, baseline_stream=None):
         out["end_to_end_pipeline"] = {"value": round(fps, 1), "unit": "frames/s", "streams": n_streams, "host_threads": threads, "cpu_quota": quota, "cpus_visible": os.cpu_count(),
                                       "by_threads": table, "single_thread_parse_fps": round(st1["pictures"] / st1["seconds"], 1),
                                       "upload_GBps": round(st["bytes_uploaded"] / st["seconds"] / 1e9, 2) if "bytes_uploaded" in st else None,
+                                      "main_thread_waits_s": {"for_the_parsers": round(st["wait_parse_seconds"], 3), "for_the_device": round(st["wait_device_seconds"], 3), "of": round(st["seconds"], 3)},
                                       "what": "Annex-B in host memory -> CAVLC parse on the host threads (into registered huge pages) -> DMA uploads -> batched reconstruction; pictures stay in HBM; "
                                               "bound by the host parse: compare parse_only_fps (same threads, no GPU)"}
         # ... and the reference beside it: as many reference processes as the pipeline had parser threads, on the same cores
@@ -528,6 +529,92 @@ def cpu_baseline_n(stream_path, n_procs, loops=12):
                       % (n_procs, loops, frames, dt)}
 
 
+def kernel_fingerprint():
+    """SHA-256 over the HIP sources (csrc/hip/*, names and contents): what a counter summary under profiles/ was collected on.
+    profiles/summarize.py stamps traffic_latest.json with it; a summary of other kernels is STALE and is not replayed."""
+    import hashlib
+    d = os.path.join(ROOT, "p264decoder_amd", "csrc", "hip")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
+    return h.hexdigest()
+
+
+def live_counters(S, edge_info_fused, counters=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"), budget_s=200):
+    """HBM traffic and vector instructions of THIS build on THIS box: one rocprofv3 --pmc pass per counter (never combined with
+    a trace; MI355X_MICROARCH.md's HBM section) around a short child run of this same script - the same streams, the same
+    batch, 1 warm-up + 2 timed P launches, no extras (so the child never gets here).  Per stage: bytes per launch =
+    (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950: FETCH_SIZE counts a 128-byte request as 64), averaged over the P launches.
+    Returns None when rocprofv3 is missing, refuses, or runs out of its time budget - the caller then falls back to the
+    committed summary if that is of the same kernels."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="p264amd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t_end = time.time() + budget_s
+    agg = {}
+    try:
+        for ctr in counters:
+            left = t_end - time.time()
+            if left < 20:
+                return None
+            d = os.path.join(tmp, ctr)
+            cmd = [prof, "--pmc", ctr, "--kernel-include-regex", "^(void )?k_", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--streams", str(S), "--no-extras", "--no-cpu-baseline"]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd="/tmp", env=env, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None
+            found = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not found:
+                return None
+            for row in csv.DictReader(open(max(found, key=os.path.getmtime))):
+                k = row["Kernel_Name"].split("(")[0]
+                k = k[5:] if k.startswith("void ") else k
+                agg.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def avg(k, c):
+        # (the P launches only: the first launch of k_deblock is the IDR picture's; k_mc* and k_intra_sparse have none for it)
+        v = agg.get(k, {}).get(c, [])
+        v = v[1:] if k.startswith("k_deblock") and len(v) > 1 else v
+        return sum(v) / len(v) if v else 0.0
+    stage_kernels_ = {"inter": ("k_mc_sort", "k_mc"), "intra": ("k_intra_sparse",), "deblock": ("k_deblock",) if edge_info_fused else ("k_deblock", "k_deblock_bs<false>")}
+    out = {"launches_averaged": len(agg.get("k_mc", {}).get(counters[0], []))}
+    for stage, ks in stage_kernels_.items():
+        out[stage] = {"traffic": int(sum(2 * avg(k, "FETCH_SIZE") + avg(k, "WRITE_SIZE") for k in ks) * 1024) if "FETCH_SIZE" in counters else None,
+                      "valu": int(sum(avg(k, "SQ_INSTS_VALU") for k in ks)) if "SQ_INSTS_VALU" in counters else None,
+                      "per_kernel": {k: {c: round(avg(k, c)) for c in counters} for k in ks}}
+    return out
+
+
+def static_traffic(stage, S):
+    """HBM traffic cannot be counted inside this run (PMC counters need rocprofv3 passes of their own): it is replayed
+    from the committed summary of the same command profiled on the same code (profiles/collect.sh), and says so."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(tpath):
+        return None, None
+    try:
+        tj = json.load(open(tpath))
+        if tj.get("kernels_sha256") != kernel_fingerprint():
+            # (the driver's line must not carry a traffic figure of kernels that are no longer the ones that ran)
+            sys.stderr.write("bench.py: profiles/traffic_latest.json was collected on other kernels (csrc/hip changed since %s): NOT replayed - "
+                             "run profiles/collect.sh + summarize.py\n" % tj.get("source"))
+            return None, "STALE: profiles/%s was collected on other kernels than this build's (csrc/hip fingerprint differs); not replayed" % tj.get("source")
+        if S == int(tj.get("pictures_per_launch", 1024)):              # (counted for the default batch: scaled to nothing else)
+            return tj.get(stage), "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
+        return None, "none: profiles/%s was collected at %d pictures per launch, this run has %d" % (tj.get("source"), int(tj.get("pictures_per_launch", 1024)), S)
+    except Exception:
+        return None, None
+
+
 def measured_copy_bandwidth(torch):
     """Achievable HBM ceiling on this box next to the 8 TB/s vendor peak: device-to-device copy of 1 GiB,
     bytes read + bytes written per second."""
@@ -593,6 +680,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2048, help="independent 1080p streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (HBM traffic, vector instructions) behind the timed region")
     ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0)")
     ap.add_argument("--only-batch-256", action="store_true", help="print extras.batch_256 (the metric's workload at 256 pictures per launch) and nothing else")
     args = ap.parse_args()
@@ -715,19 +803,7 @@ def main():
                     kernels[name]["frac_with_residual"] = round(alg["inter_with_residual"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
 
-        def traffic_of(stage):
-            """HBM traffic cannot be counted inside this run (PMC counters need rocprofv3 passes of their own): it is replayed
-            from the committed summary of the same command profiled on the same code (profiles/collect.sh), and says so."""
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if not os.path.exists(tpath):
-                return None, None
-            try:
-                tj = json.load(open(tpath))
-                if S == int(tj.get("pictures_per_launch", 1024)):              # (counted for the default batch: scaled to nothing else)
-                    return tj.get(stage), "static: profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3`, %s" % (tj.get("source"), tj.get("formula"))
-                return None, "none: profiles/%s was collected at %d pictures per launch, this run has %d" % (tj.get("source"), int(tj.get("pictures_per_launch", 1024)), S)
-            except Exception:
-                return None, None
+        traffic_of = lambda stage: static_traffic(stage, S)   # noqa: E731
 
         def valu_of(stage):
             """Vector-instruction issue of the stage's kernels: instructions per launch from the committed counter summary (like the
@@ -735,7 +811,7 @@ def main():
             SIMD of the device.  The kernels of this path are bound by instruction issue as much as by HBM."""
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-                if S != int(tj.get("pictures_per_launch", 1024)):
+                if S != int(tj.get("pictures_per_launch", 1024)) or tj.get("kernels_sha256") != kernel_fingerprint():
                     return None
                 pmc = json.load(open(os.path.join(ROOT, "profiles", tj["source"])))
                 names = {"inter": ("k_mc_sort", "k_mc"), "intra": ("k_intra_sparse",), "deblock": ("k_deblock",) if EDGE_INFO_FUSED else ("k_deblock", "k_deblock_bs<false>")}[stage]
@@ -787,6 +863,30 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: a reported baseline, not part of the scaling runs
             out["cpu_baseline"] = cpu_baseline(paths[0], T)
     hip.close()
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_live_counters:
+        # counters of this build on this box, in child processes after the timed region (never inside it)
+        try:
+            live = live_counters(S, EDGE_INFO_FUSED)
+        except Exception as e:                              # noqa: BLE001 - the committed summary stays
+            live = None
+            sys.stderr.write("bench.py: live counters failed: %r\n" % (e,))
+        if live:
+            prop = torch.cuda.get_device_properties(local_rank)
+            for r in (out["roofline"], out["roofline_mc"]):
+                if not r or not live[r["stage"]]["traffic"]:
+                    continue
+                lv, st = live[r["stage"]], r["stage"]
+                r.update(traffic=lv["traffic"], traffic_over_algorithmic=round(lv["traffic"] / kernels[st]["algorithmic_bytes"], 3),
+                         traffic_source="live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate, no trace) of a child `bench.py --steps 2 --warmup 1 --streams %d` on this box "
+                                        "after the timed region, (2*FETCH_SIZE + WRITE_SIZE) KB averaged over %d P launches" % (S, live["launches_averaged"]),
+                         counters_per_kernel=lv["per_kernel"])
+                if st == "inter":
+                    r["traffic_over_algorithmic_with_residual"] = round(lv["traffic"] / kernels[st]["algorithmic_bytes_with_residual"], 3)
+                if lv["valu"]:
+                    simds, hz = prop.multi_processor_count * 4, 2.24e9
+                    r["valu"] = {"wave_instructions_per_launch": lv["valu"], "issue_cycles_frac": round(lv["valu"] * 4.0 / (kernels[st]["avg_ms"] * 1e-3 * hz * simds), 3),
+                                 "simds": simds, "clock_MHz": round(hz / 1e6), "clock_source": "measured under load in round 5 (GRBM_GUI_ACTIVE), static here",
+                                 "source": "live: SQ_INSTS_VALU pass of the same child run, 4 cycles per wave instruction"}
     fan = None
     if world > 1 and not args.no_fanout and os.environ.get("P264AMD_BENCH_FANOUT", "1") != "0":
         fan = fanout_leg(rank, local_rank, world, lib)       # after the timed region, in child processes, never `value`

@@ -29,6 +29,8 @@ typedef struct {
     int     rounds, streams, threads;
     int     reserved;
     int64_t bytes_uploaded;      /* parsed-picture bytes copied host -> HBM (0 when the parsers run alone) */
+    double  wait_parse_seconds;  /* the main thread's wait for the last parse task of a round, summed (parser-bound run: most of `seconds`) */
+    double  wait_device_seconds; /* ... and for the device to be through a round's uploads and kernels (a GPU-bound run shows here) */
 } p264pipe_stats_t;
 
 p264pipe *p264pipe_open(int device, int n_streams, int n_threads);

@@ -67,7 +67,7 @@ class PipeStats(C.Structure):
     """p264pipe_stats_t"""
     _fields_ = [("pictures", C.c_int64), ("bytes", C.c_int64), ("seconds", C.c_double), ("parse_seconds", C.c_double),
                 ("submit_seconds", C.c_double), ("rounds", C.c_int), ("streams", C.c_int), ("threads", C.c_int), ("reserved", C.c_int),
-                ("bytes_uploaded", C.c_int64)]
+                ("bytes_uploaded", C.c_int64), ("wait_parse_seconds", C.c_double), ("wait_device_seconds", C.c_double)]
 
 _lib = None
 

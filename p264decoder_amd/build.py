@@ -18,12 +18,14 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libp264amd.so")
 TOOLS_DIR = os.path.join(HERE, "tools")
 
-HOST_SRCS = ["parser.c", "vlc.c", "cabac.c", "dropin.c", "pipeline.c", "fanout.c", "input_layout.c"]
+HOST_SRCS = ["parser.c", "vlc.c", "cabac.c", "dropin.c", "pipeline.c", "fanout.c", "input_layout.c", "cpu_check.c"]
+HOST_BASELINE = {"cpu_check.c"}      # built WITHOUT HOST_ARCH: its constructor looks at the CPU before any x86-64-v3 code runs
 HIP_SRCS = ["p264hip.hip", "fan_rccl.hip"]
 HIP_ARCH = "gfx950"
 # host code for AVX2 / BMI2 machines (every EPYC; the GPU boxes are Zen 5): the CABAC parse gains 4.5 % per thread, CAVLC
 # nothing (scratch/r5_parse_flags.sh; -march=znver3, -O2 and a profile-guided build all lose on CAVLC).  p264parse_open refuses
-# to run on an older CPU.
+# to run on an older CPU - and so does every other public entry of the host objects (cpu_check.c: a library constructor, the one
+# object built for plain x86-64).  Needs gcc >= 11 (-march=x86-64-v3).
 HOST_ARCH = ["-march=x86-64-v3", "-falign-functions=64"]     # (functions on cache-line boundaries: CAVLC + 1.5 % per thread, scratch/r5_parse_ab.sh)
 
 
@@ -63,7 +65,7 @@ def build(force=False, verbose=False):
         src = os.path.join(HOST_DIR, s)
         obj = os.path.join(OBJ_DIR, s + ".o")
         if force or _newer(obj, [src] + hdrs):
-            out = _run(["gcc", "-O3"] + HOST_ARCH + ["-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-I" + INC, "-I" + HOST_DIR, "-c", src, "-o", obj])
+            out = _run(["gcc", "-O3"] + ([] if s in HOST_BASELINE else HOST_ARCH) + ["-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-I" + INC, "-I" + HOST_DIR, "-c", src, "-o", obj])
             if verbose and out:
                 print(out)
         objs.append(obj)

@@ -155,7 +155,9 @@ extern "C" int p264hip_create(p264hip_ctx **out, int device, int mb_w, int mb_h,
     g.w = mb_w * 16; g.h = mb_h * 16; g.cw = g.w / 2; g.ch = g.h / 2;
     g.ystrip = (uint32_t)g.h * 16u; g.cstrip = (uint32_t)g.ch * 16u; g.coff = (uint32_t)g.n_mb * MB_LUMA_BYTES;
     c->frame_bytes = align_up((size_t)g.n_mb * (MB_LUMA_BYTES + MB_CHROMA_BYTES), 256);      // strip layout (device_common.h)
-    if (c->frame_bytes * (size_t)slots >= (1ull << 32)) { delete c; return fail(P264HIP_EINVAL, "frame store of one stream exceeds 4 GiB (%d slots of %zu bytes)", slots, c->frame_bytes); }
+    // (one stream's store is addressed by 32-bit offsets through one buffer descriptor, and the kernels use MC_OOB as "an offset
+    // beyond any store" for loads that must return zeros - kernel_mc.h: the store has to end at or below it)
+    if (c->frame_bytes * (size_t)slots > (size_t)MC_OOB) { delete c; return fail(P264HIP_EINVAL, "frame store of one stream exceeds %u bytes (%d slots of %zu bytes)", MC_OOB, slots, c->frame_bytes); }
     {   // locality band of the motion-compensation lists: 16 macroblock rows unless that makes more than MC_MAX_BANDS bands
         int band_log2 = 4;
         if (const char *e = getenv("P264AMD_MC_BAND_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 9) band_log2 = v; }
@@ -479,6 +481,10 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
         d.cap = need;
     }
     HIPCHK(hipMemcpyAsync(d.dev, s.dev, need, hipMemcpyDeviceToDevice, c->stream));
+    // the verdict of the record check is kept per slot (k_check_records -> d_slot_bad[slot]): an unchecked block takes its
+    // verdict along (behind the check on the same stream), any other clone clears what an earlier tenant of dst left there
+    if (s.unchecked) HIPCHK(hipMemcpyAsync(c->d_slot_bad + dst, c->d_slot_bad + src, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(hipMemsetAsync(c->d_slot_bad + dst, 0, sizeof(int), c->stream));
     d.off_mv = s.off_mv; d.off_ref = s.off_ref; d.off_i4 = s.off_i4; d.off_coef = s.off_coef; d.off_mv_l1 = s.off_mv_l1; d.off_ref_l1 = s.off_ref_l1; d.off_weights = s.off_weights; d.bytes = s.bytes;
     d.meta = s.meta; d.valid = true; d.unchecked = s.unchecked; d.last_use = s.last_use = ++c->epoch;
     return P264HIP_OK;
@@ -580,6 +586,11 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         any_p |= s.meta.slice_type != P264_SLICE_I;
         any_i |= s.meta.slice_type == P264_SLICE_I;
     }
+    // from here on work that reads the batch's input slots is (about to be) queued: the slots carry the new epoch BEFORE the first
+    // launch, so that whichever way this function returns - a launch error half-way included - a later p264hip_input_reserve
+    // of one of them waits for the stream instead of letting a peer overwrite a block under running kernels
+    ++c->epoch;
+    for (int i = 0; i < n; i++) c->pics[(size_t)pic_ids[i]].last_use = c->epoch;
     ScopedStamp whole(c, 3);
     HIPCHK(hipMemcpyAsync(c->d_batch[r], hb, (size_t)n * sizeof(PicDev), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->batch_free[r], c->stream));
@@ -676,8 +687,6 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
                            (const EdgeInfo *)c->d_edge, c->d_status, n, rb_log2, per_wg, odd_single);
     }
     HIPCHK(hipGetLastError());
-    ++c->epoch;
-    for (int i = 0; i < n; i++) c->pics[(size_t)pic_ids[i]].last_use = c->epoch;
     return P264HIP_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <string.h>
 #include "cabac.h"
 #include "p264parse.h"
+#include "host_cpu.h"
 
 void p264cabac_init_contexts(p264cabac_t *c, int is_i_slice, int cabac_init_idc, int slice_qp)
 {
@@ -33,6 +34,7 @@ void p264cabac_start(p264cabac_t *c, const uint8_t *data, size_t bytes)
 int p264cabac_decode_ops(const uint8_t *data, size_t bytes, int is_i_slice, int cabac_init_idc, int slice_qp,
                          const int16_t *ops, int n_ops, uint8_t *bins)
 {
+    if (p264amd_cpu_refuse("p264cabac_decode_ops")) return -1;
     if (!data || !ops || !bins || n_ops < 0) return -1;
     p264cabac_t c;
     p264cabac_init_contexts(&c, is_i_slice, cabac_init_idc, slice_qp);

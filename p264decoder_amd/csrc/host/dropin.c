@@ -14,6 +14,7 @@
 #include "p264_dropin.h"
 #include "p264parse.h"
 #include "p264hip.h"
+#include "host_cpu.h"
 
 #define OUT_BUFS 2
 
@@ -158,6 +159,7 @@ int64_t p264_mdate(void)
 
 p264_t *p264_decoder_open(p264_param_t *param)
 {
+    if (p264amd_cpu_refuse("p264_decoder_open")) return NULL;
     if (p264hip_device_count() < 1) {
         fprintf(stderr, "p264amd: no HIP device: the MI355X reconstruction path cannot run and there is no CPU fallback\n");
         return NULL;

@@ -16,6 +16,7 @@
 #include "p264fan.h"
 #include "p264parse.h"
 #include "p264_dropin.h"
+#include "host_cpu.h"
 
 static __thread char g_err[512] = "";
 static int fail(const char *fmt, ...)
@@ -244,6 +245,7 @@ static void tcp_close(void *c)
 }
 int p264fan_tcp_transport(p264fan_transport_t *out, int rank, int world, const char *host, int port)
 {
+    if (p264amd_cpu_refuse("p264fan_tcp_transport")) return p264fan_set_error("p264fan_tcp_transport: CPU older than the build's target (x86-64-v3)");
     if (!out || world < 1 || rank < 0 || rank >= world || port < 1 || port > 65535) return fail("p264fan_tcp_transport: bad argument");
     tcp_t *t = (tcp_t *)calloc(1, sizeof *t);
     if (!t) return fail("out of memory");
@@ -298,6 +300,7 @@ struct p264fan {
 
 p264fan *p264fan_open(int rank, int world, const p264fan_transport_t *t, const p264fan_backend_t *backend, int device)
 {
+    if (p264amd_cpu_refuse("p264fan_open")) { p264fan_set_error("p264fan_open: CPU older than the build's target (x86-64-v3)"); return NULL; }
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && (!t || !t->send || !t->recv))) { fail("p264fan_open: bad argument"); return NULL; }
     p264fan *f = (p264fan *)calloc(1, sizeof *f);
     if (!f) { fail("out of memory"); return NULL; }

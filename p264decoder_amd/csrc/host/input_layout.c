@@ -3,6 +3,7 @@
  * stream fan-out packs pictures on the rank that parses them, include/p264fan.h); the device side is p264hip.hip. */
 #include <string.h>
 #include "p264hip.h"
+#include "host_cpu.h"
 
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -29,6 +30,7 @@ int p264hip_input_layout(const p264hip_picture_t *d, p264hip_input_layout_t *o)
 
 int64_t p264hip_pack_input(const p264hip_picture_t *p, void *dst_, size_t cap)
 {
+    if (p264amd_cpu_refuse("p264hip_pack_input")) return P264HIP_EINVAL;
     p264hip_input_layout_t L;
     if (!p || !dst_ || p264hip_input_layout(p, &L)) return P264HIP_EINVAL;
     if (cap < L.bytes) return P264HIP_ENOMEM;
@@ -57,6 +59,7 @@ int64_t p264hip_pack_input(const p264hip_picture_t *p, void *dst_, size_t cap)
 
 int p264hip_unpack_input(const p264hip_picture_t *desc, const void *packed, size_t bytes, p264hip_picture_t *pic)
 {
+    if (p264amd_cpu_refuse("p264hip_unpack_input")) return P264HIP_EINVAL;
     p264hip_input_layout_t L;
     if (!desc || !packed || !pic || p264hip_input_layout(desc, &L) || bytes < L.bytes) return P264HIP_EINVAL;
     const uint8_t *b = (const uint8_t *)packed;

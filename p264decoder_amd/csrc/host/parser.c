@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "p264parse.h"
+#include "host_cpu.h"
 #include "bits.h"
 #include "vlc.h"
 #include "cavlc_tables.h"
@@ -1360,21 +1361,9 @@ static int decode_slice(p264parse *p, int nal_type, int nal_ref_idc, const uint8
 }
 
 /* ---------------------------------------------------------------- public ---------------- */
-/* The host sources are built for x86-64-v3 (build.py: BMI2 shifts and LZCNT are worth 4.5 % on the CABAC parse, nothing on
- * CAVLC): say so instead of dying on an illegal instruction where the CPU is older than that. */
-#if defined(__x86_64__) && defined(__AVX2__)
-__attribute__((target("arch=x86-64"))) static int cpu_is_v3(void)
-{
-    __builtin_cpu_init();
-    return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("fma");
-}
-#else
-static int cpu_is_v3(void) { return 1; }
-#endif
-
 p264parse *p264parse_open(int options)
 {
-    if (!cpu_is_v3()) { fprintf(stderr, "p264amd: this build of the host parser needs an x86-64-v3 CPU (AVX2, BMI2)\n"); return NULL; }
+    if (p264amd_cpu_refuse("p264parse_open")) return NULL;     /* (cpu_check.c: the host objects are built for x86-64-v3) */
     if (cavlc_global_init() != 0) { fprintf(stderr, "p264amd: CAVLC tables are not prefix-free\n"); return NULL; }
     p264parse *p = (p264parse *)calloc(1, sizeof *p);
     if (!p) return NULL;

@@ -20,6 +20,7 @@
 #include "p264parse.h"
 #include "p264hip.h"
 #include "p264_dropin.h"
+#include "host_cpu.h"
 
 typedef struct {
     p264parse *parser;
@@ -36,7 +37,8 @@ struct p264pipe {
     p264hip_ctx *ctx; int mb_w, mb_h, slots;
     /* thread pool */
     pthread_t *threads; int started;
-    pthread_mutex_t mu; pthread_cond_t go, idle;
+    pthread_mutex_t mu; pthread_cond_t go, idle, turn;
+    int turn_waiters;                    /* (under mu) threads blocked on `turn`: a stream's previous picture is still being parsed */
     int generation, busy, quit, max_pictures;
     /* one run: tasks t = round * n_streams + stream, taken in order */
     long long next_task;                 /* (atomic) */
@@ -94,7 +96,16 @@ static void *worker(void *arg)
             pthread_mutex_unlock(&p->mu);
             if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) break;
             /* the stream's previous picture is parsed (tasks are taken in order, so it nearly always is: a parser is not reentrant) */
-            while (__atomic_load_n(&p->parsed[s], __ATOMIC_ACQUIRE) < R && !__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) sched_yield();
+            /* (a few yields, then BLOCK: with about as many threads as streams a finished thread routinely draws a stream whose
+             * previous picture another thread is still parsing - spinning there burns the CPU quota the parsers need) */
+            for (int spins = 0; __atomic_load_n(&p->parsed[s], __ATOMIC_ACQUIRE) < R && !__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE); ) {
+                if (++spins <= 32) { sched_yield(); continue; }
+                pthread_mutex_lock(&p->mu);
+                p->turn_waiters++;
+                while (__atomic_load_n(&p->parsed[s], __ATOMIC_ACQUIRE) < R && !__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) pthread_cond_wait(&p->turn, &p->mu);
+                p->turn_waiters--;
+                pthread_mutex_unlock(&p->mu);
+            }
             if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) break;
             double t0 = now_s();
             parse_one(p, &p->st[s]);
@@ -104,6 +115,7 @@ static void *worker(void *arg)
             const int failed = __atomic_load_n(&p->st[s].failed, __ATOMIC_RELAXED);
             pthread_mutex_lock(&p->mu);
             if (failed) p->failed_in_round[R & 1] = 1;
+            if (p->turn_waiters) pthread_cond_broadcast(&p->turn);     /* (parsed[s] was stored before mu was taken: a waiter has seen it or is waiting) */
             if (++p->parsed_in_round[R & 1] == S) pthread_cond_signal(&p->idle);
             pthread_mutex_unlock(&p->mu);
         }
@@ -129,6 +141,7 @@ static void end_run(p264pipe *p)
     pthread_mutex_lock(&p->mu);
     __atomic_store_n(&p->stop, 1, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&p->go);
+    pthread_cond_broadcast(&p->turn);
     while (p->busy) pthread_cond_wait(&p->idle, &p->mu);
     pthread_mutex_unlock(&p->mu);
 }
@@ -153,6 +166,7 @@ static void rounds_done(p264pipe *p, int r)
 
 p264pipe *p264pipe_open(int device, int n_streams, int n_threads)
 {
+    if (p264amd_cpu_refuse("p264pipe_open")) return NULL;
     if (n_streams < 1 || n_threads < 1) return NULL;
     if (device >= 0 && p264hip_device_count() <= device) {
         fprintf(stderr, "p264pipe_open: no HIP device %d (there is no CPU fallback for the reconstruction; device -1 runs the parsers only)\n", device);
@@ -166,7 +180,7 @@ p264pipe *p264pipe_open(int device, int n_streams, int n_threads)
     p->parsed = (int *)calloc((size_t)n_streams, sizeof(int));
     p->round_pic[0] = (const p264hip_picture_t **)calloc((size_t)n_streams, sizeof(void *));
     p->round_pic[1] = (const p264hip_picture_t **)calloc((size_t)n_streams, sizeof(void *));
-    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->idle, NULL);
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->idle, NULL); pthread_cond_init(&p->turn, NULL);
     if (!p->st || !p->threads || !p->parsed || !p->round_pic[0] || !p->round_pic[1]) { p264pipe_close(p); return NULL; }
     for (int i = 0; i < n_streams; i++) {
         p->st[i].parser = p264parse_open(P264PARSE_OPT_QUIET);
@@ -248,6 +262,7 @@ int p264pipe_run(p264pipe *p, int max_pictures, p264pipe_stats_t *stats)
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->pictures = pictures; stats->seconds = t1 - t0; stats->parse_seconds = p->parse_seconds; stats->submit_seconds = submit;
+        stats->wait_parse_seconds = wait_parse; stats->wait_device_seconds = wait_gpu;
         stats->rounds = rounds; stats->streams = p->n_streams; stats->threads = p->n_threads; stats->bytes_uploaded = uploaded;
         for (int i = 0; i < p->n_streams; i++) stats->bytes += p->st[i].pos;
     }
@@ -282,7 +297,7 @@ void p264pipe_close(p264pipe *p)
     if (p->ctx) { (void)p264hip_sync(p->ctx); }
     if (p->st) for (int i = 0; i < p->n_streams; i++) { if (p->st[i].parser) p264parse_close(p->st[i].parser); free(p->st[i].rbsp); }
     if (p->ctx) p264hip_destroy(p->ctx);
-    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->idle);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->idle); pthread_cond_destroy(&p->turn);
     free(p->parsed); free((void *)p->round_pic[0]); free((void *)p->round_pic[1]);
     free(p->st); free(p->threads); free(p);
 }

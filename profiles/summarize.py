@@ -60,6 +60,9 @@ def hbm_any(prefix):
 bs_own_launch = any(k.startswith("k_deblock_bs") and pmc[k].get("launches_averaged", 0) + 1 >= pmc.get("k_deblock", {}).get("launches_averaged", 0) for k in pmc)
 traffic = {"inter": hbm_any("k_mc"), "intra": hbm("k_intra_sparse" if "k_intra_sparse" in pmc else "k_intra"), "deblock": hbm_any("k_deblock") if bs_own_launch else hbm("k_deblock"),
            "unit": "bytes per launch", "source": tag + "_pmc.json", "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB"}
+sys.path.insert(0, os.path.join(here, ".."))
+import bench                                               # noqa: E402 - the fingerprint of the kernels these counters belong to
+traffic["kernels_sha256"] = bench.kernel_fingerprint()      # (run summarize.py on the tree the collection ran on)
 traffic["pictures_per_launch"] = int(json.load(open(os.path.join(here, tag + "_bench.json")))["config"]["pictures_per_step"])   # bench.py's default batch, which collect.sh profiles
 if "--no-latest" in sys.argv:                              # (a profile of another batch size: its own file, bench.py's roofline keeps the default batch's)
     json.dump(traffic, open(os.path.join(here, tag + "_traffic.json"), "w"), indent=1)

@@ -25,3 +25,24 @@ def test_the_accounting_does_not_read_the_environment(monkeypatch):
     import inspect
     src = inspect.getsource(bench)
     assert "P264AMD_BS_FUSED" not in src.replace('P264AMD_BS_FUSED=0 gives it its own launch', "")
+
+
+def test_a_counter_summary_of_other_kernels_is_not_replayed(monkeypatch, capsys):
+    """roofline.traffic is replayed from profiles/traffic_latest.json only while that summary belongs to THIS build's kernels
+    (fingerprint over csrc/hip); after any kernel change it is reported as STALE (null + a line on stderr), never silently."""
+    import json
+    import os
+    tj = json.load(open(os.path.join(bench.ROOT, "profiles", "traffic_latest.json")))
+    S = int(tj["pictures_per_launch"])
+    monkeypatch.setattr(bench, "kernel_fingerprint", lambda: tj["kernels_sha256"])
+    t, src = bench.static_traffic("inter", S)
+    assert t == tj["inter"] and src.startswith("static: profiles/")
+    assert bench.static_traffic("inter", S + 1)[0] is None
+    monkeypatch.setattr(bench, "kernel_fingerprint", lambda: "0" * 64)
+    t, src = bench.static_traffic("inter", S)
+    assert t is None and src.startswith("STALE") and "NOT replayed" in capsys.readouterr().err
+
+
+def test_kernel_fingerprint_follows_the_sources(tmp_path, monkeypatch):
+    a = bench.kernel_fingerprint()
+    assert len(a) == 64 and a == bench.kernel_fingerprint()

@@ -236,3 +236,40 @@ def test_fanout_config5_stream_two_ranks_one_gpu(lib, monkeypatch, device_road):
     for s in range(3):
         for i in range(n):
             assert got[(s, i)] == hashes[i], "stream %d picture %d differs from the oracle" % (s, i)
+
+
+def test_a_clone_takes_the_verdict_of_the_record_check_along(lib):
+    """k_check_records' verdict lives per input slot: p264hip_clone_picture of a block a device producer committed must carry it
+    to the clone (a bad block's clone is an error too, not an out-of-bounds walk through coefs[]), and a clone of a good block
+    must not inherit what an earlier, bad tenant of the destination slot left behind."""
+    import numpy as np
+    from p264decoder_amd import HipReconstructor, Parser
+    parser = Parser(quiet=True, lib=lib)
+    p = parser.parse_stream(synth_cases.stream_bytes("cif_ip"))[0]
+    hip = HipReconstructor(p.mb_w, p.mb_h, n_streams=3, slots=parser.slots, max_pictures=4, lib=lib)
+    good = HipReconstructor.pack(p, lib)
+    bad = good.copy()
+    words = bad[:p.mb_w * p.mb_h * 16].view(np.uint32).reshape(-1, 4)
+    words[int(np.flatnonzero(words[:, 1] != 0)[0]), 2] = 0x7fffff00
+
+    def commit(slot, blk):
+        dev, n = hip.input_reserve(slot, p)
+        assert lib.p264hip_copy_to_device(dev, blk.ctypes.data, n) == 0
+        hip.input_commit(slot)
+    commit(1, bad)
+    hip.clone_picture(2, 1)                                       # unchecked and bad: the clone is as bad
+    with pytest.raises(Exception, match="outside coefs"):
+        hip.reconstruct([2], [2])
+    hip.sync()
+    with pytest.raises(Exception, match="outside coefs"):         # (and so is the original, still)
+        hip.reconstruct([1], [1])
+    hip.sync()
+    # slot 2 has held a bad block; a good block committed into slot 3 and cloned into slot 2 must decode
+    commit(3, good)
+    hip.clone_picture(2, 3)
+    hip.upload(0, [p])
+    hip.reconstruct([0, 2], [0, 2])
+    hip.sync()
+    for a, b in zip(hip.read_frame(0, p.desc.dst_slot), hip.read_frame(2, p.desc.dst_slot)):
+        assert np.array_equal(a, b)
+    hip.close()

@@ -62,3 +62,25 @@ def test_pack_refuses_records_that_point_outside_the_coefficients(lib):
     finally:
         p.desc.mb[coded[-1]].coef_index = keep
     assert lib.p264hip_pack_input(C.byref(p.desc), buf.ctypes.data, buf.size) == lay.bytes
+
+
+def test_every_host_entry_refuses_a_cpu_older_than_the_build(lib):
+    """The host objects are built for x86-64-v3; cpu_check.c (built for plain x86-64) looks at the CPU when the library is loaded
+    and every public entry of the other objects asks it - a message and an error instead of an illegal instruction.  The
+    verdict is a flag of the library: flipped here."""
+    import ctypes as C
+    from p264decoder_amd import Parser, _native
+    flag = C.c_int.in_dll(lib, "p264amd_cpu_unsupported")
+    assert flag.value == 0
+    pics = Parser(quiet=True, lib=lib).parse_stream(synth_cases.stream_bytes("tiny_1x1"))
+    flag.value = 1
+    try:
+        assert not lib.p264parse_open(0)
+        assert not lib.p264pipe_open(-1, 1, 1)
+        buf = (C.c_uint8 * (1 << 16))()
+        assert lib.p264hip_pack_input(C.byref(pics[0].desc), buf, len(buf)) < 0
+        p = _native.p264_param_t() if hasattr(_native, "p264_param_t") else None
+        assert not lib.p264_decoder_open(None if p is None else C.byref(p))
+    finally:
+        flag.value = 0
+    assert lib.p264hip_pack_input(C.byref(pics[0].desc), buf, len(buf)) > 0

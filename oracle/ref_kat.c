@@ -210,3 +210,48 @@ int refk_direct(int spatial, const int8_t *nb_ref, const int16_t *nb_mv, int col
     }
     return ok;
 }
+
+/* ---- the whole deblocking driver (core/frame.c:490-643: raster order, bS derivation :535-581, edge QPs :593-601, the table
+ *      look-ups and the tc = tc0 (+1 for chroma) of deblock_edge :472-488, the eight sample filters) on hand-made state.
+ *      Planes are MB-aligned without pads (stride = width), filtered in place.  Per macroblock: intra or not, QP, the 16 luma
+ *      4x4 blocks with coefficients as a bit mask in decode order (= the index of non_zero_count), list-0 reference index per
+ *      8x8 and vector per 4x4 (raster inside the macroblock).  P slices. ------------------------------------------------ */
+int refk_deblock_frame(int mb_w, int mb_h, uint8_t *y, uint8_t *u, uint8_t *v, const uint8_t *intra, const uint8_t *qp,
+                       const uint32_t *nnz_mask, const int8_t *ref8, const int16_t *mv4, int chroma_qp_offset, int alpha_off, int beta_off)
+{
+    static p264_sps_t sps;
+    p264_t *h = g_h;
+    const int n = mb_w * mb_h;
+    p264_frame_t fr;
+    memset(&fr, 0, sizeof fr);
+    int8_t *type = malloc(n), *q = malloc(n), *ts = calloc(n, 1), *ref = malloc(n * 4);
+    uint8_t (*nzc)[24] = calloc(n, 24);
+    int16_t (*mv)[2] = calloc(n * 16, sizeof(int16_t[2]));
+    if (!type || !q || !ts || !ref || !nzc || !mv) return -1;
+    for (int m = 0; m < n; m++) {
+        const int mx = m % mb_w, my = m / mb_w;
+        type[m] = intra[m] ? I_16x16 : P_L0;
+        q[m] = (int8_t)qp[m];
+        for (int b = 0; b < 16; b++) nzc[m][b] = (nnz_mask[m] >> b) & 1;
+        for (int k = 0; k < 4; k++) ref[(2 * my + (k >> 1)) * 2 * mb_w + 2 * mx + (k & 1)] = ref8[m * 4 + k];
+        for (int k = 0; k < 16; k++) {
+            int16_t *d = mv[(4 * my + (k >> 2)) * 4 * mb_w + 4 * mx + (k & 3)];
+            d[0] = mv4[(m * 16 + k) * 2]; d[1] = mv4[(m * 16 + k) * 2 + 1];
+        }
+    }
+    sps.i_mb_width = mb_w; sps.i_mb_height = mb_h;
+    h->sps = &sps;
+    g_pps.i_chroma_qp_index_offset = chroma_qp_offset;
+    h->sh.i_alpha_c0_offset = alpha_off; h->sh.i_beta_offset = beta_off;
+    h->param.b_cabac = 0;
+    h->mb.i_mb_stride = mb_w;
+    h->mb.type = type; h->mb.qp = q; h->mb.mb_transform_size = ts; h->mb.non_zero_count = nzc;
+    h->mb.ref[0] = ref; h->mb.mv[0] = mv;
+    fr.plane[0] = y; fr.plane[1] = u; fr.plane[2] = v;
+    fr.i_stride[0] = 16 * mb_w; fr.i_stride[1] = fr.i_stride[2] = 8 * mb_w;
+    h->fdec = &fr;
+    p264_frame_deblocking_filter(h, SLICE_TYPE_P);
+    h->fdec = NULL; h->mb.type = NULL; h->mb.qp = NULL; h->mb.mb_transform_size = NULL; h->mb.non_zero_count = NULL; h->mb.ref[0] = NULL; h->mb.mv[0] = NULL;
+    free(type); free(q); free(ts); free(ref); free(nzc); free(mv);
+    return 0;
+}

@@ -106,3 +106,51 @@ def test_bipred_average_and_weight(oracle):
         else:
             oracle.oracle_bipred_avg(P(o), 24, P(np.ascontiguousarray(b)), 24, w, h)
         assert np.array_equal(o, want), "size %dx%d weighted %d w1 %d" % (w, h, weighted, w1)
+
+
+def test_loop_filter_against_the_reference_frame_driver(oracle):
+    """tests/golden/kat_deblock_frame.npz (p264_frame_deblocking_filter on hand-made state, make_kat_frame.py): the oracle's
+    boundary strengths, table look-ups, filters and their order on 160 pictures; the same pictures go through the HIP kernels in
+    tests/test_gpu_kat_frame.py."""
+    from tests import kat_seam as K, oracle_bind
+    kat = K.deblock_frames()
+    for i in range(len(kat["dbf_par"])):
+        pic, ref, want = K.deblock_frame_case(kat, i)
+        store = oracle_bind.FrameStore(pic.mb_w, pic.mb_h, 3)
+        for s in (1, 2):
+            for dst, src in zip(store[s], ref):
+                dst[:] = src
+        for name, a, b in zip("yuv", oracle_bind.reconstruct(oracle, store, pic), want):
+            assert np.array_equal(a, b), "case %d plane %s" % (i, name)
+
+
+def test_seam_pictures_of_the_intra_and_dc_vectors(oracle):
+    """The pictures tests/test_gpu_kat_intra.py feeds the HIP kernels (tests/kat_seam.py), through the oracle: the builders put
+    every case where the kernels will look for it."""
+    from tests import kat_seam as K, oracle_bind
+    kat = K.hotpath()
+
+    def run(pic, ref):
+        store = oracle_bind.FrameStore(pic.mb_w, pic.mb_h, 2)
+        for dst, src in zip(store[1], ref):
+            dst[:] = src
+        return oracle_bind.reconstruct(oracle, store, pic)
+    for i in range(len(kat["p16_mode"])):
+        y, u, v = run(*K.pred16_case(kat["p16_in"][i], kat["p16_mode"][i], i))
+        assert np.array_equal(y[16:32, 16:32], kat["p16_out"][i][1:17, 1:17]), i
+    for i in range(0, len(kat["p8_mode"]), 2):
+        y, u, v = run(*K.pred8_case(kat["p8_in"][i], kat["p8_in"][i + 1], kat["p8_mode"][i], i))
+        assert np.array_equal(u[8:16, 8:16], kat["p8_out"][i][1:9, 1:9]) and np.array_equal(v[8:16, 8:16], kat["p8_out"][i + 1][1:9, 1:9]), i
+    for i in range(len(kat["p4_mode"])):
+        y, u, v = run(*K.pred4_case(kat["p4_in"][i], kat["p4_mode"][i], i))
+        assert np.array_equal(y[16:20, 16:20], kat["p4_out"][i][1:5, 1:5]), i
+    cases = list(range(0, 400, 7))
+    y, u, v = run(*K.luma_dc_picture(cases, kat["ldc_in"], kat["ldc_qp"], 128))
+    for k, i in enumerate(cases):
+        assert np.array_equal(y[16:32, k * 16:k * 16 + 16], np.kron(K.dc_only(128, kat["ldc_out"][i]).reshape(4, 4), np.ones((4, 4), np.uint8))), i
+    cases = [i for i in range(0, 400, 5) if int(kat["cdc_qp"][i]) in K.LUMA_QP_FOR_CHROMA]
+    for intra in (False, True):
+        y, u, v = run(*K.chroma_dc_picture(cases, kat["cdc_in"], kat["cdc_qp"], 128, intra))
+        for k, i in enumerate(cases):
+            want = np.kron(K.dc_only(128, kat["cdc_out"][i]).reshape(2, 2), np.ones((4, 4), np.uint8))
+            assert np.array_equal(u[8:16, k * 8:k * 8 + 8], want) and np.array_equal(v[8:16, k * 8:k * 8 + 8], want), (i, intra)

@@ -132,6 +132,10 @@ int  p264hip_upload(p264hip_ctx *ctx, int first, const p264hip_picture_t *pics, 
  * a marker taken after this call has been reached (p264hip_marker / p264hip_marker_wait) or p264hip_sync returns;
  * they should live in pinned memory (p264hip_host_alloc) for the copies to be real DMA transfers. */
 int  p264hip_upload_async(p264hip_ctx *ctx, int slot, const p264hip_picture_t *pic);
+/* Both notice arrays that already lie in host memory the way an input slot is laid out (p264hip_input_layout_t below: the
+ * parser of this library builds its pictures like that) and then copy records, vectors, indices, modes and levels in ONE
+ * transfer instead of five.  Host -> HBM copies queued so far by the two calls (diagnostic; -1 without a context): */
+int64_t p264hip_upload_copies(p264hip_ctx *ctx);
 /* Pinned host memory for picture inputs and frame downloads; usable without a context.  Ordinary (huge) pages registered with
  * the runtime - the CPU writes and re-reads them at full speed, which it does not on hipHostMalloc'ed memory;
  * P264AMD_HOST_ALLOC = 0 gives hipHostMalloc back. */

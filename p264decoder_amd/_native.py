@@ -121,6 +121,8 @@ def load(path=None):
         lib.p264hip_last_launch.argtypes = [C.c_void_p, C.POINTER(LaunchInfo)]
         lib.p264hip_build_info.restype = C.c_int
         lib.p264hip_build_info.argtypes = []
+        lib.p264hip_upload_copies.restype = C.c_int64
+        lib.p264hip_upload_copies.argtypes = [C.c_void_p]
         lib.p264hip_upload_async.restype = C.c_int
         lib.p264hip_upload_async.argtypes = [C.c_void_p, C.c_int, C.POINTER(Picture)]
         lib.p264hip_host_alloc.restype = C.c_void_p

@@ -103,6 +103,7 @@ struct p264hip_ctx {
     int batch_cap = 0, ring = 0;
     int *d_status = nullptr;
     int *d_slot_bad = nullptr;             // [max_pictures]: k_check_records' verdict per input slot
+    uint64_t upload_copies = 0;            // host -> HBM copies queued by p264hip_upload / _upload_async (one per picture whose arrays lie like a slot)
     uint64_t epoch = 0, done_epoch = 0;    // work queued on the stream / known to have completed (a slot is free for a new producer once its last_use is done)
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
     uint32_t *d_mc = nullptr;              // [batch_cap][ml.words], motion-compensation work lists (k_mc_sort -> k_mc, k_mc_second)
@@ -286,12 +287,22 @@ static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
         HIPCHK(hipMemcpyAsync(s.dev + L.off_ref_l1, p->ref_idx_l1, n * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(s.dev + L.off_weights, p->bipred_weight, sizeof p->bipred_weight, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(s.dev + L.off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(s.dev + L.off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(s.dev + L.off_i4, p->i4modes, n * 16, hipMemcpyHostToDevice, c->stream));
-    if (p->n_coef_blocks)
-        HIPCHK(hipMemcpyAsync(s.dev + L.off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
+    // The caller's arrays already lie in host memory the way the slot is laid out (the parser builds its pictures like that since
+    // round 6, csrc/host/parser.c: picbuf_t): ONE copy for records, vectors, indices, modes and levels instead of five - the
+    // pipeline's uploads ran at 12 GB/s in pieces, a packed block goes at 35 (bench.py: extras.upload_inclusive).
+    const uint8_t *hb = (const uint8_t *)p->mb;
+    const bool as_slot = (const uint8_t *)p->mv == hb + L.off_mv && (const uint8_t *)p->ref_idx == hb + L.off_ref && (const uint8_t *)p->i4modes == hb + L.off_i4
+                         && (p->n_coef_blocks == 0 || (const uint8_t *)p->coefs == hb + L.off_coef);
+    if (as_slot) HIPCHK(hipMemcpyAsync(s.dev, hb, L.off_coef + (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
+    else {
+        HIPCHK(hipMemcpyAsync(s.dev, p->mb, n * sizeof(p264hip_mb_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.dev + L.off_mv, p->mv, n * 64, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.dev + L.off_ref, p->ref_idx, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.dev + L.off_i4, p->i4modes, n * 16, hipMemcpyHostToDevice, c->stream));
+        if (p->n_coef_blocks)
+            HIPCHK(hipMemcpyAsync(s.dev + L.off_coef, p->coefs, (size_t)p->n_coef_blocks * 32, hipMemcpyHostToDevice, c->stream));
+    }
+    c->upload_copies += as_slot ? 1 : 5;
     slot_meta(s, p);
     s.valid = true; s.unchecked = false; s.last_use = ++c->epoch;
     return 0;
@@ -689,6 +700,8 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
     HIPCHK(hipGetLastError());
     return P264HIP_OK;
 }
+
+extern "C" int64_t p264hip_upload_copies(p264hip_ctx *c) { return c ? (int64_t)c->upload_copies : -1; }
 
 extern "C" int p264hip_last_launch(p264hip_ctx *c, p264hip_launch_info_t *out)
 {

@@ -62,6 +62,11 @@ typedef struct {
     p264hip_mb_t *mb; int16_t *mv; int8_t *ref; uint8_t *i4; int16_t *coef;
     int16_t *mv1; int8_t *ref1;               /* list 1 (B pictures; allocated with the others for non-Baseline streams) */
     size_t coef_cap, coef_n;
+    /* mb, mv, ref, i4 and coef are sections of ONE allocation laid out like an input slot of the HIP layer (p264hip_input_layout:
+     * records | vectors | reference indices | intra 4x4 modes | coded levels, each on a 256-byte boundary), so that a picture goes
+     * host -> HBM as one copy (p264hip_upload / _upload_async notice it); coef_own: the coded levels outgrew their section and
+     * moved to an allocation of their own (the picture then travels in pieces, as every picture did until round 5) */
+    uint8_t *block; int coef_own;
     void *(*alloc)(size_t); void (*release)(void *);   /* where the arrays live (p264parse_set_allocator) */
 } picbuf_t;
 
@@ -209,7 +214,7 @@ static int parse_pps(p264parse *p, bitrd_t *b)
 /* ---------------------------------------------------------------- context --------------- */
 static void release_bufs(picbuf_t *q)
 {
-    if (q->release) { q->release(q->mb); q->release(q->mv); q->release(q->ref); q->release(q->i4); q->release(q->coef); if (q->mv1) q->release(q->mv1); if (q->ref1) q->release(q->ref1); }
+    if (q->release) { q->release(q->block); if (q->coef_own) q->release(q->coef); if (q->mv1) q->release(q->mv1); if (q->ref1) q->release(q->ref1); }
     memset(q, 0, sizeof *q);
 }
 /* A caller may still be reading the last completed picture's arrays when the next slice re-initialises the context (the
@@ -241,13 +246,18 @@ static int init_context(p264parse *p, int sps_id, int pps_id)
     for (int i = 0; i < 2; i++) {
         picbuf_t *q = &p->buf[i];
         q->alloc = p->alloc ? p->alloc : malloc; q->release = p->release ? p->release : free;
-        q->mb  = (p264hip_mb_t *)q->alloc(n * sizeof(p264hip_mb_t));
-        q->mv  = (int16_t *)q->alloc(n * 32 * sizeof(int16_t));
-        q->ref = (int8_t *)q->alloc(n * 4);
-        q->i4  = (uint8_t *)q->alloc(n * 16);
-        q->coef_cap = n * 4 + 64;
-        q->coef = (int16_t *)q->alloc(q->coef_cap * 16 * sizeof(int16_t));
-        if (!q->mb || !q->mv || !q->ref || !q->i4 || !q->coef) return -1;
+        q->coef_cap = n * 8 + 64;                   /* (at most 26 per macroblock; beyond the section: coef_reserve) */
+        p264hip_picture_t shape; p264hip_input_layout_t lay;
+        memset(&shape, 0, sizeof shape);
+        shape.mb_w = s->mb_w; shape.mb_h = s->mb_h; shape.slice_type = P264_SLICE_P; shape.n_coef_blocks = (uint32_t)q->coef_cap;
+        if (p264hip_input_layout(&shape, &lay)) return -1;
+        q->block = (uint8_t *)q->alloc(lay.bytes);
+        if (!q->block) return -1;
+        q->mb  = (p264hip_mb_t *)(q->block + lay.off_mb);
+        q->mv  = (int16_t *)(q->block + lay.off_mv);
+        q->ref = (int8_t *)(q->block + lay.off_ref);
+        q->i4  = (uint8_t *)(q->block + lay.off_i4);
+        q->coef = (int16_t *)(q->block + lay.off_coef); q->coef_own = 0;
         memset(q->mb, 0, n * sizeof(p264hip_mb_t)); memset(q->mv, 0, n * 32 * sizeof(int16_t));
         memset(q->ref, 0, n * 4); memset(q->i4, 0, n * 16);
         if (s->profile_idc != 66) {                 /* anything but Baseline may carry B slices: list-1 arrays */
@@ -713,8 +723,8 @@ static int coef_reserve(picbuf_t *q, size_t more)
     int16_t *n = (int16_t *)q->alloc(cap * 16 * sizeof(int16_t));
     if (!n) return -1;
     memcpy(n, q->coef, q->coef_n * 16 * sizeof(int16_t));
-    q->release(q->coef);
-    q->coef = n; q->coef_cap = cap;
+    if (q->coef_own) q->release(q->coef);               /* (else: a section of q->block, which stays) */
+    q->coef = n; q->coef_cap = cap; q->coef_own = 1;
     return 0;
 }
 

@@ -3,6 +3,7 @@ batched reconstruction per round.  Streams of different content and length run s
 every stream must be the real reference decoder's (committed SHA-256)."""
 import os
 
+import numpy as np
 import pytest
 
 from p264decoder_amd import Pipeline
@@ -79,3 +80,38 @@ print("ok")
     env = dict(os.environ, P264AMD_HOST_ALLOC=mode)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:]
+
+
+def test_parsed_pictures_go_up_in_one_copy(lib):
+    """The parser lays a picture's arrays out like an input slot (tests/test_input_layout.py): p264hip_upload queues ONE host ->
+    HBM copy per P / I picture; arrays that lie anywhere else (a caller's own: here numpy copies) still take five."""
+    from p264decoder_amd import HipReconstructor, Parser, _native as N
+    import ctypes as C
+    h = lib.p264parse_open(1)
+    data = synth_cases.stream_bytes("cif_ip")
+    hip = None
+    want = 0
+    for typ, idc, rbsp in N.split_annexb(lib, data):
+        pic = C.POINTER(N.Picture)()
+        buf = (C.c_uint8 * max(len(rbsp), 1)).from_buffer_copy(rbsp if len(rbsp) else b"\0")
+        if lib.p264parse_nal(h, typ, idc, buf, len(rbsp), C.byref(pic)) != 1:
+            continue
+        d = pic.contents
+        if hip is None:
+            hip = HipReconstructor(d.mb_w, d.mb_h, n_streams=2, slots=lib.p264parse_slots(h), max_pictures=2, lib=lib)
+        assert lib.p264hip_upload(hip.h, 0, pic, 1) == 0
+        want += 1
+        assert lib.p264hip_upload_copies(hip.h) == want
+        hip.reconstruct([0], [0])
+    lib.p264parse_close(h)
+    # the same stream through owned copies of the arrays (recon.ParsedPicture): five copies each, the same pictures
+    pics = Parser(quiet=True, lib=lib).parse_stream(data)
+    for p in pics:
+        hip.upload(1, [p])
+        want += 5
+        assert lib.p264hip_upload_copies(hip.h) == want
+        hip.reconstruct([1], [1])
+    hip.sync()
+    for a, b in zip(hip.read_frame(0, pics[-1].desc.dst_slot), hip.read_frame(1, pics[-1].desc.dst_slot)):
+        assert np.array_equal(a, b)
+    hip.close()

@@ -84,3 +84,34 @@ def test_every_host_entry_refuses_a_cpu_older_than_the_build(lib):
     finally:
         flag.value = 0
     assert lib.p264hip_pack_input(C.byref(pics[0].desc), buf, len(buf)) > 0
+
+
+@pytest.mark.parametrize("case", ["cif_ip", "tiny_1x1", "wide_70", "dense"])
+def test_the_parser_builds_its_pictures_in_the_layout_of_an_input_slot(lib, case):
+    """records | vectors | reference indices | intra 4x4 modes | coded levels as sections of ONE host block at the offsets of
+    p264hip_input_layout: p264hip_upload / _upload_async then need one host -> HBM copy per picture, not five."""
+    import ctypes as C
+    from p264decoder_amd import _native as N
+    h = lib.p264parse_open(1)
+    assert h
+    n_pics = in_one = 0
+    for typ, idc, rbsp in N.split_annexb(lib, synth_cases.stream_bytes(case)):
+        pic = C.POINTER(N.Picture)()
+        buf = (C.c_uint8 * max(len(rbsp), 1)).from_buffer_copy(rbsp if len(rbsp) else b"\0")
+        rc = lib.p264parse_nal(h, typ, idc, buf, len(rbsp), C.byref(pic))
+        assert rc >= 0
+        if rc != 1:
+            continue
+        d = pic.contents
+        lay = N.InputLayout()
+        assert lib.p264hip_input_layout(C.byref(d), C.byref(lay)) == 0
+        base = C.cast(d.mb, C.c_void_p).value
+        assert C.cast(d.mv, C.c_void_p).value == base + lay.off_mv
+        assert C.cast(d.ref_idx, C.c_void_p).value == base + lay.off_ref
+        assert C.cast(d.i4modes, C.c_void_p).value == base + lay.off_i4
+        # (the section holds 8 blocks per macroblock; a picture with more - up to 26 are possible - moves its levels out)
+        assert d.n_coef_blocks == 0 or C.cast(d.coefs, C.c_void_p).value == base + lay.off_coef or d.n_coef_blocks > 8 * d.mb_w * d.mb_h + 64
+        in_one += d.n_coef_blocks <= 8 * d.mb_w * d.mb_h + 64
+        n_pics += 1
+    lib.p264parse_close(h)
+    assert n_pics >= 6 and in_one >= n_pics - 2

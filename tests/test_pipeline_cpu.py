@@ -34,7 +34,8 @@ def test_gpu_pipeline_needs_a_device(lib):
 
 
 def test_parser_allocator_hook(lib, f26):
-    """p264parse_set_allocator: every picture array comes from the caller's allocator, output unchanged."""
+    """p264parse_set_allocator: every picture array comes from the caller's allocator - since round 6 as sections of one block
+    per picture buffer, laid out like an input slot of the HIP layer -, output unchanged."""
     live, total = {}, [0]
     ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t)
     FREE = C.CFUNCTYPE(None, C.c_void_p)
@@ -64,13 +65,14 @@ def test_parser_allocator_hook(lib, f26):
         assert rc >= 0
         if rc == 1:
             n_mb = pic.contents.mb_w * pic.contents.mb_h
-            assert C.addressof(pic.contents.mb.contents) in live and C.addressof(pic.contents.mv.contents) in live
+            base = C.addressof(pic.contents.mb.contents)
+            assert base in live and base < C.addressof(pic.contents.mv.contents) < base + live[base]
             mine = C.string_at(pic.contents.mv, n_mb * 64)
             assert mine == C.string_at(ref[got].desc.mv, n_mb * 64)
             got += 1
             if got == 5:
                 break
-    assert total[0] >= 10                                               # 2 buffers x 5 arrays
+    assert total[0] >= 2                                                # 2 picture buffers, one block each
     lib.p264parse_close(h)
     assert not live                                                     # everything given back
 

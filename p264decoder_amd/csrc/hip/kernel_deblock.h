@@ -80,8 +80,11 @@ enum { EC_LEFT = 0, EC_TOP = 1, EC_INNER = 2 };     // edge classes
 //            top, chroma inner (core/frame.c:593-601)
 // alpha / beta / tc0 come out of tables in the consumer (edge_expand below).
 struct EdgeInfo { uint32_t bs[2], qp, avg; };
-#define EDGE_DW 16                 // per macroblock in LDS: the four words above, then per class [class + 3 * chroma] two words
-                                   // {alpha | beta << 8, tc0 of code 1..3 in bytes 1..3 (chroma: already + 1)}
+#define EDGE_DW 56                 // per macroblock in LDS: the four words above, then per class [class + 3 * chroma] eight words:
+                                   // alpha, beta, -alpha, -beta as 16-bit pairs (the same value in both halves: what the packed filter
+                                   // arithmetic takes - round 6: expanded once per QP change instead of two v_perm and two negations
+                                   // per edge pass), tc0 of code 1..3 in bytes 1..3 (chroma: already + 1), three words of padding
+                                   // (the octets' copies 252 words apart: their banks differ)
 
 // ------------------------------------------------------------------------------------------
 // K4a
@@ -278,7 +281,8 @@ __device__ __forceinline__ void edge_tables_init(EdgeTables &T)
 }
 // Class k = class + 3 * chroma of a macroblock: alpha, beta, tc0 (deblock_edge, core/frame.c:472-488; offsets unshifted:
 // A-Q3).  k may vary per lane.  On the macroblock-edge classes code 3 means strength 4, which has no tc0: byte 3 = 0.
-__device__ __forceinline__ uint2 edge_expand(const EdgeTables &T, uint32_t qp, uint32_t avg, int k, int alpha_off, int beta_off)
+struct EdgeClass { uint4 ab; uint32_t tc; };         // {alpha, beta, -alpha, -beta} as pairs; tc0 bytes
+__device__ __forceinline__ EdgeClass edge_expand(const EdgeTables &T, uint32_t qp, uint32_t avg, int k, int alpha_off, int beta_off)
 {
     const int sh = k < 2 ? 6 * k : 6 * (k - 1);                        // k: 0 1 [2] 3 4 5 -> field 0 1 [qp] 2 3 4 of avg
     const int q = k == 2 ? (int)(qp & 63u) : (int)((avg >> sh) & 63u);
@@ -286,24 +290,30 @@ __device__ __forceinline__ uint2 edge_expand(const EdgeTables &T, uint32_t qp, u
     const uint32_t be = T.beta[clip3i(q + beta_off, 0, 51)];
     uint32_t v = at + (k >= 3 ? 0x01010100u : 0u);                     // chroma: tc0 + 1 (no carries: tc0 <= 25)
     if (k != 2 && k != 5) v &= 0x00ffffffu;
-    return make_uint2((v & 0xffu) | (be << 8), v & 0xffffff00u);
+    const uint32_t a2 = (v & 0xffu) * 0x00010001u, b2 = be * 0x00010001u;
+    EdgeClass c;
+    c.ab = make_uint4(a2, b2, 0u - a2 + ((a2 & 0xffffu) ? 0x00010000u : 0u), 0u - b2 + ((b2 & 0xffffu) ? 0x00010000u : 0u));   // (per-half negation: the low half's borrow given back)
+    c.tc = v & 0xffffff00u;
+    return c;
 }
 
 // A macroblock's EdgeInfo as its eight lanes see it: the two boundary-strength words in registers, the class
 // parameters fetched from the octet's LDS copy where an edge needs them.
 struct EdgeRegs {
     uint32_t e[2];
-    const uint32_t *lds;            // the octet's copy: 4 raw words, then 6 classes x 2 words
+    const uint32_t *lds;            // the octet's copy: 4 raw words, then 6 classes x 8 words
     // code of (edge ed, the lane's segment): seg2 = 2 * segment
     __device__ __forceinline__ int code(int dir, int ed, int seg2) const { return (int)__builtin_amdgcn_ubfe(e[dir], (unsigned)(8 * ed + seg2), 2u); }
 };
-// class k occupies dwords 4+2k (alpha, beta) and 5+2k (0, tc0 of code 1..3); k is a compile-time constant.  Everything comes out
-// as a 16-bit pair with the same value in both halves, one v_perm each: the filter arithmetic is packed.
+// class k occupies dwords 4+8k .. 8+8k: alpha, beta, -alpha, -beta as 16-bit pairs with the same value in both halves (the filter
+// arithmetic is packed), then (0, tc0 of code 1..3); k is a compile-time constant.
 struct EdgeParams {
-    uint32_t lo, hi;
-    __device__ __forceinline__ EdgeParams(const EdgeRegs &E, int k) { uint2 v = *(const uint2 *)(E.lds + 4 + 2 * k); lo = v.x; hi = v.y; }
-    __device__ __forceinline__ uint32_t alpha2() const { return perm(lo, lo, 0x0c000c00u); }
-    __device__ __forceinline__ uint32_t beta2() const { return perm(lo, lo, 0x0c010c01u); }
+    uint4 ab; uint32_t hi;
+    __device__ __forceinline__ EdgeParams(const EdgeRegs &E, int k) { ab = *(const uint4 *)(E.lds + 4 + 8 * k); hi = E.lds[8 + 8 * k]; }
+    __device__ __forceinline__ uint32_t alpha2() const { return ab.x; }
+    __device__ __forceinline__ uint32_t beta2() const { return ab.y; }
+    __device__ __forceinline__ uint32_t nalpha2() const { return ab.z; }
+    __device__ __forceinline__ uint32_t nbeta2() const { return ab.w; }
     // tc0 of code c (per lane; 0 for code 0 and for strength 4, which does not use it): byte c of {0, hi}
     __device__ __forceinline__ uint32_t tc2(int c) const { return perm(0u, hi, 0x0c000c00u + (uint32_t)c * 0x00010001u); }
 };
@@ -437,7 +447,7 @@ template <int K> __device__ __forceinline__ pk16 pair_byte(uint32_t a, uint32_t 
 #define RING_SLOTS   4
 #define RING_DW      24            // per slot: 4 luma rows x 4 dwords, then 2 planes x 2 rows x 2 dwords
 #define TILE_DW      100           // 16 luma rows x 4 dwords, 2 planes x 8 rows x 2 dwords, +4 so that octets land on different banks
-struct OctLds {                    // per octet: 212 dwords
+struct OctLds {                    // per octet: 252 dwords (= 28 modulo 32: the eight octets of a wavefront start on eight different banks)
     uint32_t tile[TILE_DW];
     uint32_t ring[RING_SLOTS][RING_DW];
     uint32_t edge[EDGE_DW];
@@ -614,7 +624,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                 const bool changed = act && (v.z != last_qp || v.w != last_avg);
                 if (__ballot(changed)) {
                     if (act) {
-                        if (j < 6) *(uint2 *)(L.edge + 4 + 2 * j) = edge_expand(tables, v.z, v.w, j, alpha_off, beta_off);
+                        if (j < 6) { const EdgeClass ec = edge_expand(tables, v.z, v.w, j, alpha_off, beta_off); *(uint4 *)(L.edge + 4 + 8 * j) = ec.ab; L.edge[8 + 8 * j] = ec.tc; }
                         last_qp = v.z; last_avg = v.w;
                     }
                     wave_lds_fence();
@@ -631,7 +641,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     pk16 p2 = pair_byte<1>(ya[ed], yb[ed]), p1 = pair_byte<2>(ya[ed], yb[ed]), p0 = pair_byte<3>(ya[ed], yb[ed]);
                     pk16 q0 = pair_byte<0>(ya[ed+1], yb[ed+1]), q1 = pair_byte<1>(ya[ed+1], yb[ed+1]), q2 = pair_byte<2>(ya[ed+1], yb[ed+1]);
                     const EdgeParams ep(E, k);
-                    const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2()), nA = -A, nB = -B;
+                    const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2()), nA = as_pk(ep.nalpha2()), nB = as_pk(ep.nbeta2());
                     pk16 e;
                     const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, nA, B, nB, e);
                     const pk16 ap = pk_sign(pk_within(p2 - p0, B, nB)), aq = pk_sign(pk_within(q2 - q0, B, nB));
@@ -662,7 +672,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                     const EdgeParams ep(E, k);
                     const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
                     pk16 e;
-                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, -A, B, -B, e);
+                    const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, as_pk(ep.nalpha2()), B, as_pk(ep.nbeta2()), e);
                     pk_chroma(p1, p0, q0, q1, e, f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
                     const uint32_t P0 = pk_clip_bytes(p0), Q0 = pk_clip_bytes(q0);      // (row a in byte 0, row b in byte 1)
                     ca[c] = perm(P0, ca[c], 0x04020100u);     cb[c] = perm(P0, cb[c], 0x05020100u);
@@ -710,7 +720,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         if (__ballot(b != 0) == 0) continue;
                         pk16 &p3 = c[4*ed], &p2 = c[4*ed+1], &p1 = c[4*ed+2], &p0 = c[4*ed+3], &q0 = c[4*ed+4], &q1 = c[4*ed+5], &q2 = c[4*ed+6], &q3 = c[4*ed+7];
                         const EdgeParams ep(E, k);
-                        const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2()), nA = -A, nB = -B;
+                        const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2()), nA = as_pk(ep.nalpha2()), nB = as_pk(ep.nbeta2());
                         pk16 e;
                         const pk16 f = pk_edge_flag(p1, p0, q0, q1, A, nA, B, nB, e);
                         const pk16 ap = pk_sign(pk_within(p2 - p0, B, nB)), aq = pk_sign(pk_within(q2 - q0, B, nB));
@@ -749,7 +759,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
                         const EdgeParams ep(E, k);
                         const pk16 A = as_pk(ep.alpha2()), B = as_pk(ep.beta2());
                         pk16 e;
-                        const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], A, -A, B, -B, e);
+                        const pk16 f = pk_edge_flag(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], A, as_pk(ep.nalpha2()), B, as_pk(ep.nbeta2()), e);
                         pk_chroma(d[2*ed], d[2*ed+1], d[2*ed+2], d[2*ed+3], e, f, as_pk(mask_bs123(b, ed)), as_pk(ed == 0 ? mask_bs4(b) : 0u), ed == 0 && __ballot(b == 3) != 0, as_pk(ep.tc2(b)));
                     }
                     // (all four are p0 / q0 rows: clipped here)

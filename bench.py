@@ -224,12 +224,14 @@ def small_batch_leg(lib, S=256, K=20, Wm=3):
                     "fractions of the 8 TB/s roofline at the same algorithmic bytes per macroblock as the headline (MC: 836 B per inter macroblock)"}
 
 
-def upload_inclusive_leg(lib, S=512, K=10, Wm=2):
+def upload_inclusive_leg(lib, S=512, K=10, Wm=2, compact=True):
     """The metric's workload with the host->HBM copies of the parsed inputs inside the timed region (the seam hands over host
-    buffers: p264hip_upload_packed from pinned memory, one copy per picture): every step uploads the S pictures it then
-    reconstructs.  No parse.  Reported under extras.upload_inclusive - never `value`."""
+    buffers): every step uploads the S pictures it then reconstructs, one copy per picture out of pinned memory.  compact: the
+    pictures travel in the compact link format (include/p264hip.h: one vector per partition, Intra4x4 modes where there are
+    any, 8-bit levels where they fit) and are expanded on the device by ONE kernel per step (k_expand_compact, inside the timed
+    region); else in the layout of an input slot (p264hip_upload_packed: what rounds 4 - 5 reported).  No parse, no packing
+    (the blocks are made before the clock starts).  Reported under extras.upload_inclusive - never `value`."""
     import ctypes as C
-    import numpy as np
     from p264decoder_amd import HipReconstructor, Parser
     from tests import synth_cases
     from tests.conftest import frame_sha256
@@ -239,12 +241,12 @@ def upload_inclusive_leg(lib, S=512, K=10, Wm=2):
     for g in range(DISTINCT):
         path = synth_cases.generate("cfg3_1080p_allp") if g == 0 else synth_cases.generate(synth_args(T, 1000 + g))
         parsed.append(Parser(quiet=True, lib=lib).parse_stream(open(path, "rb").read(), limit=T))
-    # the packed inputs in pinned memory (one block per distinct picture; every stream's copy of it is its own transfer)
+    # the blocks in pinned memory (one per distinct picture; every stream's copy of it is its own transfer)
     pinned, total = [], 0
     for g in range(DISTINCT):
         row = []
         for t in range(T):
-            pk = HipReconstructor.pack(parsed[g][t], lib=lib)
+            pk = HipReconstructor.pack_compact(parsed[g][t], lib=lib) if compact else HipReconstructor.pack(parsed[g][t], lib=lib)
             ptr = lib.p264hip_host_alloc(pk.size)
             if not ptr:
                 raise RuntimeError("p264hip_host_alloc failed")
@@ -253,13 +255,14 @@ def upload_inclusive_leg(lib, S=512, K=10, Wm=2):
         pinned.append(row)
     hip = HipReconstructor(MB_W, MB_H, n_streams=S, slots=2, max_pictures=S * 2, lib=lib)
     streams = list(range(S))
+    up = lib.p264hip_upload_compact if compact else lib.p264hip_upload_packed
 
     def step(t):
         nonlocal total
         base = (t & 1) * S                                   # two sets of input slots: the copies of step t + 1 never touch step t's
         for s in streams:
             ptr, n = pinned[s % DISTINCT][t]
-            hip._chk(lib.p264hip_upload_packed(hip.h, base + s, C.byref(parsed[s % DISTINCT][t].desc), ptr, n), "p264hip_upload_packed")
+            hip._chk(up(hip.h, base + s, C.byref(parsed[s % DISTINCT][t].desc), ptr, n), "p264hip_upload_compact" if compact else "p264hip_upload_packed")
             total += n
         hip.reconstruct([base + s for s in streams], streams)
     for t in range(1 + Wm):
@@ -277,9 +280,10 @@ def upload_inclusive_leg(lib, S=512, K=10, Wm=2):
         for ptr, _ in row:
             lib.p264hip_host_free(ptr)
     return {"value": round(S * K / elapsed, 1), "unit": "frames/s", "streams": S, "steps": K, "input_bytes_per_picture": int(total / (S * K)),
+            "format": "compact link format, expanded on the device (k_expand_compact) inside the timed region" if compact else "slot layout (p264hip_upload_packed)",
             "upload_GBps": round(total / elapsed / 1e9, 2), "last_picture_matches_reference": ok,
-            "what": "the metric's all-P workload with every picture's parsed input (records, vectors, reference indices, coded levels: one packed "
-                    "block in pinned host memory) copied host -> HBM inside the timed region, %d pictures per launch; no parse" % S}
+            "what": "the metric's all-P workload with every picture's parsed input (one block in pinned host memory) copied host -> HBM inside the timed "
+                    "region, %d pictures per launch; no parse" % S}
 
 
 def extras(lib, baseline_stream=None):
@@ -295,6 +299,7 @@ def extras(lib, baseline_stream=None):
         out["batch_256"] = {"error": str(e)}
     try:
         out["upload_inclusive"] = upload_inclusive_leg(lib)
+        out["upload_inclusive"]["slot_layout"] = {k: v for k, v in upload_inclusive_leg(lib, compact=False).items() if k in ("value", "input_bytes_per_picture", "upload_GBps", "format")}
     except Exception as e:
         out["upload_inclusive"] = {"error": str(e)}
     # config 2: 1280x720 Baseline CAVLC, I slices only (intra + IDCT path), 10 pictures x 1024 streams (as many streams as
@@ -682,6 +687,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (HBM traffic, vector instructions) behind the timed region")
     ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0)")
+    ap.add_argument("--only-upload-inclusive", action="store_true", help="print extras.upload_inclusive (both formats) and nothing else")
     ap.add_argument("--only-batch-256", action="store_true", help="print extras.batch_256 (the metric's workload at 256 pictures per launch) and nothing else")
     args = ap.parse_args()
 
@@ -708,6 +714,10 @@ def main():
     from tests import synth_cases
     lib = _native.load()
 
+    if args.only_upload_inclusive:
+        if rank == 0:
+            print(json.dumps({"extras": {"upload_inclusive": {"compact": upload_inclusive_leg(lib), "slot_layout": upload_inclusive_leg(lib, compact=False)}}}), flush=True)
+        return
     if args.only_batch_256:                               # (profiles/collect.sh: the kernel trace and the counters of this leg alone)
         if rank == 0:
             print(json.dumps({"extras": {"batch_256": small_batch_leg(lib, K=args.steps, Wm=args.warmup)}}), flush=True)

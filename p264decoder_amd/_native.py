@@ -130,6 +130,16 @@ def load(path=None):
         lib.p264hip_host_free.argtypes = [C.c_void_p]
         lib.p264hip_marker.restype = C.c_int
         lib.p264hip_input_layout.argtypes = [C.POINTER(Picture), C.POINTER(InputLayout)]
+        lib.p264hip_compact_bound.restype = C.c_size_t
+        lib.p264hip_compact_bound.argtypes = [C.POINTER(Picture)]
+        lib.p264hip_pack_compact.restype = C.c_int64
+        lib.p264hip_pack_compact.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t]
+        lib.p264hip_expand_compact.restype = C.c_int
+        lib.p264hip_expand_compact.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        lib.p264hip_compact_check.restype = C.c_int
+        lib.p264hip_compact_check.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t]
+        lib.p264hip_upload_compact.restype = C.c_int
+        lib.p264hip_upload_compact.argtypes = [C.c_void_p, C.c_int, C.POINTER(Picture), C.c_void_p, C.c_size_t]
         lib.p264hip_pack_input.restype = C.c_int64
         lib.p264hip_pack_input.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t]
         lib.p264hip_unpack_input.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t, C.POINTER(Picture)]

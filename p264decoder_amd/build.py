@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libp264amd.so")
 TOOLS_DIR = os.path.join(HERE, "tools")
 
-HOST_SRCS = ["parser.c", "vlc.c", "cabac.c", "dropin.c", "pipeline.c", "fanout.c", "input_layout.c", "cpu_check.c"]
+HOST_SRCS = ["parser.c", "vlc.c", "cabac.c", "dropin.c", "pipeline.c", "fanout.c", "input_layout.c", "compact.c", "cpu_check.c"]
 HOST_BASELINE = {"cpu_check.c"}      # built WITHOUT HOST_ARCH: its constructor looks at the CPU before any x86-64-v3 code runs
 HIP_SRCS = ["p264hip.hip", "fan_rccl.hip"]
 HIP_ARCH = "gfx950"

@@ -44,7 +44,7 @@
 // Timing experiments (scratch/r4_mcexp.sh, r4_mcparts.sh): pieces of the kernels compiled out to time the rest.  Results are
 // wrong unless all defaults hold, so the switches only exist in a build that says what it is: -DP264AMD_TIMING_BUILD, in
 // which p264hip_create refuses to run without P264AMD_TIMING_BUILD_OK=1 and p264hip_build_info() reports the flag.
-#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPM_LUMA_COPY) || defined(EXPM_NO_STORE) || defined(EXPM_NO_WINDOW) || defined(EXPM_ONLY) || defined(EXPM_RESID) || defined(EXPM_FORCE_KEY))
+#if !defined(P264AMD_TIMING_BUILD) && (defined(EXPM_LUMA_COPY) || defined(EXPM_NO_STORE) || defined(EXPM_NO_WINDOW) || defined(EXPM_ONLY) || defined(EXPM_RESID) || defined(EXPM_FORCE_KEY) || defined(EXPM_HALF_LEVELS))
 #error "EXPM_* switches produce wrong pictures: they need -DP264AMD_TIMING_BUILD"
 #endif
 #ifndef EXPM_LUMA_COPY
@@ -62,6 +62,12 @@
 #ifndef EXPM_RESID
 #define EXPM_RESID 1
 #endif
+#ifndef EXPM_HALF_LEVELS
+#define EXPM_HALF_LEVELS 0         // 1: a coded block's levels are read as ONE 16-byte piece at half the stride (round 6: what 8-bit levels could save at most)
+#endif
+// a coded block's sixteen levels (two 16-byte pieces)
+#define MC_LOAD_LEVELS(cfp, la_, lb_) do { if (EXPM_HALF_LEVELS) { la_ = gload4((const int16_t *)((const uint8_t *)(cfp) - ((const uint8_t *)(cfp) - (const uint8_t *)pd->coefs) / 2)); lb_ = la_; } \
+                                            else { la_ = gload4(cfp); lb_ = gload4((cfp) + 8); } } while (0)
 // EXPM_FORCE_KEY=k: every chunk is taken for key k (scratch/mc_count.sh: static instruction counts per role and class)
 #ifdef EXPM_FORCE_KEY
 #define MC_CHUNK_KEY(v) ((void)(v), (int)(EXPM_FORCE_KEY))
@@ -1057,7 +1063,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
             if (!PB) resid_fields();
             if (coded) {
                 const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
-                la = gload4(cf); lb = gload4(cf + 8);
+                MC_LOAD_LEVELS(cf, la, lb);
             }
         }
         wave_lds_fence();
@@ -1070,7 +1076,7 @@ __device__ __forceinline__ void mc_luma_body(uint8_t *images, const uint32_t *re
             if (!PB) resid_fields();
             if (coded) {
                 const int16_t *cf = pd->coefs + ((size_t)cidx + coef_slot(mask, blk)) * 16;
-                la = gload4(cf); lb = gload4(cf + 8);
+                MC_LOAD_LEVELS(cf, la, lb);
             }
         }
         // one prediction per lane from reference frame `ro` with vector `mv` (lanes with use = false are left alone)
@@ -1344,7 +1350,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
         if (key & MCC_RESID) {
             if (!PB) resid_fields();
             const int16_t *cf = pd->coefs + (size_t)cidx * 16;
-            if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
+            if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; MC_LOAD_LEVELS(c, la, lb); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
         wave_lds_fence();
@@ -1363,7 +1369,7 @@ __device__ __forceinline__ void mc_chroma_body(uint8_t *images, const uint32_t *
         if (key & MCC_RESID) {
             if (!PB) resid_fields();
             const int16_t *cf = pd->coefs + (size_t)cidx * 16;
-            if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; la = gload4(c); lb = gload4(c + 8); }
+            if (has_res && ((mask >> cb) & 1)) { const int16_t *c = cf + coef_slot(mask, cb) * 16; MC_LOAD_LEVELS(c, la, lb); }
             if (has_res && (mask & P264_COEF_CHROMA_DC)) dcl = gload2(cf + ((mask >> 24) & 1) * 16 + p * 4);
         }
         const int b0 = (q >> 1) * 8 + (q & 1) * 2;

@@ -17,6 +17,7 @@
 #include "kernel_deblock.h"
 #include "kernel_mc.h"
 #include "kernel_intra.h"
+#include "kernel_expand.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, ...)
@@ -53,11 +54,14 @@ struct PicSlot {                       // one device-resident parsed picture
     size_t   bytes = 0;                // bytes in use
     p264hip_picture_t meta;            // scalar fields only; pointers unused
     bool     valid = false, reserved = false;   // reserved: p264hip_input_reserve handed the block out, commit is pending
+    uint8_t *stage = nullptr; size_t stage_cap = 0;   // p264hip_upload_compact: the compact block as it arrived; pending: its expansion into dev has not been launched yet
+    bool     pending = false;
     bool     unchecked = false;                  // committed by a device producer: the record check (k_check_records) has been queued, its verdict not yet read
     uint64_t last_use = 0;                       // epoch of the last work queued on the context's stream that reads or writes the block
 };
 
 #define BATCH_RING 4
+#define COPY_STREAMS 4
 
 // device frame layout (strips, device_common.h) <-> planar staging (host boundary only): one thread per dword of the frame
 __global__ void k_tile_convert(uint8_t *frame, uint8_t *planar, Geom g, int to_planar)
@@ -103,6 +107,14 @@ struct p264hip_ctx {
     int batch_cap = 0, ring = 0;
     int *d_status = nullptr;
     int *d_slot_bad = nullptr;             // [max_pictures]: k_check_records' verdict per input slot
+    std::vector<int> pending;              // input slots whose compact block waits for k_expand_compact (launched in front of the next reconstruct / clone / sync)
+    ExpandJob *h_jobs = nullptr, *d_jobs = nullptr; int jobs_cap = 0; hipEvent_t jobs_free = nullptr;
+    // compact blocks travel on COPY_STREAMS side streams, round robin: a copy of ~0.5 MB costs ~18 us of fixed latency beside ~9 us of
+    // transfer (measured, round 6: 512 copies per step on the context's one stream ran at 19.6 GB/s) - side by side the latencies overlap.
+    // The expansion kernel (context's stream) waits for the side streams' copies; a side stream waits for the last expansion before it
+    // overwrites a staging area.
+    hipStream_t cstream[COPY_STREAMS] = {}; hipEvent_t cdone[COPY_STREAMS] = {}; bool cdirty[COPY_STREAMS] = {}, cwaited[COPY_STREAMS] = {};
+    hipEvent_t expand_done = nullptr; int next_cs = 0;
     uint64_t upload_copies = 0;            // host -> HBM copies queued by p264hip_upload / _upload_async (one per picture whose arrays lie like a slot)
     uint64_t epoch = 0, done_epoch = 0;    // work queued on the stream / known to have completed (a slot is free for a new producer once its last_use is done)
     EdgeInfo *d_edge = nullptr;            // [batch_cap][n_mb], scratch between k_deblock_bs and k_deblock
@@ -198,7 +210,12 @@ extern "C" void p264hip_destroy(p264hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &p : c->pics) if (p.dev) (void)hipFree(p.dev);
+    for (auto &p : c->pics) { if (p.dev) (void)hipFree(p.dev); if (p.stage) (void)hipFree(p.stage); }
+    if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    if (c->jobs_free) (void)hipEventDestroy(c->jobs_free);
+    if (c->expand_done) (void)hipEventDestroy(c->expand_done);
+    for (int i = 0; i < COPY_STREAMS; i++) { if (c->cstream[i]) { (void)hipStreamSynchronize(c->cstream[i]); (void)hipStreamDestroy(c->cstream[i]); } if (c->cdone[i]) (void)hipEventDestroy(c->cdone[i]); }
     for (int i = 0; i < BATCH_RING; i++) {
         if (c->h_batch[i]) (void)hipHostFree(c->h_batch[i]);
         if (c->d_batch[i]) (void)hipFree(c->d_batch[i]);
@@ -273,10 +290,58 @@ static void slot_meta(PicSlot &s, const p264hip_picture_t *p)
     s.meta.mb = nullptr; s.meta.mv = nullptr; s.meta.ref_idx = nullptr; s.meta.i4modes = nullptr; s.meta.coefs = nullptr; s.meta.mv_l1 = nullptr; s.meta.ref_idx_l1 = nullptr;
 }
 
+// ---- compact link format (include/p264hip.h, kernel_expand.h) ----
+// a slot that gets new content by another road no longer waits for its compact block's expansion
+static void unpend(p264hip_ctx *c, int id)
+{
+    PicSlot &s = c->pics[(size_t)id];
+    if (!s.pending) return;
+    s.pending = false;
+    for (size_t i = 0; i < c->pending.size(); i++) if (c->pending[i] == id) { c->pending.erase(c->pending.begin() + (long)i); break; }
+}
+// ONE launch expands every compact block uploaded since the last one
+static int expand_pending(p264hip_ctx *c)
+{
+    const int n = (int)c->pending.size();
+    if (!n) return 0;
+    if (n > c->jobs_cap) {
+        if (c->jobs_free) HIPCHK(hipEventSynchronize(c->jobs_free));
+        if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+        if (c->d_jobs) (void)hipFree(c->d_jobs);
+        c->h_jobs = nullptr; c->d_jobs = nullptr;
+        const int cap = n + n / 2 + 16;
+        HIPCHK(hipHostMalloc((void **)&c->h_jobs, (size_t)cap * sizeof(ExpandJob), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&c->d_jobs, (size_t)cap * sizeof(ExpandJob)));
+        if (!c->jobs_free) HIPCHK(hipEventCreateWithFlags(&c->jobs_free, hipEventDisableTiming));
+        c->jobs_cap = cap;
+    } else HIPCHK(hipEventSynchronize(c->jobs_free));        // the copy that last read h_jobs is done
+    for (int i = 0; i < n; i++) {
+        PicSlot &s = c->pics[(size_t)c->pending[(size_t)i]];
+        c->h_jobs[i] = ExpandJob{ s.stage, s.dev, (uint32_t)s.off_mv, (uint32_t)s.off_ref, (uint32_t)s.off_i4, (uint32_t)s.off_coef };
+        s.pending = false;
+    }
+    c->pending.clear();
+    for (int i = 0; i < COPY_STREAMS; i++) {                 // the blocks' copies (side streams) in front of the kernel that reads them
+        if (!c->cdirty[i]) continue;
+        HIPCHK(hipEventRecord(c->cdone[i], c->cstream[i]));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->cdone[i], 0));
+        c->cdirty[i] = false;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_jobs, c->h_jobs, (size_t)n * sizeof(ExpandJob), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->jobs_free, c->stream));
+    hipLaunchKernelGGL(k_expand_compact, dim3((unsigned)n), dim3(EXPAND_THREADS), 0, c->stream, (const ExpandJob *)c->d_jobs);
+    HIPCHK(hipGetLastError());
+    if (!c->expand_done) HIPCHK(hipEventCreateWithFlags(&c->expand_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->expand_done, c->stream));        // the staging areas may be overwritten behind this
+    for (int i = 0; i < COPY_STREAMS; i++) c->cwaited[i] = false;
+    return 0;
+}
+
 static int upload_one(p264hip_ctx *c, int id, const p264hip_picture_t *p)
 {
     int rc = check_pic(c, p, true);
     if (rc) return rc;
+    unpend(c, id);
     PicSlot &s = c->pics[(size_t)id];
     const size_t n = (size_t)c->g.n_mb;
     p264hip_input_layout_t L;
@@ -317,11 +382,50 @@ extern "C" int p264hip_upload_packed(p264hip_ctx *c, int slot, const p264hip_pic
     if (rc) return rc;
     p264hip_input_layout_t L;
     if (p264hip_input_layout(desc, &L) || bytes != L.bytes) return fail(P264HIP_EINVAL, "p264hip_upload_packed: %zu bytes, the layout has %zu", bytes, L.bytes);
+    unpend(c, slot);
     PicSlot &s = c->pics[(size_t)slot];
     if ((rc = slot_prepare(c, s, L))) return rc;
     HIPCHK(hipMemcpyAsync(s.dev, packed, L.bytes, hipMemcpyHostToDevice, c->stream));
     slot_meta(s, desc);
     s.valid = true; s.unchecked = false; s.last_use = ++c->epoch;
+    return P264HIP_OK;
+}
+
+extern "C" int p264hip_upload_compact(p264hip_ctx *c, int slot, const p264hip_picture_t *desc, const void *compact, size_t bytes)
+{
+    if (!c || !desc || !compact || slot < 0 || slot >= c->max_pictures) return fail(P264HIP_EINVAL, "p264hip_upload_compact: bad argument (slot %d)", slot);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = check_pic(c, desc, false);
+    if (rc) return rc;
+    if (!p264hip_compact_header_ok(desc, compact, bytes)) return fail(P264HIP_EINVAL, "p264hip_upload_compact: the block is not a consistent compact picture of %dx%d macroblocks with %u coefficient blocks (B pictures travel in the slot layout)", desc->mb_w, desc->mb_h, desc->n_coef_blocks);
+    p264hip_input_layout_t L;
+    if (p264hip_input_layout(desc, &L)) return fail(P264HIP_EINVAL, "picture layout");
+    PicSlot &s = c->pics[(size_t)slot];
+    if ((rc = slot_prepare(c, s, L))) return rc;
+    if (bytes > s.stage_cap) {
+        if (s.stage) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(s.stage)); s.stage = nullptr; s.stage_cap = 0; }
+        const size_t cap = bytes + bytes / 4;
+        hipError_t e = hipMalloc((void **)&s.stage, cap);
+        if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for a compact picture: %s", cap, hipGetErrorString(e));
+        s.stage_cap = cap;
+    }
+    const int cs = c->next_cs; c->next_cs = (c->next_cs + 1) % COPY_STREAMS;
+    if (!c->cstream[cs]) {
+        HIPCHK(hipStreamCreateWithFlags(&c->cstream[cs], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->cdone[cs], hipEventDisableTiming));
+    }
+    if (!c->cwaited[cs]) {
+        // the last expansion kernel (it read the staging areas) is in front of this side stream's copies; nothing else is - a
+        // copy into a staging area never touches the slot's arrays, so step t + 1's blocks travel while step t is reconstructed
+        if (c->expand_done) HIPCHK(hipStreamWaitEvent(c->cstream[cs], c->expand_done, 0));
+        c->cwaited[cs] = true;
+    }
+    HIPCHK(hipMemcpyAsync(s.stage, compact, bytes, hipMemcpyHostToDevice, c->cstream[cs]));
+    c->cdirty[cs] = true;
+    c->upload_copies += 1;
+    slot_meta(s, desc);
+    if (!s.pending) { s.pending = true; c->pending.push_back(slot); }
+    s.valid = true; s.unchecked = false; s.reserved = false; s.last_use = ++c->epoch;
     return P264HIP_OK;
 }
 
@@ -333,6 +437,7 @@ extern "C" int p264hip_input_reserve(p264hip_ctx *c, int slot, const p264hip_pic
     if (rc) return rc;
     p264hip_input_layout_t L;
     if (p264hip_input_layout(desc, &L)) return fail(P264HIP_EINVAL, "picture layout");
+    unpend(c, slot);
     PicSlot &s = c->pics[(size_t)slot];
     s.valid = false;
     // Whatever still reads the slot's previous picture on the context's stream must be through before somebody else writes
@@ -483,6 +588,8 @@ extern "C" int p264hip_clone_picture(p264hip_ctx *c, int dst, int src)
     if (!c || dst < 0 || src < 0 || dst >= c->max_pictures || src >= c->max_pictures || dst == src || !c->pics[(size_t)src].valid)
         return fail(P264HIP_EINVAL, "p264hip_clone_picture: bad slots %d <- %d", dst, src);
     HIPCHK(hipSetDevice(c->device));
+    unpend(c, dst);
+    { const int rc = expand_pending(c); if (rc) return rc; }   // (src may still be a compact block)
     PicSlot &d = c->pics[(size_t)dst], &s = c->pics[(size_t)src];
     size_t need = s.bytes;
     if (need > d.cap) {
@@ -517,6 +624,7 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
 {
     if (!c || !pic_ids || !streams || n < 1) return fail(P264HIP_EINVAL, "p264hip_reconstruct: bad argument");
     HIPCHK(hipSetDevice(c->device));
+    { const int rc = expand_pending(c); if (rc) return rc; }   // compact uploads since the last launch: one expansion kernel for all of them
     if (n > c->batch_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int i = 0; i < BATCH_RING; i++) {
@@ -753,6 +861,7 @@ extern "C" int p264hip_sync(p264hip_ctx *c)
 #endif
     if (!c) return fail(P264HIP_EINVAL, "null context");
     HIPCHK(hipSetDevice(c->device));
+    { const int rc = expand_pending(c); if (rc) return rc; }
     { const uint64_t upto = c->epoch; HIPCHK(hipStreamSynchronize(c->stream)); c->done_epoch = upto; }
     drain_stamps(c);
     int st = 0;

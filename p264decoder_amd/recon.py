@@ -151,6 +151,32 @@ class HipReconstructor:
             raise P264Error("p264hip_pack_input: %d" % n)
         return buf
 
+    @staticmethod
+    def pack_compact(picture, lib=None):
+        """The picture's arrays in the compact link format (include/p264hip.h: p264hip_compact_hdr_t); numpy uint8, host side only."""
+        lib = lib or N.load()
+        buf = np.zeros(lib.p264hip_compact_bound(C.byref(picture.desc)), np.uint8)
+        n = lib.p264hip_pack_compact(C.byref(picture.desc), buf.ctypes.data, buf.size)
+        if n < 0:
+            raise P264Error("p264hip_pack_compact: %d" % n)
+        return buf[:n].copy()
+
+    @staticmethod
+    def expand_compact(picture, compact, lib=None):
+        """Host reference of the device expansion: the compact block back in the slot layout (what pack() gives, up to bytes no kernel reads)."""
+        lib = lib or N.load()
+        lay = N.InputLayout()
+        if lib.p264hip_input_layout(C.byref(picture.desc), C.byref(lay)) != 0:
+            raise P264Error("p264hip_input_layout failed")
+        out = np.zeros(lay.bytes, np.uint8)
+        rc = lib.p264hip_expand_compact(C.byref(picture.desc), compact.ctypes.data, compact.size, out.ctypes.data, out.size)
+        if rc != 0:
+            raise P264Error("p264hip_expand_compact: %d" % rc)
+        return out
+
+    def upload_compact(self, slot, picture, compact):
+        self._chk(self.lib.p264hip_upload_compact(self.h, slot, C.byref(picture.desc), compact.ctypes.data, compact.size), "p264hip_upload_compact")
+
     def upload_packed(self, slot, picture, packed):
         self._chk(self.lib.p264hip_upload_packed(self.h, slot, C.byref(picture.desc), packed.ctypes.data, packed.size), "p264hip_upload_packed")
 

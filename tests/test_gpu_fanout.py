@@ -273,3 +273,65 @@ def test_a_clone_takes_the_verdict_of_the_record_check_along(lib):
     for a, b in zip(hip.read_frame(0, p.desc.dst_slot), hip.read_frame(2, p.desc.dst_slot)):
         assert np.array_equal(a, b)
     hip.close()
+
+
+def test_compact_uploads_match_the_plain_upload(lib):
+    """p264hip_upload_compact (the compact link format, include/p264hip.h) against p264hip_upload, picture by picture and as a
+    batch: the blocks of several pictures wait for ONE expansion kernel (k_expand_compact) in front of the reconstruct call;
+    parsed streams (all vector shapes, Intra4x4 modes, narrow levels) and seam-level random pictures with levels up to the
+    int16 limits and sub-8x8 vectors; a slot that gets new content by another road before its block was expanded; a clone of
+    a slot whose block has not been expanded yet."""
+    import numpy as np
+    from p264decoder_amd import HipReconstructor, Parser
+    from tests import seam_fuzz
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("cif_ip"))[:10]
+    S = 3
+    hip = HipReconstructor(pics[0].mb_w, pics[0].mb_h, n_streams=S + 1, slots=parser.slots, max_pictures=S + 2, lib=lib)
+    for i, p in enumerate(pics):
+        blk = HipReconstructor.pack_compact(p, lib)
+        hip.upload(0, [p])
+        for s in range(1, S):
+            hip.upload_compact(s, p, blk)
+        if i == 3:                                              # superseded before it was expanded: the plain upload must win
+            hip.upload_compact(1, pics[0], HipReconstructor.pack_compact(pics[0], lib))
+            hip.upload(1, [p])
+        hip.clone_picture(S, 2)                                 # (expands what is pending first)
+        hip.reconstruct([0, 1, 2, S], [0, 1, 2, S])
+        hip.sync()
+        f0 = hip.read_frame(0, p.desc.dst_slot)
+        for s in (1, 2, S):
+            for a, b in zip(f0, hip.read_frame(s, p.desc.dst_slot)):
+                assert np.array_equal(a, b), "picture %d stream %d" % (i, s)
+    hip.close()
+    # seam-level pictures: every level style, sub-8x8 partitions, several references
+    rng = np.random.default_rng(99)
+    mb_w, mb_h = 9, 6
+    hip = HipReconstructor(mb_w, mb_h, n_streams=2, slots=3, max_pictures=2, lib=lib)
+    for s in range(2):
+        for slot in range(3):
+            hip.write_frame(s, slot, *seam_fuzz.random_frame(np.random.default_rng(5 + slot), mb_w, mb_h))
+    for k in range(8):
+        p = seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=(k != 3), n_ref=2, slots=3, dst_slot=k % 3, level_style=["small", "large", "wrap", "mixed"][k % 4], sub8x8=True)
+        hip.upload(0, [p])
+        hip.upload_compact(1, p, HipReconstructor.pack_compact(p, lib))
+        hip.reconstruct([0, 1], [0, 1])
+        hip.sync()
+        for a, b in zip(hip.read_frame(0, p.desc.dst_slot), hip.read_frame(1, p.desc.dst_slot)):
+            assert np.array_equal(a, b), "seam picture %d" % k
+    hip.close()
+    # 1080p: the golden all-P stream through compact uploads only, against the reference decoder's hashes
+    from tests.conftest import frame_sha256
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("cfg3_1080p_allp"), limit=4)
+    hashes = synth_cases.golden("cfg3_1080p_allp")[1]
+    hip = HipReconstructor(120, 68, n_streams=1, slots=parser.slots, max_pictures=1, lib=lib)
+    sizes = []
+    for i, p in enumerate(pics):
+        blk = HipReconstructor.pack_compact(p, lib)
+        sizes.append((blk.size, HipReconstructor.pack(p, lib).size))
+        hip.upload_compact(0, p, blk)
+        hip.reconstruct([0], [0])
+        assert frame_sha256(*hip.read_frame(0, p.desc.dst_slot)) == hashes[i], "1080p picture %d through the compact format" % i
+    hip.close()
+    assert all(c < 0.45 * f for c, f in sizes[1:]), sizes          # a P picture of the bench's kind: well under half its slot layout

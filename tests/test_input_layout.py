@@ -115,3 +115,66 @@ def test_the_parser_builds_its_pictures_in_the_layout_of_an_input_slot(lib, case
         n_pics += 1
     lib.p264parse_close(h)
     assert n_pics >= 6 and in_one >= n_pics - 2
+
+
+def _seam_pictures():
+    """parsed pictures of several streams + seam-level random pictures with levels up to the int16 limits and sub-8x8 vectors"""
+    import numpy as np
+    from tests import seam_fuzz
+    pics = []
+    for case in ("cif_ip", "dense", "qp0", "mv_far"):
+        pics += Parser(quiet=True).parse_stream(synth_cases.stream_bytes(case))[:6]
+    rng = np.random.default_rng(77)
+    for k in range(6):
+        pics.append(seam_fuzz.make_picture(rng, 7, 5, p_picture=(k != 2), n_ref=2, slots=3, dst_slot=0, level_style="mixed" if k % 2 else "small", sub8x8=True))
+    return pics
+
+
+def test_compact_link_format_round_trip(lib):
+    """p264hip_pack_compact -> p264hip_expand_compact gives the slot layout back: records, reference indices and coded levels byte
+    for byte, the vectors of every inter macroblock, the Intra4x4 modes of every Intra4x4 macroblock (zero vectors / mode 2
+    elsewhere: nothing reads those); the block is smaller; a tampered block is refused by the check the upload runs."""
+    import ctypes as C
+    import numpy as np
+    from p264decoder_amd import HipReconstructor, _native as N
+    shapes = set()
+    for p in _seam_pictures():
+        if p.desc.slice_type == N.SLICE_B:
+            continue
+        plain = HipReconstructor.pack(p, lib)
+        comp = HipReconstructor.pack_compact(p, lib)
+        assert lib.p264hip_compact_check(C.byref(p.desc), comp.ctypes.data, comp.size) == 0
+        back = HipReconstructor.expand_compact(p, comp, lib)
+        lay = N.InputLayout()
+        lib.p264hip_input_layout(C.byref(p.desc), C.byref(lay))
+        n = p.desc.mb_w * p.desc.mb_h
+        rec = plain[:n * 16].reshape(n, 16)
+        assert np.array_equal(back[:n * 16], plain[:n * 16])
+        assert np.array_equal(back[lay.off_ref:lay.off_ref + n * 4], plain[lay.off_ref:lay.off_ref + n * 4])
+        nb = p.desc.n_coef_blocks
+        assert np.array_equal(back[lay.off_coef:lay.off_coef + nb * 32], plain[lay.off_coef:lay.off_coef + nb * 32])
+        inter = rec[:, 0] > N.MB_IPCM
+        mv_b, mv_p = back[lay.off_mv:lay.off_mv + n * 64].reshape(n, 64), plain[lay.off_mv:lay.off_mv + n * 64].reshape(n, 64)
+        assert np.array_equal(mv_b[inter], mv_p[inter]) and not mv_b[~inter].any()
+        i4 = rec[:, 0] == N.MB_I4x4
+        m_b, m_p = back[lay.off_i4:lay.off_i4 + n * 16].reshape(n, 16), plain[lay.off_i4:lay.off_i4 + n * 16].reshape(n, 16)
+        assert np.array_equal(m_b[i4], m_p[i4]) and (m_b[~i4] == 2).all()
+        hdr = comp[:64].view(np.uint32)
+        shape_bits = comp[hdr[6]:hdr[6] + (n + 3) // 4]
+        shapes |= {int((shape_bits[i >> 2] >> (2 * (i & 3))) & 3) for i in range(n)}
+        assert comp.size < plain.size
+        # tampering: a shape bit, a count, the size
+        for off, what in ((int(hdr[6]), "shape"), (44, "n_vec"), (12, "bytes")):
+            bad = comp.copy()
+            bad[off] ^= 1
+            assert lib.p264hip_compact_check(C.byref(p.desc), bad.ctypes.data, bad.size) != 0, what
+    assert shapes == {0, 1, 2, 3}
+
+
+def test_compact_format_refuses_b_pictures(lib):
+    import ctypes as C
+    import numpy as np
+    pics = Parser(quiet=True).parse_stream(synth_cases.stream_bytes(B_CIF))
+    b = [p for p in pics if p.desc.slice_type == 1][0]
+    buf = np.zeros(lib.p264hip_compact_bound(C.byref(b.desc)), np.uint8)
+    assert lib.p264hip_pack_compact(C.byref(b.desc), buf.ctypes.data, buf.size) < 0

@@ -35,3 +35,4 @@ int p264hip_copy_from_device(void *h, const void *d, size_t n) { (void)h;(void)d
 int p264fan_rccl_unique_id(uint8_t id[128]) { (void)id; return -1; }
 int p264fan_rccl_transport(p264fan_transport_t *t, int r, int w, const uint8_t id[128], int d) { (void)t;(void)r;(void)w;(void)id;(void)d; return -1; }
 int64_t p264hip_upload_copies(p264hip_ctx *c) { (void)c; return -1; }
+int p264hip_upload_compact(p264hip_ctx *c, int s, const p264hip_picture_t *d, const void *p, size_t n) { (void)c;(void)s;(void)d;(void)p;(void)n; return -1; }

@@ -437,13 +437,23 @@ template <int K> __device__ __forceinline__ pk16 pair_byte(uint32_t a, uint32_t 
 // rows above + 16 rows; chroma columns 2(j&3), +1 of plane j>>2), again two lines per instruction.
 //
 // A wavefront's eight octets are `8 >> rb_log2` pictures x `1 << rb_log2` consecutive macroblock rows
-// (a BAND).  Octet g of a band works on macroblock x = t - 2g in iteration t, which is exactly the lag
-// the raster order demands, and hands the bottom rows of a finished macroblock to the octet below
+// (a BAND).  Octet g of a band works on macroblock x = t - DB_LAG * g in iteration t (DB_LAG = 1: the lag
+// the raster order demands once an iteration runs its vertical edges before its horizontal ones, see DB_LAG), and hands the bottom rows of a finished macroblock to the octet below
 // through an LDS ring.  Bands synchronise through progress counters in LDS (wavefront_sync.h); the
 // pixels of the band above travel through global memory (same CU, same L1).
 //
 // Every sample is loaded once and stored once, both as whole 16-byte (8-byte chroma) rows: the store
 // of macroblock x-1 waits one iteration for its last four columns, which the left edge of x changes.
+// Columns a row of a band lags behind the row above it.  The raster order needs MB (x, y) after (x - 1, y) and after the LEFT EDGE
+// of (x + 1, y - 1) - which changes the last columns of (x, y - 1), rows 12 - 15 included - but not after the rest of (x + 1, y - 1):
+// an iteration filters all vertical edges first (registers), hands the finished rows 12 - 15 of macroblock x - 1 to the octet
+// below, and only then runs the horizontal edges, whose top edge is the first thing to read those rows.  So the octet below can
+// work on macroblock x - 1 of its row in the SAME iteration: a lag of one column per row, not two (rounds 1 - 5 ran with two:
+// 2 x 67 + 120 = 254 dependent iterations down a 1080p picture instead of 67 + 120 = 187 - what a picture costs where it has a
+// CU to itself: 0.98 -> 0.7x ms at 256 pictures per launch and for the single picture of the drop-in API).
+#ifndef DB_LAG
+#define DB_LAG 1
+#endif
 #define RING_SLOTS   4
 #define RING_DW      24            // per slot: 4 luma rows x 4 dwords, then 2 planes x 2 rows x 2 dwords
 #define TILE_DW      100           // 16 luma rows x 4 dwords, 2 planes x 8 rows x 2 dwords, +4 so that octets land on different banks
@@ -532,7 +542,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         // Addresses inside the iteration loop: macroblock x = t - 2 gr of the row.  The lane-constant part (- 2 gr strips) is folded
         // into the bases here, in 64-bit arithmetic, so that the loop adds only t x strip - a scalar - to one pointer per array
         // (as (uint32) x * strip the compiler cannot fold it and keeps one 64-bit constant per array alive: registers it does not have).
-        const ptrdiff_t lag = -(ptrdiff_t)(2 * gr);
+        const ptrdiff_t lag = -(ptrdiff_t)(DB_LAG * gr);
         uint8_t *ownY0 = ownY + lag * (ptrdiff_t)sY, *ownC0 = ownC + lag * (ptrdiff_t)sC, *topP0 = topP + lag * (ptrdiff_t)sT;
         const EdgeInfo *pinfo0 = pinfo + (ptrdiff_t)row * g.mb_w + lag;
         int *my_progress = &progress[piw & (MAX_PICS_PER_WG - 1)][band];
@@ -541,14 +551,14 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
 
         uint32_t ya0 = 0, yb0 = 0, ca0 = 0, cb0 = 0;                  // columns -4..-1: the previous macroblock's last four
         uint4 fYa = make_uint4(0, 0, 0, 0), fYb = fYa, fC = fYa, fT = fYa, fE = fYa;   // in flight for the next iteration
-        const int n_iter = g.mb_w + 1 + 2 * last;
+        const int n_iter = g.mb_w + 1 + DB_LAG * last;
         const int *wait_on = from_above ? my_progress - 1 : my_progress;
         // tile addresses of this lane's rows
         uint32_t *tYa = L.tile + (2 * j) * 4, *tYb = tYa + 4, *tCa = L.tile + 64 + cp * 16 + cr * 2, *tCb = tCa + 2;
 
         // loads for iteration t
         auto prefetch = [&](int t) {
-            const int x = t - 2 * gr;
+            const int x = t - DB_LAG * gr;
             const bool actn = have_row && x >= 0 && x < g.mb_w;
             if (ok) {
                 // macroblock x needs the band above to have stored x completely
@@ -586,7 +596,7 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         prefetch(0);
         for (int t = 0; t < n_iter; t++) {
             DB_STAMP(0);
-            const int x = t - 2 * gr;
+            const int x = t - DB_LAG * gr;
             const bool act = have_row && x >= 0 && x < g.mb_w;         // filter macroblock x
             const bool flush = have_row && x >= 1 && x <= g.mb_w;       // store macroblock x-1
             uint32_t *ring = L.ring[x & 3];

@@ -786,11 +786,11 @@ extern "C" int p264hip_reconstruct(p264hip_ctx *c, const int *pic_ids, const int
         auto units_cost = [&](int lg) {
             const int rows = 1 << lg, pw = 8 >> lg;
             const long bands = (g.mb_h + rows - 1) / rows, groups = (per_wg + pw - 1) / pw;
-            return bands * groups * (long)(g.mb_w + 1 + 2 * (rows - 1));
+            return bands * groups * (long)(g.mb_w + 1 + DB_LAG * (rows - 1));
         };
         int rb_log2 = units_cost(3) < units_cost(2) ? 3 : 2;
         // an odd number (>= 3) of pictures: the pairs in bands of 4 rows, the last picture alone in bands of 8 (k_deblock, odd_single)
-        const long cost_mixed = (per_wg >= 3 && (per_wg & 1)) ? ((g.mb_h + 3) / 4) * (long)(per_wg / 2) * (g.mb_w + 7) + ((g.mb_h + 7) / 8) * (long)(g.mb_w + 15) : -1;
+        const long cost_mixed = (per_wg >= 3 && (per_wg & 1)) ? ((g.mb_h + 3) / 4) * (long)(per_wg / 2) * (g.mb_w + 1 + 3 * DB_LAG) + ((g.mb_h + 7) / 8) * (long)(g.mb_w + 1 + 7 * DB_LAG) : -1;
         int odd_single = cost_mixed >= 0 && cost_mixed < units_cost(rb_log2);
         if (odd_single) rb_log2 = 2;
         if (c->tune_rb_log2 >= 1 && c->tune_rb_log2 <= 3) { rb_log2 = c->tune_rb_log2; odd_single = 0; }

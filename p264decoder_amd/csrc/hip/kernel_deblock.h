@@ -133,19 +133,28 @@ __device__ __forceinline__ void pic_of_init(PicOf &T, const PicDev *pd)
         T.of[l][k] = l == 0 ? pd->ref_off[k < pd->n_ref ? k : 0] : pd->ref_off_l1[k < pd->n_ref_l1 ? k : 0];
     }
 }
+// what edge_info_of needs of the macroblock above: the type / QP word and the coded-block mask of its record, the bottom row of
+// its vectors, its reference indices.  A caller that walks a column downwards has them in registers from the row before
+// (the edge-info role of k_intra_sparse, round 6); everybody else lets edge_info_of load them (top = nullptr).
+struct EdgeTop { uint32_t rec_x, rec_y, refs; uint4 mv; };
 template <bool TWO_LISTS>
 __device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, int mbi, int mbx, int mby, const uint4 rec,
-                                              const uint4 m0, const uint4 m1, const uint4 m2, const uint4 m3, const uint32_t refs, const PicOf *pic_tab)
+                                              const uint4 m0, const uint4 m1, const uint4 m2, const uint4 m3, const uint32_t refs, const PicOf *pic_tab,
+                                              const EdgeTop *top = nullptr)
 {
     const bool b_pic = TWO_LISTS && pd->slice_type == P264_SLICE_B;
     // neighbours (self where there is none: unused).  (ti written so that no select needs the picture width in a vector register)
     const int above = mbi - g.mb_w;
     const int li = mbx > 0 ? mbi - 1 : mbi, ti = above >= 0 ? above : mbi;
     const uint4 *recs = (const uint4 *)pd->mb;
-    const uint4 recT = gload4(ubase(recs, (uint32_t)ti * 16u));
     const int *mvs = pd->mv;
-    const uint4 mT = gload4(ubase(mvs, (uint32_t)ti * 64u + 48u));                     // bottom row of the macroblock above
-    const uint32_t refsT = gload1(ubase(pd->ref_idx, (uint32_t)ti * 4u));
+    uint4 recT, mT; uint32_t refsT;
+    if (top) { recT = make_uint4(top->rec_x, top->rec_y, 0u, 0u); mT = top->mv; refsT = top->refs; }       // (compile time: the pointer is a constant of the call site)
+    else {
+        recT = gload4(ubase(recs, (uint32_t)ti * 16u));
+        mT = gload4(ubase(mvs, (uint32_t)ti * 64u + 48u));                              // bottom row of the macroblock above
+        refsT = gload1(ubase(pd->ref_idx, (uint32_t)ti * 4u));
+    }
     // The left macroblock is the lane below's own macroblock (callers: consecutive lanes = consecutive macroblocks, and a lane's
     // left neighbour is active whenever the lane is): its record, the right column of its vectors and its reference indices
     // come out of that lane's registers (DPP wave_shr:1) - as loads they were six requests per lane for bytes that another
@@ -206,12 +215,17 @@ __device__ __forceinline__ uint4 edge_info_of(const PicDev *pd, const Geom &g, i
 
     // ---- boundary strengths, core/frame.c:535-581 ----
     uint32_t word[2] = { 0, 0 };
+    // (the top edge first: what it needs of the macroblock above - four vectors, indices, mask - is dead after four segments instead of
+    // alive through all thirty-two; the edge-info role of the 64-register k_intra_sparse build has no register to spare)
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++)
 #pragma unroll
     for (int dir = 0; dir < 2; dir++)
 #pragma unroll
         for (int e = 0; e < EXPD_EDGE_INFO_EDGES; e++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
+                if ((pass == 0) != (dir == 1 && e == 0)) continue;
                 const int x = dir == 0 ? e : i, y = dir == 0 ? i : e;
                 const int xn = dir == 0 ? (x + 3) & 3 : x, yn = dir == 0 ? y : (y + 3) & 3;
                 const bool outer = e == 0;

@@ -698,6 +698,58 @@ void k_intra_sparse(const PicDev *__restrict__ pics, Geom g, int *status, const 
         if (!pd->deblock) return;
         // (stores through a buffer descriptor of the picture's edge-info array: 32-bit offsets, no 64-bit address per lane)
         const rsrc_t info_rs = make_rsrc(info + (size_t)pic * g.n_mb, (uint32_t)g.n_mb * (uint32_t)sizeof(EdgeInfo));
+        // Round 6: with ONE edge-info workgroup per picture (the default) a thread walks a COLUMN of macroblocks downwards - lanes are
+        // neighbouring columns of one row: the loads stay whole cache lines, the left neighbour still comes out of the lane below
+        // (DPP) - and what edge_info_of needs of the macroblock above (record, bottom row of its vectors, reference indices) is what
+        // the thread itself held one row earlier: no load.  As three loads per macroblock of lines another thread had fetched 120
+        // macroblocks earlier they were 96 bytes of 32-byte sectors per macroblock that often had to come from memory again (the
+        // launch streams ~ 4 TB/s through 32 MB of L2): 3.49 GB for 1.75 GB of algorithmic bytes in round 5.  The workgroup's threads
+        // cover blockDim / pitch segments of rows (pitch = the picture's width rounded up to wavefronts); a segment's first row loads.
+        const int pitch = (g.mb_w + 63) & ~63;
+        if (bs_wgs == 1 && pitch <= (int)blockDim.x) {
+            const int segs = (int)blockDim.x / pitch, seg = rfl((int)threadIdx.x / pitch), rows = (g.mb_h + segs - 1) / segs;      // (a wavefront lies inside one segment: scalars)
+            int col = (int)threadIdx.x - seg * pitch;
+            asm volatile("" : "+v"(col));
+            const int y0 = seg * rows, y1 = min(y0 + rows, g.mb_h);
+            const bool mine = seg < segs && col < g.mb_w;
+            // (the carried words live in the launch's dynamic LDS - the intra roles' tiles, which this workgroup does not use: 32 bytes
+            // per thread {record word 0, coded-block mask, reference indices, -} {bottom row of vectors}; in registers they cost this
+            // 64-register build five spills)
+            extern __shared__ __attribute__((aligned(16))) uint8_t intra_dyn_lds[];
+            uint4 *carry = (uint4 *)intra_dyn_lds + 2 * threadIdx.x;
+            const int *mvs = pd->mv;
+            if (mine && y0 < y1) {
+                uint4 r = make_uint4(0, 0, 0, 0), m = r; uint32_t rf = 0;
+                if (y0 > 0) {
+                    const uint32_t ti = (uint32_t)((y0 - 1) * g.mb_w + col);
+                    r = gload4(ubase(pd->mb, ti * 16u)); m = gload4(ubase(mvs, ti * 64u + 48u)); rf = gload1(ubase(pd->ref_idx, ti * 4u));
+                }
+                carry[0] = make_uint4(r.x, r.y, rf, 0u); carry[1] = m;
+            }
+            for (int y = y0; y < y1; y++) {                    // (uniform trip count per wavefront: a wavefront lies inside one segment)
+                if (!mine) continue;
+                // (column and LDS slot derived from the thread number again per row: two instructions, no register held across the loop -
+                // the build has 64)
+                int tid = (int)threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                const int col = tid - seg * pitch;
+                uint4 *carry = (uint4 *)intra_dyn_lds + 2 * tid;
+                int mbi = y * g.mb_w + col;
+                asm volatile("" : "+v"(mbi));
+                const uint4 rec = gload4(ubase(pd->mb, (uint32_t)mbi * 16u));
+                const uint4 m0 = gload4(ubase(mvs, (uint32_t)mbi * 64u)), m1 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 16u)), m2 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 32u)), m3 = gload4(ubase(mvs, (uint32_t)mbi * 64u + 48u));
+                const uint32_t refs = gload1(ubase(pd->ref_idx, (uint32_t)mbi * 4u));
+                const uint4 c0 = carry[0];
+                const EdgeTop top = { c0.x, c0.y, c0.z, carry[1] };
+                carry[0] = make_uint4(rec.x, rec.y, refs, 0u); carry[1] = m3;
+                const uint4 ei = edge_info_of<false>(pd, g, mbi, col, y, rec, m0, m1, m2, m3, refs, nullptr, &top);
+                // (the store's offset from the thread number once more: kept alive across edge_info_of it was the build's one spill)
+                int tid2 = (int)threadIdx.x;
+                asm volatile("" : "+v"(tid2));
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{ ei.x, ei.y, ei.z, ei.w }, info_rs, (y * g.mb_w + tid2 - seg * pitch) * 16, 0, 0);
+            }
+            return;
+        }
         for (int mbi_it = (role - 2) * (int)blockDim.x + (int)threadIdx.x; mbi_it < g.n_mb; mbi_it += bs_wgs * (int)blockDim.x) {
             // (every address below is a scalar base + this 32-bit index: hidden from the loop optimiser, which otherwise turns each
             // into a 64-bit induction variable per lane - this build has 64 registers)

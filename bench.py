@@ -686,7 +686,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-metric figures (config 2, config 3 I+P, pipeline, drop-in API)")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (HBM traffic, vector instructions) behind the timed region")
-    ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0)")
+    ap.add_argument("--no-fanout", action="store_true", help="N > 1: skip the config-5 fan-out leg (also P264AMD_BENCH_FANOUT=0).  By default the leg runs at "
+                    "N = 2 only - two more GPU processes beside the two ranks - so that a transport that has never met a second device cannot take "
+                    "the N = 4 / 8 scaling lines down with it; P264AMD_BENCH_FANOUT=1 runs it at any N > 1")
     ap.add_argument("--only-upload-inclusive", action="store_true", help="print extras.upload_inclusive (both formats) and nothing else")
     ap.add_argument("--only-batch-256", action="store_true", help="print extras.batch_256 (the metric's workload at 256 pictures per launch) and nothing else")
     args = ap.parse_args()
@@ -898,7 +900,8 @@ def main():
                                  "simds": simds, "clock_MHz": round(hz / 1e6), "clock_source": "measured under load in round 5 (GRBM_GUI_ACTIVE), static here",
                                  "source": "live: SQ_INSTS_VALU pass of the same child run, 4 cycles per wave instruction"}
     fan = None
-    if world > 1 and not args.no_fanout and os.environ.get("P264AMD_BENCH_FANOUT", "1") != "0":
+    fan_env = os.environ.get("P264AMD_BENCH_FANOUT", "")
+    if world > 1 and not args.no_fanout and fan_env != "0" and (world == 2 or fan_env == "1"):
         fan = fanout_leg(rank, local_rank, world, lib)       # after the timed region, in child processes, never `value`
     if rank == 0:
         if not args.no_extras and world == 1:

@@ -85,11 +85,12 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
 
 
 def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
-    """No WORLD_SIZE: bench.py is its own launcher.  Without a GPU the ranks it starts refuse to run (no CPU fallback) - both of
-    them, each under its own RANK - and the parent reports the failure instead of a JSON line."""
+    """No WORLD_SIZE: bench.py is its own launcher.  Without a GPU the ranks it starts refuse to run (no CPU fallback; the
+    launcher ends the other rank as soon as the first one has failed, so one or two of them get to say so) and the parent reports
+    the failure instead of a JSON line."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("CPU-only check of the launcher (the GPU box runs tests/test_gpu_bench_ranks.py)")
     out = _bench(["--gpus", "2", "--steps", "1", "--streams", "2", "--no-extras"], {})
     assert out.returncode != 0 and not out.stdout.strip()
-    assert out.stderr.count("bench.py needs an MI355X") == 2 and "the ranks failed" in out.stderr
+    assert 1 <= out.stderr.count("bench.py needs an MI355X") <= 2 and "the ranks failed" in out.stderr

@@ -172,27 +172,31 @@ int  p264hip_unpack_input(const p264hip_picture_t *desc, const void *packed, siz
 int  p264hip_upload_packed(p264hip_ctx *ctx, int slot, const p264hip_picture_t *desc, const void *packed, size_t bytes);
 /* ---- the compact LINK format (round 6).  A picture's arrays as they travel where the link is the bound (a packed upload over
  * PCIe, a scatter over xGMI / TCP): 1.42 MB per 1080p P picture of the bench stream in the slot layout, ~0.5 MB compact -
- *   records and reference indices verbatim (16 + 4 bytes per macroblock);
- *   vectors by shape, 2 bits per macroblock: 0 none (intra), 1 one vector (16x16 / skip), 2 one per 8x8 quadrant, 3 all sixteen;
- *   Intra4x4 modes for Intra4x4 macroblocks only;
- *   coded levels as sixteen int8 per block where every level of the block fits (one flag bit per block), else sixteen int16.
- * Nothing is lost: p264hip_expand_compact (host; the reference of the device kernel) gives back the slot layout, with zero
- * vectors for intra macroblocks and mode 2 (DC) for macroblocks that are not Intra4x4 - values no kernel reads.  P and I pictures
- * (a B picture returns P264HIP_EINVAL: its list-1 arrays travel in the slot layout, p264hip_pack_input).
+ *   records and reference indices verbatim (16 + 4 bytes per macroblock and list);
+ *   vectors by shape, 2 bits per macroblock and list: 0 sixteen zero vectors (intra macroblocks, an unused list, a block at
+ *   rest), 1 one vector (16x16 / skip), 2 one per 8x8 quadrant, 3 all sixteen;
+ *   Intra4x4 modes only for the macroblocks whose sixteen modes are not all 2 (DC: what a parser leaves everywhere else), one
+ *   flag bit per macroblock;
+ *   coded levels as sixteen int8 per block where every level of the block fits (one flag bit per block), else sixteen int16;
+ *   B pictures: the same for list 1, and the 512 bytes of bipred_weight[].
+ * Nothing is lost: p264hip_expand_compact (host; the reference of the device kernel) gives back the slot layout byte for byte
+ * (p264hip_pack_input's block, up to the padding between its sections).
  * p264hip_upload_compact copies the block into a staging area of the slot (one asynchronous copy) and queues its expansion:
  * ONE kernel expands every picture uploaded since the last one, in front of the next p264hip_reconstruct (or clone / sync).
  * Like p264hip_upload_packed the call trusts the block to come from the packer (which checks the records as p264hip_upload
  * does): it checks the header (O(1): p264hip_compact_header_ok - sections inside the block, in order, large enough for the
  * header's counts) and the device clamps every place it derives from the block's bits to its section - an inconsistent block
  * gives a wrong picture, never an access outside the block or the slot.  p264hip_compact_check is the full check (counts implied
- * by the shape and flag bits, records) for blocks from anywhere else. */
+ * by the shape and flag bits, records, weights) for blocks from anywhere else. */
 #define P264HIP_COMPACT_MAGIC 0x43343632u           /* "264C" */
 #define P264HIP_COMPACT_MAX_MB 8192                 /* macroblocks per picture the device expansion takes (its offsets live in LDS) */
-typedef struct p264hip_compact_hdr {                /* 64 bytes; sections follow at 16-byte aligned offsets from the block's start */
+typedef struct p264hip_compact_hdr {                /* 128 bytes; sections follow at 16-byte aligned offsets from the block's start */
     uint32_t magic, n_mb, n_coef_blocks, bytes;     /* bytes: of the whole block */
-    uint32_t off_rec, off_ref, off_shape, off_vec, off_i4, off_lvflag, off_levels;
-    uint32_t n_vec, n_i4, level_bytes;              /* vectors (dwords) in the vec section, Intra4x4 macroblocks, bytes of levels */
-    uint32_t reserved[2];
+    uint32_t n_lists;                               /* 1; 2 for a B picture */
+    uint32_t off_rec, off_i4flag, off_i4, off_lvflag, off_levels, off_weights;      /* off_weights: 0 unless n_lists == 2 */
+    uint32_t n_i4, level_bytes;                     /* macroblocks with an Intra4x4 mode entry, bytes of levels */
+    struct { uint32_t off_ref, off_shape, off_vec, n_vec; } list[2];               /* n_vec: vectors (dwords) in the list's vec section */
+    uint32_t reserved[11];
 } p264hip_compact_hdr_t;
 /* bytes a compact block of this picture needs at most */
 size_t  p264hip_compact_bound(const p264hip_picture_t *pic);

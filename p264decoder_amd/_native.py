@@ -63,6 +63,17 @@ class InputLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("off_mb", "off_mv", "off_ref", "off_i4", "off_coef", "off_mv_l1", "off_ref_l1", "off_weights", "bytes")]
 
 
+class CompactList(C.Structure):
+    _fields_ = [("off_ref", C.c_uint32), ("off_shape", C.c_uint32), ("off_vec", C.c_uint32), ("n_vec", C.c_uint32)]
+
+
+class CompactHdr(C.Structure):
+    """p264hip_compact_hdr_t (128 bytes)"""
+    _fields_ = [("magic", C.c_uint32), ("n_mb", C.c_uint32), ("n_coef_blocks", C.c_uint32), ("bytes", C.c_uint32), ("n_lists", C.c_uint32),
+                ("off_rec", C.c_uint32), ("off_i4flag", C.c_uint32), ("off_i4", C.c_uint32), ("off_lvflag", C.c_uint32), ("off_levels", C.c_uint32),
+                ("off_weights", C.c_uint32), ("n_i4", C.c_uint32), ("level_bytes", C.c_uint32), ("list", CompactList * 2), ("reserved", C.c_uint32 * 11)]
+
+
 class PipeStats(C.Structure):
     """p264pipe_stats_t"""
     _fields_ = [("pictures", C.c_int64), ("bytes", C.c_int64), ("seconds", C.c_double), ("parse_seconds", C.c_double),

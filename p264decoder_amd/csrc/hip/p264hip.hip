@@ -317,7 +317,8 @@ static int expand_pending(p264hip_ctx *c)
     } else HIPCHK(hipEventSynchronize(c->jobs_free));        // the copy that last read h_jobs is done
     for (int i = 0; i < n; i++) {
         PicSlot &s = c->pics[(size_t)c->pending[(size_t)i]];
-        c->h_jobs[i] = ExpandJob{ s.stage, s.dev, (uint32_t)s.off_mv, (uint32_t)s.off_ref, (uint32_t)s.off_i4, (uint32_t)s.off_coef };
+        c->h_jobs[i] = ExpandJob{ s.stage, s.dev, (uint32_t)s.off_mv, (uint32_t)s.off_ref, (uint32_t)s.off_i4, (uint32_t)s.off_coef,
+                                  (uint32_t)s.off_mv_l1, (uint32_t)s.off_ref_l1, (uint32_t)s.off_weights, 0u };
         s.pending = false;
     }
     c->pending.clear();
@@ -397,7 +398,7 @@ extern "C" int p264hip_upload_compact(p264hip_ctx *c, int slot, const p264hip_pi
     HIPCHK(hipSetDevice(c->device));
     int rc = check_pic(c, desc, false);
     if (rc) return rc;
-    if (!p264hip_compact_header_ok(desc, compact, bytes)) return fail(P264HIP_EINVAL, "p264hip_upload_compact: the block is not a consistent compact picture of %dx%d macroblocks with %u coefficient blocks (B pictures travel in the slot layout)", desc->mb_w, desc->mb_h, desc->n_coef_blocks);
+    if (!p264hip_compact_header_ok(desc, compact, bytes)) return fail(P264HIP_EINVAL, "p264hip_upload_compact: the block is not a consistent compact picture of %dx%d macroblocks with %u coefficient blocks", desc->mb_w, desc->mb_h, desc->n_coef_blocks);
     p264hip_input_layout_t L;
     if (p264hip_input_layout(desc, &L)) return fail(P264HIP_EINVAL, "picture layout");
     PicSlot &s = c->pics[(size_t)slot];

@@ -311,14 +311,29 @@ def test_compact_uploads_match_the_plain_upload(lib):
     for s in range(2):
         for slot in range(3):
             hip.write_frame(s, slot, *seam_fuzz.random_frame(np.random.default_rng(5 + slot), mb_w, mb_h))
-    for k in range(8):
-        p = seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=(k != 3), n_ref=2, slots=3, dst_slot=k % 3, level_style=["small", "large", "wrap", "mixed"][k % 4], sub8x8=True)
+    for k in range(12):
+        p = seam_fuzz.make_picture(rng, mb_w, mb_h, p_picture=(k != 3), b_picture=(k >= 8), n_ref=2, n_ref_l1=2, slots=3, dst_slot=k % 3,
+                                   level_style=["small", "large", "wrap", "mixed"][k % 4], sub8x8=True)
         hip.upload(0, [p])
         hip.upload_compact(1, p, HipReconstructor.pack_compact(p, lib))
         hip.reconstruct([0, 1], [0, 1])
         hip.sync()
         for a, b in zip(hip.read_frame(0, p.desc.dst_slot), hip.read_frame(1, p.desc.dst_slot)):
             assert np.array_equal(a, b), "seam picture %d" % k
+    hip.close()
+    # a parsed Main-profile stream (CABAC, I + P + B, implicit weights, direct prediction): compact against plain, picture by picture
+    from tests.test_input_layout import B_CIF
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes(B_CIF + " --cabac"))
+    assert sum(p.desc.slice_type == 1 for p in pics) >= 3
+    hip = HipReconstructor(pics[0].mb_w, pics[0].mb_h, n_streams=2, slots=parser.slots, max_pictures=2, lib=lib)
+    for i, p in enumerate(pics):
+        hip.upload(0, [p])
+        hip.upload_compact(1, p, HipReconstructor.pack_compact(p, lib))
+        hip.reconstruct([0, 1], [0, 1])
+        hip.sync()
+        for a, b in zip(hip.read_frame(0, p.desc.dst_slot), hip.read_frame(1, p.desc.dst_slot)):
+            assert np.array_equal(a, b), "Main-profile picture %d (slice type %d)" % (i, p.desc.slice_type)
     hip.close()
     # 1080p: the golden all-P stream through compact uploads only, against the reference decoder's hashes
     from tests.conftest import frame_sha256

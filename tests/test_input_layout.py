@@ -131,16 +131,20 @@ def _seam_pictures():
 
 
 def test_compact_link_format_round_trip(lib):
-    """p264hip_pack_compact -> p264hip_expand_compact gives the slot layout back: records, reference indices and coded levels byte
-    for byte, the vectors of every inter macroblock, the Intra4x4 modes of every Intra4x4 macroblock (zero vectors / mode 2
-    elsewhere: nothing reads those); the block is smaller; a tampered block is refused by the check the upload runs."""
+    """p264hip_pack_compact -> p264hip_expand_compact gives the slot layout back byte for byte - records, both lists' vectors and
+    reference indices, Intra4x4 modes, coded levels, a B picture's weights (only the padding between the sections is not
+    compared); the block is smaller; a tampered block is refused by the full check."""
     import ctypes as C
     import numpy as np
     from p264decoder_amd import HipReconstructor, _native as N
-    shapes = set()
-    for p in _seam_pictures():
-        if p.desc.slice_type == N.SLICE_B:
-            continue
+    assert C.sizeof(N.CompactHdr) == 128
+    shapes, n_b = set(), 0
+    pics = _seam_pictures() + Parser(quiet=True).parse_stream(synth_cases.stream_bytes(B_CIF))
+    rng = np.random.default_rng(78)
+    from tests import seam_fuzz
+    for k in range(3):
+        pics.append(seam_fuzz.make_picture(rng, 7, 5, p_picture=True, b_picture=True, n_ref=2, n_ref_l1=2, slots=3, dst_slot=0, level_style="mixed", sub8x8=True))
+    for p in pics:
         plain = HipReconstructor.pack(p, lib)
         comp = HipReconstructor.pack_compact(p, lib)
         assert lib.p264hip_compact_check(C.byref(p.desc), comp.ctypes.data, comp.size) == 0
@@ -148,33 +152,21 @@ def test_compact_link_format_round_trip(lib):
         lay = N.InputLayout()
         lib.p264hip_input_layout(C.byref(p.desc), C.byref(lay))
         n = p.desc.mb_w * p.desc.mb_h
-        rec = plain[:n * 16].reshape(n, 16)
-        assert np.array_equal(back[:n * 16], plain[:n * 16])
-        assert np.array_equal(back[lay.off_ref:lay.off_ref + n * 4], plain[lay.off_ref:lay.off_ref + n * 4])
         nb = p.desc.n_coef_blocks
-        assert np.array_equal(back[lay.off_coef:lay.off_coef + nb * 32], plain[lay.off_coef:lay.off_coef + nb * 32])
-        inter = rec[:, 0] > N.MB_IPCM
-        mv_b, mv_p = back[lay.off_mv:lay.off_mv + n * 64].reshape(n, 64), plain[lay.off_mv:lay.off_mv + n * 64].reshape(n, 64)
-        assert np.array_equal(mv_b[inter], mv_p[inter]) and not mv_b[~inter].any()
-        i4 = rec[:, 0] == N.MB_I4x4
-        m_b, m_p = back[lay.off_i4:lay.off_i4 + n * 16].reshape(n, 16), plain[lay.off_i4:lay.off_i4 + n * 16].reshape(n, 16)
-        assert np.array_equal(m_b[i4], m_p[i4]) and (m_b[~i4] == 2).all()
-        hdr = comp[:64].view(np.uint32)
-        shape_bits = comp[hdr[6]:hdr[6] + (n + 3) // 4]
+        sections = [(0, n * 16), (lay.off_mv, n * 64), (lay.off_ref, n * 4), (lay.off_i4, n * 16), (lay.off_coef, nb * 32)]
+        if p.desc.slice_type == N.SLICE_B:
+            n_b += 1
+            sections += [(lay.off_mv_l1, n * 64), (lay.off_ref_l1, n * 4), (lay.off_weights, 512)]
+        for off, size in sections:
+            assert np.array_equal(back[off:off + size], plain[off:off + size]), (off, size)
+        hdr = N.CompactHdr.from_buffer_copy(comp[:128].tobytes())
+        assert hdr.n_lists == (2 if p.desc.slice_type == N.SLICE_B else 1)
+        shape_bits = comp[hdr.list[0].off_shape:hdr.list[0].off_shape + (n + 3) // 4]
         shapes |= {int((shape_bits[i >> 2] >> (2 * (i & 3))) & 3) for i in range(n)}
         assert comp.size < plain.size
         # tampering: a shape bit, a count, the size
-        for off, what in ((int(hdr[6]), "shape"), (44, "n_vec"), (12, "bytes")):
+        for off, what in ((int(hdr.list[0].off_shape), "shape"), (N.CompactHdr.list.offset + 12, "n_vec"), (12, "bytes")):
             bad = comp.copy()
             bad[off] ^= 1
             assert lib.p264hip_compact_check(C.byref(p.desc), bad.ctypes.data, bad.size) != 0, what
-    assert shapes == {0, 1, 2, 3}
-
-
-def test_compact_format_refuses_b_pictures(lib):
-    import ctypes as C
-    import numpy as np
-    pics = Parser(quiet=True).parse_stream(synth_cases.stream_bytes(B_CIF))
-    b = [p for p in pics if p.desc.slice_type == 1][0]
-    buf = np.zeros(lib.p264hip_compact_bound(C.byref(b.desc)), np.uint8)
-    assert lib.p264hip_pack_compact(C.byref(b.desc), buf.ctypes.data, buf.size) < 0
+    assert shapes == {0, 1, 2, 3} and n_b >= 5

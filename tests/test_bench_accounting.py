@@ -46,3 +46,13 @@ def test_a_counter_summary_of_other_kernels_is_not_replayed(monkeypatch, capsys)
 def test_kernel_fingerprint_follows_the_sources(tmp_path, monkeypatch):
     a = bench.kernel_fingerprint()
     assert len(a) == 64 and a == bench.kernel_fingerprint()
+
+
+def test_the_committed_counter_summary_belongs_to_these_kernels():
+    """profiles/traffic_latest.json is the fall-back of roofline.traffic where the run cannot count for itself (N > 1, no
+    rocprofv3): it must have been collected on the kernels in the tree (profiles/collect.sh + summarize.py after the last change
+    under csrc/hip)."""
+    import json
+    import os
+    tj = json.load(open(os.path.join(bench.ROOT, "profiles", "traffic_latest.json")))
+    assert tj.get("kernels_sha256") == bench.kernel_fingerprint(), "csrc/hip changed since profiles/%s was collected: run profiles/collect.sh + summarize.py" % tj.get("source")

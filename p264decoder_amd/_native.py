@@ -147,6 +147,8 @@ def load(path=None):
         lib.p264hip_pack_compact.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t]
         lib.p264hip_expand_compact.restype = C.c_int
         lib.p264hip_expand_compact.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        lib.p264hip_compact_header_ok.restype = C.c_int
+        lib.p264hip_compact_header_ok.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t]
         lib.p264hip_compact_check.restype = C.c_int
         lib.p264hip_compact_check.argtypes = [C.POINTER(Picture), C.c_void_p, C.c_size_t]
         lib.p264hip_upload_compact.restype = C.c_int

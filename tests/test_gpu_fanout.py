@@ -350,3 +350,44 @@ def test_compact_uploads_match_the_plain_upload(lib):
         assert frame_sha256(*hip.read_frame(0, p.desc.dst_slot)) == hashes[i], "1080p picture %d through the compact format" % i
     hip.close()
     assert all(c < 0.45 * f for c, f in sizes[1:]), sizes          # a P picture of the bench's kind: well under half its slot layout
+
+
+def test_an_inconsistent_compact_block_is_a_wrong_picture_not_a_fault(lib):
+    """p264hip_upload_compact checks a block's HEADER; what the block's bits imply is clamped to the block's sections on the device
+    (kernel_expand.h).  Blocks whose header is fine but whose shape / flag bits claim far more vectors, mode entries and 16-bit
+    levels than their sections hold must go through upload + expansion + reconstruction without an error from the device, and the
+    context must decode the intact block right afterwards.  (p264hip_compact_check refuses every one of them: an untrusted
+    producer's blocks go through it first.)"""
+    import ctypes as C
+    import numpy as np
+    from p264decoder_amd import HipReconstructor, Parser, _native as N
+    parser = Parser(quiet=True, lib=lib)
+    pics = parser.parse_stream(synth_cases.stream_bytes("cif_ip"))[:3]
+    hip = HipReconstructor(pics[0].mb_w, pics[0].mb_h, n_streams=2, slots=parser.slots, max_pictures=2, lib=lib)
+    for p in pics:
+        good = HipReconstructor.pack_compact(p, lib)
+        hdr = N.CompactHdr.from_buffer_copy(good[:128].tobytes())
+        n = p.desc.mb_w * p.desc.mb_h
+        for what, lo, size, value in (("every macroblock sixteen vectors", hdr.list[0].off_shape, (n + 3) // 4, 0xff),
+                                      ("every macroblock an Intra4x4 entry", hdr.off_i4flag, (n + 7) // 8, 0xff),
+                                      ("every block sixteen-bit levels", hdr.off_lvflag, (p.desc.n_coef_blocks + 7) // 8, 0x00),
+                                      ("every block eight-bit levels", hdr.off_lvflag, (p.desc.n_coef_blocks + 7) // 8, 0xff)):
+            bad = good.copy()
+            bad[lo:lo + size] = value
+            if what == "every block eight-bit levels" and hdr.level_bytes == 16 * p.desc.n_coef_blocks:
+                continue                                       # (every block of this picture is narrow already: only padding bits would change)
+            assert lib.p264hip_compact_header_ok(C.byref(p.desc), bad.ctypes.data, bad.size) == 1, what
+            assert lib.p264hip_compact_check(C.byref(p.desc), bad.ctypes.data, bad.size) != 0, what
+            hip.upload_compact(1, p, bad)
+            hip.reconstruct([1], [1])                          # a wrong picture in stream 1's store; no fault, no error
+            hip.sync()
+        hip.upload(0, [p])
+        hip.upload_compact(1, p, good)
+        # stream 1's store holds garbage references by now: give both streams the same ones
+        for slot in range(parser.slots):
+            hip.write_frame(1, slot, *hip.read_frame(0, slot))
+        hip.reconstruct([0, 1], [0, 1])
+        hip.sync()
+        for a, b in zip(hip.read_frame(0, p.desc.dst_slot), hip.read_frame(1, p.desc.dst_slot)):
+            assert np.array_equal(a, b)
+    hip.close()

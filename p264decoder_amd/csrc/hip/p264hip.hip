@@ -56,6 +56,7 @@ struct PicSlot {                       // one device-resident parsed picture
     bool     valid = false, reserved = false;   // reserved: p264hip_input_reserve handed the block out, commit is pending
     uint8_t *stage = nullptr; size_t stage_cap = 0;   // p264hip_upload_compact: the compact block as it arrived; pending: its expansion into dev has not been launched yet
     bool     pending = false;
+    int      stage_cs = 0;                            // the side stream that carried the pending block (a second block for the same slot follows on the same one)
     bool     unchecked = false;                  // committed by a device producer: the record check (k_check_records) has been queued, its verdict not yet read
     uint64_t last_use = 0;                       // epoch of the last work queued on the context's stream that reads or writes the block
 };
@@ -410,7 +411,10 @@ extern "C" int p264hip_upload_compact(p264hip_ctx *c, int slot, const p264hip_pi
         if (e != hipSuccess) return fail(P264HIP_ENOMEM, "hipMalloc(%zu) for a compact picture: %s", cap, hipGetErrorString(e));
         s.stage_cap = cap;
     }
-    const int cs = c->next_cs; c->next_cs = (c->next_cs + 1) % COPY_STREAMS;
+    // (a slot whose block is still waiting for its expansion gets the newer block on the SAME side stream: two copies into one
+    // staging area on two streams would land in any order)
+    int cs = s.stage_cs;
+    if (!s.pending) { cs = c->next_cs; c->next_cs = (c->next_cs + 1) % COPY_STREAMS; s.stage_cs = cs; }
     if (!c->cstream[cs]) {
         HIPCHK(hipStreamCreateWithFlags(&c->cstream[cs], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->cdone[cs], hipEventDisableTiming));

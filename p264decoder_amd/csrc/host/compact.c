@@ -14,7 +14,7 @@ size_t p264hip_compact_bound(const p264hip_picture_t *p)
     if (!p || p->mb_w < 1 || p->mb_h < 1) return 0;
     const size_t n = (size_t)p->mb_w * (size_t)p->mb_h, lists = p->slice_type == P264_SLICE_B ? 2 : 1;
     return sizeof(p264hip_compact_hdr_t) + n * 16 + 16 + lists * (n * 4 + 16 + n / 4 + 32 + n * 64 + 16) + n / 8 + 32 + n * 16 + 16
-           + (size_t)p->n_coef_blocks / 8 + 32 + (size_t)p->n_coef_blocks * 32 + 16 + 512 + 16;
+           + (size_t)p->n_coef_blocks / 8 + 32 + (size_t)p->n_coef_blocks * 32 + 64 + 512 + 64;
 }
 
 /* 0 sixteen zero vectors, 1 one vector, 2 one per 8x8 quadrant, 3 sixteen */

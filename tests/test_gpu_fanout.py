@@ -296,6 +296,9 @@ def test_compact_uploads_match_the_plain_upload(lib):
         if i == 3:                                              # superseded before it was expanded: the plain upload must win
             hip.upload_compact(1, pics[0], HipReconstructor.pack_compact(pics[0], lib))
             hip.upload(1, [p])
+        if i == 5:                                              # two compact blocks for one slot, no expansion in between: the later one counts
+            hip.upload_compact(2, pics[0], HipReconstructor.pack_compact(pics[0], lib))
+            hip.upload_compact(2, p, blk)
         hip.clone_picture(S, 2)                                 # (expands what is pending first)
         hip.reconstruct([0, 1, 2, S], [0, 1, 2, S])
         hip.sync()

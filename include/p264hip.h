@@ -181,8 +181,10 @@ int  p264hip_upload_packed(p264hip_ctx *ctx, int slot, const p264hip_picture_t *
  *   B pictures: the same for list 1, and the 512 bytes of bipred_weight[].
  * Nothing is lost: p264hip_expand_compact (host; the reference of the device kernel) gives back the slot layout byte for byte
  * (p264hip_pack_input's block, up to the padding between its sections).
- * p264hip_upload_compact copies the block into a staging area of the slot (one asynchronous copy) and queues its expansion:
- * ONE kernel expands every picture uploaded since the last one, in front of the next p264hip_reconstruct (or clone / sync).
+ * p264hip_upload_compact copies the block into a staging area of the slot (one asynchronous copy, on a side stream of the context)
+ * and queues its expansion: ONE kernel expands every picture uploaded since the last one, in front of the next
+ * p264hip_reconstruct (or clone / sync), which also is where the context's stream starts to wait for the copies - the caller's
+ * block must stay untouched until a marker taken AFTER that call has been reached (or p264hip_sync has returned).
  * Like p264hip_upload_packed the call trusts the block to come from the packer (which checks the records as p264hip_upload
  * does): it checks the header (O(1): p264hip_compact_header_ok - sections inside the block, in order, large enough for the
  * header's counts) and the device clamps every place it derives from the block's bits to its section - an inconsistent block

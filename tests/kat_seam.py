@@ -71,7 +71,7 @@ def pred16_case(tile, fn_index, seed):
     3 plane, 4 DC_LEFT, 5 DC_TOP, 6 DC_128).  Returns (picture, reference frame [y, u, v])."""
     mb_w, mb_h = PRED_SHAPE
     ref = _noise_frame(np.random.RandomState(seed), mb_w, mb_h)
-    ref[0][15, 15:48] = tile[0, :33][:33] if tile.shape[1] >= 33 else np.concatenate([tile[0], ref[0][15, 15 + tile.shape[1]:48]])[:33]
+    ref[0][15, 15:47] = tile[0, :32]                      # corner, the sixteen samples above, and what the tile holds to their right
     ref[0][16:32, 15] = tile[1:17, 0]
     pic = base_picture(mb_w, mb_h)
     r = pic.rec[TARGET]

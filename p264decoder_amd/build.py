@@ -20,7 +20,9 @@ TOOLS_DIR = os.path.join(HERE, "tools")
 
 HOST_SRCS = ["parser.c", "vlc.c", "cabac.c", "dropin.c", "pipeline.c", "fanout.c", "input_layout.c", "compact.c", "cpu_check.c"]
 HOST_BASELINE = {"cpu_check.c"}      # built WITHOUT HOST_ARCH: its constructor looks at the CPU before any x86-64-v3 code runs
-HIP_SRCS = ["p264hip.hip", "fan_rccl.hip"]
+HIP_SRCS = ["p264hip.hip", "k_deblock.hip", "fan_rccl.hip"]
+# options of single translation units (k_deblock.hip: the backend's max-ILP scheduling strategy - kernel_deblock.h says why)
+HIP_EXTRA = {"k_deblock.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 HIP_ARCH = "gfx950"
 # host code for AVX2 / BMI2 machines (every EPYC; the GPU boxes are Zen 5): the CABAC parse gains 4.5 % per thread, CAVLC
 # nothing (scratch/r5_parse_flags.sh; -march=znver3, -O2 and a profile-guided build all lose on CAVLC).  p264parse_open refuses
@@ -74,8 +76,8 @@ def build(force=False, verbose=False):
         src = os.path.join(HIP_DIR, s)
         obj = os.path.join(OBJ_DIR, s + ".o")
         if force or _newer(obj, [src] + hdrs):
-            out = _run([hipcc, "--offload-arch=" + HIP_ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall",
-                        "-I" + INC, "-I" + HIP_DIR, "-c", src, "-o", obj])
+            out = _run([hipcc, "--offload-arch=" + HIP_ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall"] + HIP_EXTRA.get(s, []) +
+                       ["-I" + INC, "-I" + HIP_DIR, "-c", src, "-o", obj])
             if verbose and out:
                 print(out)
         objs.append(obj)

@@ -57,7 +57,7 @@
 #ifndef EXPD_NO_SAMPLE_LOADS
 #define EXPD_NO_SAMPLE_LOADS 0     // 1: the macroblock's own samples are not loaded (round 5: what a fused prediction + filter pass could save at most)
 #endif
-#ifdef EXPD_STAMPS
+#if defined(EXPD_STAMPS) && !defined(P264HIP_K_DEBLOCK_DECL_ONLY)
 // in-kernel clock stamps of one wavefront (diagnostic build only: scratch/r4_stamps.sh)
 __device__ unsigned long long g_db_stamps[256 * 8];
 #define DB_STAMP(k) do { if (stamp_me && t < 256) g_db_stamps[t * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -479,6 +479,14 @@ struct OctLds {                    // per octet: 252 dwords (= 28 modulo 32: the
 #define MAX_PICS_PER_WG 16             // pictures one workgroup serves (in groups of as many as a wavefront holds)
 #define MAX_BANDS (MAX_MB_ROWS / 2)
 
+// The kernel is DEFINED in a translation unit of its own (k_deblock.hip, round 6) and only declared where it is launched
+// (p264hip.hip defines P264HIP_K_DEBLOCK_DECL_ONLY): that unit is compiled with the backend's max-ILP scheduling strategy
+// (-mllvm -amdgpu-sched-strategy=max-ilp, build.py), which suits this kernel - one long dependent iteration per wavefront, no
+// spills at 115 registers: 0.833 -> 0.803 ms at 256 pictures per launch - and none of the others (k_intra_sparse spills under it,
+// 0.79 -> 0.91 ms; k_mc is unchanged).  The option is per compilation, there is no per-function form a HIP source can spell.
+#ifdef P264HIP_K_DEBLOCK_DECL_ONLY
+__global__ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status, int n_pics, int rb_log2_, int pics_per_wg, int odd_single);
+#else
 __global__ __launch_bounds__(ROW_WAVES * 64)
 void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restrict__ info, int *status, int n_pics, int rb_log2_, int pics_per_wg, int odd_single)
 {
@@ -804,3 +812,4 @@ void k_deblock(const PicDev *__restrict__ pics, Geom g_, const EdgeInfo *__restr
         wave_lds_fence();
     }
 }
+#endif   // P264HIP_K_DEBLOCK_DECL_ONLY

@@ -14,6 +14,7 @@
 #include <unordered_map>
 #include "p264hip.h"
 #include "device_common.h"
+#define P264HIP_K_DEBLOCK_DECL_ONLY          // k_deblock lives in k_deblock.hip (its own compiler options: kernel_deblock.h)
 #include "kernel_deblock.h"
 #include "kernel_mc.h"
 #include "kernel_intra.h"
@@ -852,13 +853,16 @@ static int drain_stamps(p264hip_ctx *c)
     return 0;
 }
 
+#ifdef EXPD_STAMPS
+extern "C" int p264hip_db_stamps_read(unsigned long long *h, size_t bytes);     // k_deblock.hip
+#endif
 extern "C" int p264hip_sync(p264hip_ctx *c)
 {
 #ifdef EXPD_STAMPS
     if (const char *path = getenv("P264AMD_STAMPS_OUT")) {     // diagnostic build: the clock stamps of one k_deblock wavefront
         static unsigned long long h[256 * 8];
         (void)hipDeviceSynchronize();
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_db_stamps), sizeof h) == hipSuccess) {
+        if (p264hip_db_stamps_read(h, sizeof h) == 0) {
             FILE *f = fopen(path, "w");
             if (f) { for (int i = 0; i < 256; i++) { for (int k = 0; k < 8; k++) fprintf(f, "%llu ", h[i * 8 + k]); fprintf(f, "\n"); } fclose(f); }
         }

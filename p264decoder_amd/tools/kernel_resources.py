@@ -34,7 +34,7 @@ def short_name(mangled):
 
 
 def kernel_resources(lib_path):
-    """{kernel name: {field: int}} for the gfx950 code object bundled in `lib_path`."""
+    """{kernel name: {field: int}} for the gfx950 code objects bundled in `lib_path`."""
     tmp = tempfile.mkdtemp(prefix="p264res_")
     try:
         local = os.path.join(tmp, "lib.so")
@@ -43,7 +43,8 @@ def kernel_resources(lib_path):
         objs = [f for f in os.listdir(tmp) if "gfx950" in f]
         if not objs:
             raise RuntimeError("no gfx950 code object in %s" % lib_path)
-        notes = subprocess.run([_tool("llvm-readelf"), "--notes", objs[0]], cwd=tmp, check=True, stdout=subprocess.PIPE, text=True).stdout
+        # (one code object per translation unit: p264hip.hip, k_deblock.hip - built with its own options since round 6 -, fan_rccl.hip)
+        notes = "\n".join(subprocess.run([_tool("llvm-readelf"), "--notes", o], cwd=tmp, check=True, stdout=subprocess.PIPE, text=True).stdout for o in sorted(objs))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {}

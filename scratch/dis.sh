@@ -5,7 +5,8 @@ mkdir -p $out
 d=$(mktemp -d)
 cp $lib $d/l.so
 (cd $d && /opt/rocm/lib/llvm/bin/llvm-objdump --offloading l.so > /dev/null)
-/opt/rocm/lib/llvm/bin/llvm-objdump -d --no-show-raw-insn $d/l.so.0.hipv4-amdgcn-amd-amdhsa--gfx950 | sed 's/ *\/\/ [0-9A-F]*:.*$//' > $out/all.s
+# (one code object per translation unit since round 6: all of them)
+for o in $d/l.so.*gfx950; do /opt/rocm/lib/llvm/bin/llvm-objdump -d --no-show-raw-insn $o | sed 's/ *\/\/ [0-9A-F]*:.*$//'; done > $out/all.s
 python3 - $out <<'PY'
 import re, sys
 out = sys.argv[1]

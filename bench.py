@@ -535,7 +535,7 @@ def cpu_baseline_n(stream_path, n_procs, loops=12):
 
 
 def kernel_fingerprint():
-    """SHA-256 over the HIP sources (csrc/hip/*, names and contents): what a counter summary under profiles/ was collected on.
+    """SHA-256 over the HIP sources (csrc/hip/*, names and contents) and their compiler options: what a counter summary under profiles/ was collected on.
     profiles/summarize.py stamps traffic_latest.json with it; a summary of other kernels is STALE and is not replayed."""
     import hashlib
     d = os.path.join(ROOT, "p264decoder_amd", "csrc", "hip")
@@ -543,6 +543,9 @@ def kernel_fingerprint():
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip")):
             h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read() + b"\0")
+    # (and how they are compiled: since round 6 a translation unit can have options of its own - build.py: HIP_EXTRA)
+    from p264decoder_amd import build as _build
+    h.update(repr((_build.HIP_ARCH, sorted(_build.HIP_EXTRA.items()))).encode())
     return h.hexdigest()
 
 
